@@ -1,0 +1,196 @@
+"""Model import: scikit-learn forests / trees and XGBoost-style JSON -> flat node tables.
+
+The reference hands a pickled dict of named models from train_models_pipeline to
+filter_variants_pipeline (`--model_file`, `--model_name`: docs/filter_variants_pipeline.md:26-29;
+names such as `rf_model_ignore_gt_incl_hpol_runs`: docs/howto-callset-filter.md:114; libs
+scikit-learn / xgboost: setup/environment.yml:399,354).  The engine wants plain arrays, so
+this module flattens estimators into `schema.FlatForest` (pointer layout) - host logic only.
+"""
+from __future__ import annotations
+
+import json
+import pickle
+
+import numpy as np
+
+from . import schema as S
+
+
+def f32_floor(thr64: np.ndarray) -> np.ndarray:
+    """Largest float32 <= each float64 threshold.
+
+    scikit-learn compares a float32 feature with a float64 threshold (`X[i, f] <= thr`);
+    for every float32 x:  x <= thr64  <=>  x <= f32_floor(thr64), so the f32 table decides
+    identically (bit-exact FILTER) at half the node size."""
+    t = thr64.astype(np.float32)
+    over = t.astype(np.float64) > thr64
+    t[over] = np.nextafter(t[over], np.float32(-np.inf))
+    return t
+
+
+def f32_ceil(thr64: np.ndarray) -> np.ndarray:
+    """Smallest float32 >= each float64 threshold (x < thr64 <=> x < f32_ceil(thr64))."""
+    t = thr64.astype(np.float32)
+    under = t.astype(np.float64) < thr64
+    t[under] = np.nextafter(t[under], np.float32(np.inf))
+    return t
+
+
+def _depth(left, right, feature, root):
+    best, stack = 0, [(root, 0)]
+    while stack:
+        i, d = stack.pop()
+        if feature[i] < 0:
+            best = max(best, d)
+        else:
+            stack.append((left[i], d + 1))
+            stack.append((right[i], d + 1))
+    return best
+
+
+def flatten_sklearn(model, n_features: int | None = None) -> S.FlatForest:
+    """RandomForestClassifier / ExtraTrees / DecisionTreeClassifier (binary) -> FlatForest."""
+    ests = list(model.estimators_) if hasattr(model, "estimators_") else [model]
+    classes = list(getattr(model, "classes_", [0, 1]))
+    if len(classes) > 2:
+        raise ValueError("only binary (fp/tp) classifiers are supported")
+    feats, thrs, lefts, rights, roots, leaves = [], [], [], [], [], []
+    node_base = leaf_base = 0
+    depth = 0
+    for e in ests:
+        t = e.tree_
+        n = t.node_count
+        is_leaf = t.children_left == -1
+        leaf_id = np.cumsum(is_leaf) - 1 + leaf_base
+        feat = np.where(is_leaf, -1, t.feature).astype(np.int32)
+        left = np.where(is_leaf, leaf_id, t.children_left + node_base).astype(np.int32)
+        right = np.where(is_leaf, 0, t.children_right + node_base).astype(np.int32)
+        thr = np.where(is_leaf, 0.0, t.threshold)
+        val = t.value[is_leaf, 0, :]
+        if val.shape[1] == 1:                       # single-class tree
+            only = int(e.classes_[0]) if hasattr(e, "classes_") else 0
+            full = np.zeros((val.shape[0], 2))
+            full[:, 1 if only == classes[-1] and len(classes) == 2 else 0] = val[:, 0]
+            val = full
+        feats.append(feat); thrs.append(f32_floor(thr)); lefts.append(left); rights.append(right)
+        roots.append(node_base); leaves.append(val.astype(np.float64))
+        depth = max(depth, int(t.max_depth))
+        node_base += n
+        leaf_base += int(is_leaf.sum())
+    nf = n_features or int(getattr(model, "n_features_in_", 0))
+    return S.FlatForest(S.MODEL_RF, np.concatenate(feats), np.concatenate(thrs),
+                        np.concatenate(lefts), np.concatenate(rights),
+                        np.array(roots, dtype=np.int32), np.concatenate(leaves, axis=0),
+                        n_features=nf, max_depth=depth)
+
+
+def flatten_xgb_json(doc: dict | str) -> S.FlatForest:
+    """XGBoost `save_model(...json)` document (binary:logistic) -> FlatForest (MODEL_GBT).
+
+    xgboost itself is not installable here; the JSON schema fields used are
+    learner.gradient_booster.model.trees[*].{split_indices, split_conditions, left_children,
+    right_children, base_weights} and learner.learner_model_param.base_score."""
+    if isinstance(doc, str):
+        doc = json.loads(doc)
+    learner = doc["learner"]
+    base = float(learner["learner_model_param"]["base_score"])
+    base = min(max(base, 1e-7), 1 - 1e-7)
+    margin0 = float(np.log(base / (1.0 - base)))
+    feats, thrs, lefts, rights, roots, leaves = [], [], [], [], [], []
+    nb = lb = 0
+    for tr in learner["gradient_booster"]["model"]["trees"]:
+        lc = np.asarray(tr["left_children"], dtype=np.int64)
+        rc = np.asarray(tr["right_children"], dtype=np.int64)
+        is_leaf = lc == -1
+        leaf_id = np.cumsum(is_leaf) - 1 + lb
+        feat = np.where(is_leaf, -1, np.asarray(tr["split_indices"])).astype(np.int32)
+        cond = np.asarray(tr["split_conditions"], dtype=np.float64)
+        thr = np.where(is_leaf, 0.0, cond).astype(np.float32)   # xgboost stores f32 already
+        left = np.where(is_leaf, leaf_id, lc + nb).astype(np.int32)
+        right = np.where(is_leaf, 0, rc + nb).astype(np.int32)
+        val = np.zeros((int(is_leaf.sum()), 2))
+        val[:, 0] = cond[is_leaf].astype(np.float32)            # leaf value lives in split_conditions
+        feats.append(feat); thrs.append(thr); lefts.append(left); rights.append(right)
+        roots.append(nb); leaves.append(val)
+        nb += lc.size
+        lb += int(is_leaf.sum())
+    f = S.FlatForest(S.MODEL_GBT, np.concatenate(feats), np.concatenate(thrs),
+                     np.concatenate(lefts), np.concatenate(rights), np.array(roots, dtype=np.int32),
+                     np.concatenate(leaves, axis=0),
+                     n_features=int(learner["learner_model_param"]["num_feature"]),
+                     base_score=margin0)
+    f.max_depth = max(_depth(f.left, f.right, f.feature, int(r)) for r in f.tree_root)
+    return f
+
+
+def make_gbt(trees: list, n_features: int, base_margin: float = 0.0) -> S.FlatForest:
+    """Build a MODEL_GBT FlatForest from (feature, threshold, left, right, value) array tuples
+    (children -1 at leaves) - used for the XGBoost-shaped C5 ensemble."""
+    doc_trees = []
+    for feat, thr, lc, rc, val in trees:
+        cond = np.where(np.asarray(lc) == -1, val, thr)
+        doc_trees.append(dict(split_indices=list(map(int, np.maximum(feat, 0))),
+                              split_conditions=[float(np.float32(c)) for c in cond],
+                              left_children=list(map(int, lc)), right_children=list(map(int, rc))))
+    p = 1.0 / (1.0 + np.exp(-base_margin))
+    doc = dict(learner=dict(learner_model_param=dict(base_score=str(p), num_feature=str(n_features)),
+                            gradient_booster=dict(model=dict(trees=doc_trees))))
+    return flatten_xgb_json(doc)
+
+
+# ---------------------------------------------------------------- persistence of flat models
+def save_models(path: str, models: dict, meta: dict | None = None) -> None:
+    """{name: [FlatForest per group]} -> one .npz (the frozen synthetic model of SURVEY.md §8(d))."""
+    out = {"__meta__": np.frombuffer(json.dumps(meta or {}).encode(), dtype=np.uint8)}
+    names = []
+    for name, groups in models.items():
+        names.append(name)
+        for g, f in enumerate(groups):
+            p = f"{name}/{g}/"
+            out[p + "hdr"] = np.array([f.kind, f.n_features, f.max_depth], dtype=np.int64)
+            out[p + "base"] = np.array([f.base_score], dtype=np.float64)
+            for k in ("feature", "threshold", "left", "right", "tree_root", "leaf_value"):
+                out[p + k] = getattr(f, k)
+    out["__names__"] = np.frombuffer("\n".join(names).encode(), dtype=np.uint8)
+    np.savez_compressed(path, **out)
+
+
+def load_models(path: str) -> dict:
+    z = np.load(path)
+    names = bytes(z["__names__"]).decode().split("\n")
+    models = {}
+    for name in names:
+        groups = []
+        for g in range(S.N_GROUPS):
+            p = f"{name}/{g}/"
+            if p + "hdr" not in z:
+                break
+            kind, nf, md = (int(x) for x in z[p + "hdr"])
+            groups.append(S.FlatForest(kind, z[p + "feature"], z[p + "threshold"], z[p + "left"],
+                                       z[p + "right"], z[p + "tree_root"], z[p + "leaf_value"],
+                                       n_features=nf, base_score=float(z[p + "base"][0]), max_depth=md))
+        models[name] = groups
+    return models
+
+
+def load_model_file(path: str, model_name: str | None = None):
+    """`--model_file` / `--model_name`: a .npz of flat models, or a pickle holding a dict of
+    {name: model}; a model is either [estimator per group] / {group_name: estimator} or one
+    estimator used for every group."""
+    if path.endswith(".npz"):
+        models = load_models(path)
+    else:
+        with open(path, "rb") as fh:
+            raw = pickle.load(fh)
+        models = {}
+        for name, m in (raw.items() if isinstance(raw, dict) else [("model", raw)]):
+            if isinstance(m, dict):
+                m = [m[g] for g in S.GROUP_NAMES]
+            if not isinstance(m, (list, tuple)):
+                m = [m] * S.N_GROUPS
+            models[name] = [x if isinstance(x, S.FlatForest) else flatten_sklearn(x) for x in m]
+    if model_name is None:
+        return models
+    if model_name not in models:
+        raise KeyError(f"model {model_name!r} not in {path}; available: {sorted(models)}")
+    return models[model_name]
