@@ -1,0 +1,187 @@
+/* ugvc_mi355x.h - C ABI of the MI355X-native post-GATK variant-filtering engine.
+ *
+ * Drop-in boundary for the hot path of `ugvc filter_variants_pipeline` /
+ * `train_models_pipeline` (featurize -> interval/blacklist lookup -> tree-ensemble score ->
+ * FILTER).  The reference has NO native boundary for this path: its contract is a Python
+ * module with run(argv) (/root/reference/ugvc/__main__.py:42-56,103-105) whose body calls, per
+ * VCF, the pandas functions listed next to each entry point below (bodies live in the
+ * un-vendored submodule ugbio_utils; cited by call site).  This header is therefore the
+ * BUILDER-DEFINED FFI a maintainer binds with ctypes: plain pointers and
+ * sizes, caller owns every host buffer, opaque context handle, int return codes.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; ugvc_last_error() gives the message
+ *     (thread-local).  Reference behaviour is Python exceptions (e.g.
+ *     ugvc/comparison/quick_fingerprinter.py:134-135); the Python shim raises RuntimeError.
+ *   - all table pointers are HOST pointers to contiguous column arrays (numpy); the library
+ *     copies to HBM and never frees or retains caller memory.
+ *   - one host thread per context; kernels run on the context's own HIP stream; calls are
+ *     synchronous unless stated.
+ *   - base codes: N=0 A=1 C=2 G=3 T=4.  POS is the 1-based VCF position.  Variants must be
+ *     sorted by (contig, pos).
+ */
+#ifndef UGVC_MI355X_H
+#define UGVC_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UGVC_ABI_VERSION 1
+#define UGVC_MAX_TRACKS 5
+#define UGVC_N_GROUPS 3          /* snp, h-indel, non-h-indel */
+#define UGVC_N_BASE_FEATURES 17  /* + one per annotation track; order: schema.BASE_FEATURES */
+#define UGVC_MODEL_RF 0          /* sklearn forest: x <= thr, mean of f64 leaf fractions      */
+#define UGVC_MODEL_GBT 1         /* XGBoost-style:  x <  thr, f32 additive margin + sigmoid   */
+
+#define UGVC_FILTER_PASS 0
+#define UGVC_FILTER_LOW_SCORE 1
+#define UGVC_FLAG_HPOL_RUN 1
+#define UGVC_FLAG_COHORT_FP 2
+#define UGVC_FLAG_SEC 4
+#define UGVC_FLAG_TRACK0_SHIFT 3
+
+typedef struct ugvc_ctx ugvc_ctx;
+
+/* Variant table, one column per array (replaces the DataFrame built by
+ * ugbio_core.vcfbed.vcftools.get_vcf_df: call sites ugvc/pipelines/run_no_gt_report.py:307-312,
+ * shape ugvc/reports/report_wo_gt.ipynb:1207-1210). */
+typedef struct ugvc_variants {
+    int64_t n;
+    const uint8_t* contig;    /* contig index into the uploaded reference                  */
+    const int32_t* pos;       /* 1-based                                                   */
+    const uint16_t* ref_len;
+    const uint16_t* alt_len;
+    const uint32_t* ref_off;  /* offsets into `alleles`                                    */
+    const uint32_t* alt_off;
+    const uint8_t* alleles;   /* pool of base codes                                        */
+    int64_t alleles_len;
+    const float* qual;        /* QUAL (or 10*TLOD for --is_mutect, set by the host)        */
+    const float* sor;         /* INFO/SOR                                                  */
+    const int32_t* dp;        /* FORMAT/DP                                                 */
+    const int32_t* ad_ref;    /* FORMAT/AD[0]                                              */
+    const int32_t* ad_alt;    /* FORMAT/AD[1]                                              */
+    const uint8_t* gq;        /* FORMAT/GQ                                                 */
+} ugvc_variants;
+
+/* Per-variant outputs (replaces the FILTER / TREE_SCORE / HPOL_RUN / COHORT_FP columns the
+ * reference writes back per record: docs/howto-callset-filter.md:65,
+ * ugvc/pipelines/evaluate_concordance.py:47). */
+typedef struct ugvc_results {
+    float* tree_score;        /* TREE_SCORE                                                */
+    uint8_t* filter;          /* UGVC_FILTER_*                                             */
+    uint8_t* flags;           /* UGVC_FLAG_* | track bits                                  */
+} ugvc_results;
+
+/* Pileup tally outputs (builder-defined; the reference reads FORMAT/AD, DP, SB, VAF, INFO/SOR
+ * pre-computed by the caller: test/resources/unit/vcfbed/test_vcftools/header.txt:3379,3391-3398). */
+typedef struct ugvc_pileup_out {
+    int32_t* ref_fwd; int32_t* ref_rev; int32_t* alt_fwd; int32_t* alt_rev;
+    int32_t* other;   int32_t* dp;      int32_t* bq_ref;  int32_t* bq_alt;
+    float* vaf;       float* sor;
+} ugvc_pileup_out;
+
+int ugvc_abi_version(void);
+const char* ugvc_last_error(void);
+
+/* ---- context ------------------------------------------------------------------------- */
+int ugvc_ctx_create(int device_id, ugvc_ctx** out);
+int ugvc_ctx_destroy(ugvc_ctx* ctx);
+int ugvc_device_info(ugvc_ctx* ctx, char* name, int name_cap, int* n_cus, int64_t* hbm_bytes);
+int ugvc_sync(ugvc_ctx* ctx);
+
+/* ---- resident side tables --------------------------------------------------------------
+ * ugvc_ref_upload: `--reference_file` (docs/filter_variants_pipeline.md:38-39); replaces the
+ *   per-row pyfaidx fetches (pattern: ugvc/pipelines/vcfbed/calibrate_bridging_snvs.py:28-30).
+ * ugvc_runs_upload: `--runs_file` + `--hpol_filter_length_dist L D` (docs/...md:30-33);
+ *   runs shorter than min_len are dropped on upload; mark_hpol=0 keeps the two features but
+ *   never sets UGVC_FLAG_HPOL_RUN.
+ * ugvc_track_upload: one `--annotate_intervals` BED (docs/...md:45-46), track_id < UGVC_MAX_TRACKS.
+ * ugvc_blacklist_upload: `--blacklist` loci as sorted unique u64 keys contig<<32|pos (docs/...md:34-35).
+ * ugvc_model_upload: one model of the `--model_file` dict entry `--model_name`, flattened
+ *   (docs/...md:26-29; variantcalling_amd/model_io.py); one call per group.
+ *   node i: feature[i] < 0 -> leaf with payload row left[i]; else left/right child indices.
+ *   leaf_value: n_leaves x 2 doubles (RF: class fractions; GBT: margin, 0). */
+int ugvc_ref_upload(ugvc_ctx* ctx, const uint8_t* codes, int64_t total_len,
+                    const int64_t* contig_off, int n_contigs);
+int ugvc_runs_upload(ugvc_ctx* ctx, const int32_t* starts, const int32_t* ends,
+                     const int32_t* contig_ptr, int64_t n, int min_len, int max_dist, int mark_hpol);
+int ugvc_track_upload(ugvc_ctx* ctx, int track_id, const int32_t* starts, const int32_t* ends,
+                      const int32_t* contig_ptr, int64_t n);
+int ugvc_set_n_tracks(ugvc_ctx* ctx, int n_tracks);
+int ugvc_blacklist_upload(ugvc_ctx* ctx, const uint64_t* keys, int64_t n);
+int ugvc_set_flow_order(ugvc_ctx* ctx, const char* flow4 /* e.g. "TGCA" */);
+int ugvc_model_upload(ugvc_ctx* ctx, int group, int kind, const int32_t* feature,
+                      const float* threshold, const int32_t* left, const int32_t* right,
+                      int32_t n_nodes, const int32_t* tree_root, int32_t n_trees,
+                      const double* leaf_value, int32_t n_leaves, int32_t n_features,
+                      float base_score, int32_t max_depth);
+
+/* ---- the hot path ----------------------------------------------------------------------
+ * ugvc_filter_variants: annotate_concordance + blacklist apply + model predict + FILTER
+ *   (call pattern ugvc/pipelines/run_no_gt_report.py:92-94,314).
+ *   Synchronous: H2D of the columns, one fused kernel, D2H of the three result columns.
+ * Resident form (inputs stay in HBM; used by bench.py and for pipelining):
+ *   ugvc_variants_upload -> ugvc_filter_resident (async launch) -> ugvc_results_download.
+ * ugvc_timed_filter: `iters` back-to-back launches bracketed by hipEvents on the context
+ *   stream; returns total milliseconds (kernel time only, inputs resident).
+ * ugvc_feature_matrix: the N x F float32 feature matrix (row-major) train_models_pipeline
+ *   fits on (docs/train_models_pipeline.md:5-10); group[i] in {0,1,2} optional (may be NULL). */
+int ugvc_filter_variants(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_results* out);
+int ugvc_variants_upload(ugvc_ctx* ctx, const ugvc_variants* v);
+int ugvc_filter_resident(ugvc_ctx* ctx);
+int ugvc_results_download(ugvc_ctx* ctx, const ugvc_results* out);
+int ugvc_timed_filter(ugvc_ctx* ctx, int iters, float* ms_total);
+/* `iters` steps of {filter kernel [+ all-gather of the result columns when gather != 0]} on the
+ * context stream; ms_total = first-to-last event, ms_kernel = sum of the per-launch kernel
+ * event pairs (what bench.py's roofline figure divides by). */
+int ugvc_timed_steps(ugvc_ctx* ctx, int iters, int64_t shard_cap, int gather, float* ms_total,
+                     float* ms_kernel);
+int ugvc_device_sync(ugvc_ctx* ctx);   /* hipDeviceSynchronize on the context's device */
+int ugvc_feature_matrix(ugvc_ctx* ctx, float* x_host, uint8_t* group_host);
+int ugvc_n_features(ugvc_ctx* ctx);
+int ugvc_set_kernel_variant(ugvc_ctx* ctx, int variant);
+
+/* ---- pileup allele/strand/base-quality tally (builder-defined) ---------
+ * offsets: n_loci+1 CSR offsets into obs; obs u16 = allele(2b: 0 ref,1 alt,2 other) |
+ * strand<<2 | bq<<3. */
+int ugvc_pileup_tally(ugvc_ctx* ctx, const int64_t* offsets, const uint16_t* obs,
+                      int64_t n_loci, const ugvc_pileup_out* out);
+int ugvc_pileup_upload(ugvc_ctx* ctx, const int64_t* offsets, const uint16_t* obs, int64_t n_loci);
+int ugvc_timed_pileup(ugvc_ctx* ctx, int iters, float* ms_total);
+
+/* ---- SEC noisy-locus statistic (/root/reference/ugvc/utils/stats_utils.py:12-70) -------
+ * per locus: k categories of observed and expected counts -> multinomial likelihood of the
+ * observation under the add-one corrected expected frequencies, and its ratio to the
+ * likelihood under the observation's own frequencies. */
+int ugvc_sec_likelihood_ratio(ugvc_ctx* ctx, const int32_t* actual, const int32_t* expected,
+                              int64_t n_loci, int k, double* likelihood, double* ratio);
+
+/* ---- is_homopolymer_snp + VAF gate (/root/reference/ugvc/pipelines/vcfbed/
+ * calibrate_bridging_snvs.py:9-66,110-126): out_pass[i]=1 when the record is un-filtered. */
+typedef struct ugvc_bridging_params {
+    double min_initial_qual; double min_tumor_vaf; double max_normal_vaf;
+    int min_query_hmer_size; int min_normal_depth; int min_distance_from_edge;
+} ugvc_bridging_params;
+int ugvc_bridging_snvs(ugvc_ctx* ctx, const ugvc_variants* v, const uint8_t* is_pass,
+                       const int32_t* ad_alt_sum, const int32_t* bg_ad_alt_sum, const int32_t* bg_dp,
+                       const ugvc_bridging_params* p, uint8_t* out_hmer_snp, uint8_t* out_pass);
+
+/* ---- multi-GPU: reassemble the scored callset with an RCCL all-gather over xGMI ---------
+ * One process per GPU.  Rank 0 calls ugvc_comm_unique_id and shares the 128 bytes out of
+ * band; every rank calls ugvc_comm_init.  ugvc_allgather_results gathers the resident
+ * result columns of every rank (shards padded to shard_cap rows) into host or device
+ * order-preserving buffers: rank r's rows land at [r*shard_cap, r*shard_cap + counts[r]). */
+int ugvc_comm_unique_id(uint8_t id[128]);
+int ugvc_comm_init(ugvc_ctx* ctx, const uint8_t id[128], int rank, int world);
+int ugvc_comm_destroy(ugvc_ctx* ctx);
+int ugvc_allgather_resident(ugvc_ctx* ctx, int64_t shard_cap);
+int ugvc_gathered_download(ugvc_ctx* ctx, int64_t shard_cap, int world, const ugvc_results* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

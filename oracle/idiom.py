@@ -41,13 +41,14 @@ class PyFasta:
             return len(self.s)
 
     def __init__(self, ref: S.Reference):
-        table = np.frombuffer(b"NACGT", dtype=np.uint8)
+        self.ref = ref
         self.seqs = {}
-        for c in range(ref.n_contigs):
-            lo, hi = int(ref.contig_off[c]), int(ref.contig_off[c + 1])
-            self.seqs[c] = self._Seq(table[ref.codes[lo:hi]].tobytes().decode())
 
     def __getitem__(self, c):
+        if c not in self.seqs:            # contigs are materialised as Python strings on first use
+            table = np.frombuffer(b"NACGT", dtype=np.uint8)
+            lo, hi = int(self.ref.contig_off[c]), int(self.ref.contig_off[c + 1])
+            self.seqs[c] = self._Seq(table[self.ref.codes[lo:hi]].tobytes().decode())
         return self.seqs[c]
 
 
@@ -250,7 +251,7 @@ def filter_variants_idiom(vt, ref, runs, tracks, blacklist, sk_models, flow_orde
             p0, p1 = O.forest_predict(m, X[sel])
             if m.kind == S.MODEL_GBT:
                 score[sel] = p1
-                flt[sel] = np.where(p1 > np.float32(0.5), 0, 1)
+                flt[sel] = np.where(p0 > np.float32(0), 0, 1)
                 continue
         else:
             pp = m.predict_proba(X[sel])

@@ -256,7 +256,8 @@ def featurize(vt: S.VariantTable, ref: S.Reference, runs: S.IntervalTrack | None
             mono[has] &= pool[off[m][has] + k] == b[has]
         start = g0[m] + 1 if cls == S.INDEL_INS else g0[m] + ref_len[m]
         nxt = _fetch(ref, contig[m], start)
-        ok = mono & (nxt == b)
+        inb = (start >= ref.contig_off[c64[m]]) & (start < ref.contig_off[c64[m] + 1])
+        ok = mono & inb & (nxt == b)
         mm = m[ok]
         run = _run_length_forward(ref, contig[mm], start[ok])
         hmer_len[mm] = run + (0 if cls == S.INDEL_INS else ref_len[mm] - 1)
@@ -352,7 +353,8 @@ def forest_predict(f: S.FlatForest, X: np.ndarray):
     ORDER in f64, divided by n_trees (`RandomForestClassifier.predict_proba`); class = argmax
     with ties to class 0 (`predict`).  MODEL_GBT: XGBoost semantics - go left when feature <
     threshold, f32 margins added in tree order starting from base_score, score =
-    sigmoid(margin) in f32, class 1 iff score > 0.5.  Returns (p0, p1) f64 / (margin, score)."""
+    sigmoid(margin) in f32, class 1 iff margin > 0 (decided on the exactly reproducible margin,
+    not on the rounded sigmoid).  Returns (p0, p1) f64 / (margin, score)."""
     n = X.shape[0]
     if f.kind == S.MODEL_RF:
         acc0 = np.zeros(n, dtype=np.float64)
@@ -401,7 +403,7 @@ def score(forests: list, X: np.ndarray, group: np.ndarray):
             flt[m] = np.where(b > a, S.FILTER_PASS, S.FILTER_LOW_SCORE)
         else:
             ts[m] = b
-            flt[m] = np.where(b > np.float32(0.5), S.FILTER_PASS, S.FILTER_LOW_SCORE)
+            flt[m] = np.where(a > np.float32(0), S.FILTER_PASS, S.FILTER_LOW_SCORE)
     return ts, flt
 
 

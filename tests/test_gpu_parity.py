@@ -1,0 +1,245 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, bit-exact for
+FILTER / flags / every integer feature / RF tree_score; stated tolerances for the two
+floating-point outputs that go through device libm (GBT sigmoid: 1e-6 abs, SOR: 1e-5 abs)."""
+import os
+
+import numpy as np
+import pytest
+
+import edge_cases as E
+from conftest import GOLDEN, real_chr1_reference
+
+pytestmark = pytest.mark.gpu
+
+RF = "rf_model_ignore_gt_incl_hpol_runs"
+XGB = "xgb_model_ignore_gt_incl_hpol_runs"
+
+
+def _oracle():
+    from oracle import oracle as O
+    return O
+
+
+def _configure(engine, cs_ref, runs, tracks, bl, forests, hpol_len=10, hpol_dist=10, flow="TGCA"):
+    from variantcalling_amd.engine import configure
+    configure(engine, cs_ref, runs, tracks, bl, forests, flow, hpol_len, hpol_dist, True)
+
+
+def _assert_same(res, exp, what=""):
+    assert np.array_equal(res.filter, exp.filter), f"FILTER mismatch {what}: {np.flatnonzero(res.filter != exp.filter)[:10]}"
+    assert np.array_equal(res.flags, exp.flags), f"flags mismatch {what}: {np.flatnonzero(res.flags != exp.flags)[:10]}"
+    assert np.array_equal(res.tree_score, exp.tree_score), f"TREE_SCORE mismatch {what}"
+
+
+def test_library_is_loaded_in_tree(engine):
+    from variantcalling_amd import engine as eng_mod
+    assert os.path.dirname(eng_mod.LIB_PATH).endswith("variantcalling_amd")
+    info = engine.device_info()
+    assert "gfx950" in info["name"], info
+    with open("/proc/self/maps") as fh:
+        assert "libugvc_mi355x.so" in fh.read()
+
+
+def test_filter_synthetic_rf(engine, small_callset, frozen_models):
+    cs = small_callset
+    O = _oracle()
+    _configure(engine, cs.ref, cs.runs, cs.tracks, cs.blacklist, frozen_models[RF])
+    res = engine.filter_variants(cs.variants)
+    exp = O.filter_variants(cs.variants, cs.ref, cs.runs, cs.tracks, cs.blacklist, frozen_models[RF])
+    _assert_same(res, exp, "synthetic C3-shaped")
+    assert 0 < (res.filter == 0).mean() < 1
+
+
+def test_feature_matrix_bit_exact(engine, small_callset, frozen_models):
+    cs = small_callset
+    O = _oracle()
+    _configure(engine, cs.ref, cs.runs, cs.tracks, cs.blacklist, frozen_models[RF])
+    X, g = engine.feature_matrix(cs.variants)
+    ft = O.featurize(cs.variants, cs.ref, cs.runs, cs.tracks)
+    assert X.shape == ft["X"].shape
+    for j, name in enumerate(__import__("variantcalling_amd.schema", fromlist=["x"]).feature_names(3)):
+        assert np.array_equal(X[:, j], ft["X"][:, j]), name
+    assert np.array_equal(g, ft["group"].astype(np.uint8))
+
+
+def test_filter_edge_cases_real_hg38(engine, frozen_models):
+    """Contig ends, N runs, 50 kb 'N homopolymers', MNPs, 60 bp indels, dp = 0, empty track contig."""
+    O = _oracle()
+    ref = real_chr1_reference()
+    vt = E.edge_table(ref)
+    runs, tracks = E.simple_tracks(ref)
+    bl = np.unique(np.concatenate([vt.keys()[::7], vt.keys()[::11] + np.uint64(1)]))
+    for flow in ("TGCA", "ACGT", "GTAC"):
+        _configure(engine, ref, runs, tracks, bl, frozen_models[RF], hpol_len=8, hpol_dist=12, flow=flow)
+        res = engine.filter_variants(vt)
+        exp = O.filter_variants(vt, ref, runs, tracks, bl, frozen_models[RF], flow_order=flow, hpol_len=8, hpol_dist=12)
+        _assert_same(res, exp, f"edge flow={flow}")
+        X, _ = engine.feature_matrix()
+        assert np.array_equal(X, O.featurize(vt, ref, runs, tracks, flow, 8, 12)["X"])
+
+
+def test_snv_only_c2_shape(engine, frozen_models):
+    from variantcalling_amd import synth
+    O = _oracle()
+    cs = synth.make_callset(50_000, genome_len=20_000_000, n_contigs=4, seed=77, snv_only=True)
+    _configure(engine, cs.ref, cs.runs, cs.tracks, cs.blacklist, frozen_models[RF])
+    _assert_same(engine.filter_variants(cs.variants),
+                 O.filter_variants(cs.variants, cs.ref, cs.runs, cs.tracks, cs.blacklist, frozen_models[RF]), "C2")
+
+
+def test_gbt_model(engine, small_callset, frozen_models):
+    """XGBoost-shaped ensemble: FILTER bit-exact (decided on the f32 margin), score within 1e-6."""
+    cs = small_callset
+    O = _oracle()
+    _configure(engine, cs.ref, cs.runs, cs.tracks, cs.blacklist, frozen_models[XGB])
+    res = engine.filter_variants(cs.variants)
+    exp = O.filter_variants(cs.variants, cs.ref, cs.runs, cs.tracks, cs.blacklist, frozen_models[XGB])
+    assert np.array_equal(res.filter, exp.filter)
+    assert np.array_equal(res.flags, exp.flags)
+    assert np.max(np.abs(res.tree_score - exp.tree_score)) <= 1e-6
+
+
+def test_empty_no_tables_and_ragged(engine, small_callset, frozen_models):
+    from variantcalling_amd.engine import Engine
+    O = _oracle()
+    cs = small_callset
+    with Engine(0) as e2:      # fresh context: no runs, no tracks, no blacklist, only an SNP model
+        e2.set_reference(cs.ref)
+        e2.set_tracks([])
+        e2.set_blacklist(None)
+        forests17 = None
+        res = e2.filter_variants(cs.variants.slice(0, 0))
+        assert res.filter.size == 0
+        sub = cs.variants.slice(1000, 1777)          # not a multiple of the block size
+        res = e2.filter_variants(sub)
+        exp = O.filter_variants(sub, cs.ref, None, [], None, [None, None, None], mark_hpol=False)
+        _assert_same(res, exp, "no tables / no model")
+        assert np.all(res.tree_score == 0) and np.all(res.filter == 0)
+        X, g = e2.feature_matrix()
+        assert np.array_equal(X, O.featurize(sub, cs.ref, None, [])["X"])
+
+
+def test_error_paths(engine, small_callset):
+    import copy
+    cs = small_callset
+    vt = copy.copy(cs.variants.slice(0, 100))
+    vt.pos = vt.pos[::-1].copy()
+    with pytest.raises(RuntimeError, match="sorted"):
+        engine.filter_variants(vt)
+    vt = copy.copy(cs.variants.slice(0, 100))
+    vt.contig = np.full(100, 200, np.uint8)
+    with pytest.raises(RuntimeError, match="contig index"):
+        engine.filter_variants(vt)
+    with pytest.raises(RuntimeError, match="permutation"):
+        engine.set_flow_order("AAGT")
+
+
+def test_golden_fixture_outputs(engine, frozen_models):
+    """Committed golden outputs (tests/golden/filter_golden_v1.npz, made by make_filter_golden.py
+    from the oracle) - guards oracle drift as well as the kernel."""
+    z = np.load(os.path.join(GOLDEN, "filter_golden_v1.npz"))
+    ref = real_chr1_reference()
+    vt = E.edge_table(ref)
+    runs, tracks = E.simple_tracks(ref)
+    bl = np.unique(np.concatenate([vt.keys()[::7], vt.keys()[::11] + np.uint64(1)]))
+    _configure(engine, ref, runs, tracks, bl, frozen_models[RF], hpol_len=8, hpol_dist=12)
+    res = engine.filter_variants(vt)
+    assert np.array_equal(res.filter, z["filter"]) and np.array_equal(res.flags, z["flags"])
+    assert np.array_equal(res.tree_score, z["tree_score"])
+    X, _ = engine.feature_matrix()
+    assert np.array_equal(X, z["X"])
+
+
+def test_pileup_tally(engine):
+    from variantcalling_amd import synth
+    O = _oracle()
+    off, obs = synth.make_pileup(50_000, seed=5)
+    # ragged: empty loci, a 5000-deep locus, a single-read locus
+    d = np.diff(off).copy()
+    d[[0, 17, 4999]] = 0
+    d[123] = 5000
+    d[-1] = 1
+    off2 = np.concatenate([[0], np.cumsum(d)])
+    rng = np.random.default_rng(1)
+    obs2 = rng.choice(obs, size=int(off2[-1]))
+    for o, b in ((off, obs), (off2, obs2)):
+        got = engine.pileup_tally(o, b)
+        exp = O.pileup_tally(o, b)
+        for k in ("ref_fwd", "ref_rev", "alt_fwd", "alt_rev", "other", "dp", "bq_ref", "bq_alt", "ad_ref", "ad_alt"):
+            assert np.array_equal(got[k], exp[k]), k
+        assert np.array_equal(got["vaf"], exp["vaf"])
+        assert np.max(np.abs(got["sor"] - exp["sor"])) <= 1e-5
+    empty = engine.pileup_tally(np.zeros(1, np.int64), np.zeros(0, np.uint16))
+    assert empty["dp"].size == 0
+
+
+def test_sec_statistic_kats(engine):
+    """Reference KATs (test/unit/utils/test_stats_utils.py:48-110) through the GPU kernel."""
+    from oracle import stats as st
+    cases = [([4, 4, 4], [4, 4, 4]), ([4, 4, 4], [40, 40, 40]), ([40, 40, 40], [40, 40, 40]), ([4, 4, 40], [4, 4, 4]),
+             ([4, 4, 40], [40, 40, 40]), ([10, 10, 10], [1, 10, 40]), ([40, 10, 1], [1, 10, 40]),
+             ([1, 10, 40], [1, 10, 40]), ([4, 4, 4], [4, 4, 0]), ([4, 4, 40], [0, 0, 0]), ([0, 0, 0], [3, 2, 1])]
+    a = np.array([c[0] for c in cases], np.int32)
+    e = np.array([c[1] for c in cases], np.int32)
+    lik, ratio = engine.sec_likelihood_ratio(a, e)
+    kat_lik = [0.0652, 0.0652, 0.0068, 3.3e-13, 3.3e-13, 2.1e-10, 2.7e-53, 0.039, 0.0043, 3.3e-13]
+    kat_ratio = [1, 1, 1, 3.3e-13, 3.3e-13, 7.8e-9, 6.9e-52, 1, 0.0661, 9.1e-12]
+    places = [3, 3, 3, 10, 10, 10, 40, 3, 3, 3]
+    for i in range(10):
+        assert round(abs(lik[i] - kat_lik[i]), places[i]) == 0, (i, lik[i])
+    for i, pl in enumerate([3, 3, 3, 10, 10, 10, 40, 3, 3, 10]):
+        assert round(abs(ratio[i] - kat_ratio[i]), pl) == 0, (i, ratio[i])
+    ol, orr = st.sec_batch(a, e)
+    assert np.allclose(lik, ol, rtol=1e-10, atol=0) and np.allclose(ratio, orr, rtol=1e-10, atol=0)
+    rng = np.random.default_rng(3)
+    A = rng.integers(0, 60, size=(20000, 5)).astype(np.int32)
+    Ex = rng.integers(0, 400, size=(20000, 5)).astype(np.int32)
+    lik, ratio = engine.sec_likelihood_ratio(A, Ex)
+    ol, orr = st.sec_batch(A, Ex)
+    assert np.allclose(lik, ol, rtol=1e-9, atol=0) and np.allclose(ratio, orr, rtol=1e-9, atol=0)
+
+
+def test_bridging_snvs(engine):
+    from oracle import bridging as B
+    ref = real_chr1_reference()
+    vt = E.edge_table(ref, seed=9, n_random=6000)
+    rng = np.random.default_rng(4)
+    n = vt.n
+    is_pass = rng.random(n) < 0.3
+    ad_alt = rng.integers(0, 40, n).astype(np.int32)
+    bg_ad = rng.integers(0, 6, n).astype(np.int32)
+    bg_dp = rng.integers(0, 40, n).astype(np.int32)
+    engine.set_reference(ref)
+    for h, edge in ((2, 0), (3, 0), (5, 1), (4, 0)):
+        got = engine.bridging_snvs(vt, is_pass, ad_alt, bg_ad, bg_dp, min_query_hmer_size=h, min_distance_from_edge=edge)
+        exp = B.calibrate(vt, ref, is_pass, ad_alt, bg_ad, bg_dp, min_query_hmer_size=h, min_distance_from_edge=edge)
+        assert np.array_equal(got[0], exp[0]), h
+        assert np.array_equal(got[1], exp[1]), h
+    assert exp[0].sum() > 0
+
+
+def test_full_size_properties(engine, frozen_models):
+    """BASELINE C3 size (5 M variants, 3.1 Gb genome): properties that need no oracle run.
+    (i) idempotence/determinism; (ii) shard invariance: scoring [0,n) equals scoring the two
+    halves separately; (iii) a 20 k random slice equals the oracle."""
+    from variantcalling_amd import synth
+    O = _oracle()
+    cs = synth.make_callset(5_000_000)
+    _configure(engine, cs.ref, cs.runs, cs.tracks, cs.blacklist, frozen_models[RF])
+    full = engine.filter_variants(cs.variants)
+    again = engine.filter_variants(cs.variants)
+    _assert_same(full, again, "determinism")
+    n = cs.variants.n
+    cut = n // 2 + 13
+    a = engine.filter_variants(cs.variants.slice(0, cut))
+    b = engine.filter_variants(cs.variants.slice(cut, n))
+    assert np.array_equal(np.concatenate([a.filter, b.filter]), full.filter)
+    assert np.array_equal(np.concatenate([a.flags, b.flags]), full.flags)
+    assert np.array_equal(np.concatenate([a.tree_score, b.tree_score]), full.tree_score)
+    lo = 3_111_111
+    sub = cs.variants.slice(lo, lo + 20_000)
+    exp = O.filter_variants(sub, cs.ref, cs.runs, cs.tracks, cs.blacklist, frozen_models[RF])
+    assert np.array_equal(full.filter[lo:lo + 20_000], exp.filter)
+    assert np.array_equal(full.flags[lo:lo + 20_000], exp.flags)
+    assert np.array_equal(full.tree_score[lo:lo + 20_000], exp.tree_score)
+    assert 0.05 < (full.filter == 0).mean() < 0.95

@@ -1,0 +1,494 @@
+// C ABI of libugvc_mi355x.so: context, resident tables, hot-path entry points.
+// See include/ugvc_mi355x.h for the contract and the reference interfaces each call replaces.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <limits>
+
+#include "ugvc_device.hpp"
+
+namespace ugvc {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+int fail(const std::string& msg) {
+    g_err = msg;
+    return -1;
+}
+
+int ensure(DeviceBuf& b, size_t bytes) {
+    if (bytes <= b.cap && b.p) return 0;
+    if (b.p) UGVC_HIP(hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    size_t want = std::max<size_t>(bytes, 256);
+    UGVC_HIP(hipMalloc(&b.p, want));
+    b.cap = want;
+    return 0;
+}
+
+int upload(ugvc_ctx* ctx, DeviceBuf& b, const void* src, size_t bytes) {
+    if (ensure(b, bytes)) return -1;
+    if (bytes) UGVC_HIP(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return 0;
+}
+
+static void release(DeviceBuf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+int build_args(ugvc_ctx* ctx, FilterArgs& a, bool want_x) {
+    if (!ctx->ref.p) return fail("no reference uploaded (ugvc_ref_upload)");
+    memset(&a, 0, sizeof(a));
+    a.n = ctx->n;
+    a.contig = ctx->v_contig.as<uint8_t>();
+    a.pos = ctx->v_pos.as<int32_t>();
+    a.ref_len = ctx->v_rl.as<uint16_t>();
+    a.alt_len = ctx->v_al.as<uint16_t>();
+    a.ref_off = ctx->v_ro.as<uint32_t>();
+    a.alt_off = ctx->v_ao.as<uint32_t>();
+    a.alleles = ctx->v_alleles.as<uint8_t>();
+    a.qual = ctx->v_qual.as<float>();
+    a.sor = ctx->v_sor.as<float>();
+    a.dp = ctx->v_dp.as<int32_t>();
+    a.ad_ref = ctx->v_adr.as<int32_t>();
+    a.ad_alt = ctx->v_ada.as<int32_t>();
+    a.gq = ctx->v_gq.as<uint8_t>();
+    a.ref = ctx->ref.as<uint8_t>();
+    a.contig_off = ctx->contig_off.as<int64_t>();
+    a.runs = TrackView{ctx->runs_s.as<int32_t>(), ctx->runs_e.as<int32_t>(), ctx->runs_p.as<int32_t>()};
+    a.has_runs = ctx->has_runs;
+    a.hpol_dist = ctx->hpol_dist;
+    a.mark_hpol = ctx->mark_hpol;
+    a.n_tracks = ctx->n_tracks;
+    for (int t = 0; t < ctx->n_tracks; ++t) {
+        if (!ctx->track_set[t]) return fail("annotation track " + std::to_string(t) + " not uploaded");
+        a.tracks[t] = TrackView{ctx->trk_s[t].as<int32_t>(), ctx->trk_e[t].as<int32_t>(), ctx->trk_p[t].as<int32_t>()};
+    }
+    a.bl = ctx->bl.as<uint64_t>();
+    a.n_bl = ctx->n_bl;
+    const int F = UGVC_N_BASE_FEATURES + ctx->n_tracks;
+    for (int g = 0; g < UGVC_N_GROUPS; ++g) {
+        const auto& m = ctx->model[g];
+        ForestView& f = a.forest[g];
+        if (m.set) {
+            if (m.n_features > F)
+                return fail("model for group " + std::to_string(g) + " wants " + std::to_string(m.n_features) +
+                            " features, engine provides " + std::to_string(F));
+            f.nodes = m.nodes.as<Node>();
+            f.roots = m.roots.as<int>();
+            f.leaves = m.leaves.as<double2>();
+            f.n_trees = m.n_trees;
+            f.depth = m.depth;
+            f.kind = m.kind;
+            f.base = m.base;
+            f.dense = m.has_dense ? m.dense.as<float2>() : nullptr;
+            f.dense_leaves = m.has_dense ? m.dense_leaves.as<double2>() : nullptr;
+        }
+    }
+    memcpy(a.flow, ctx->flow, 4);
+    a.score = ctx->r_score.as<float>();
+    a.filter = ctx->r_filter.as<uint8_t>();
+    a.flags = ctx->r_flags.as<uint8_t>();
+    a.X = want_x ? ctx->x_mat.as<float>() : nullptr;
+    a.group = want_x ? ctx->x_group.as<uint8_t>() : nullptr;
+    return 0;
+}
+
+}  // namespace ugvc
+
+using namespace ugvc;
+
+extern "C" {
+
+int ugvc_abi_version(void) { return UGVC_ABI_VERSION; }
+const char* ugvc_last_error(void) { return g_err.c_str(); }
+
+int ugvc_ctx_create(int device_id, ugvc_ctx** out) {
+    if (!out) return fail("out is NULL");
+    int n_dev = 0;
+    UGVC_HIP(hipGetDeviceCount(&n_dev));
+    if (device_id < 0 || device_id >= n_dev)
+        return fail("device " + std::to_string(device_id) + " not present (" + std::to_string(n_dev) + " visible)");
+    UGVC_HIP(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    UGVC_HIP(hipGetDeviceProperties(&prop, device_id));
+    ugvc_ctx* ctx = new ugvc_ctx();
+    ctx->device = device_id;
+    ctx->n_cus = prop.multiProcessorCount;
+    UGVC_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    UGVC_HIP(hipEventCreate(&ctx->ev0));
+    UGVC_HIP(hipEventCreate(&ctx->ev1));
+    *out = ctx;
+    return 0;
+}
+
+int ugvc_comm_destroy(ugvc_ctx* ctx);
+
+int ugvc_ctx_destroy(ugvc_ctx* ctx) {
+    if (!ctx) return 0;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ugvc_comm_destroy(ctx);
+    DeviceBuf* all[] = {&ctx->ref, &ctx->contig_off, &ctx->runs_s, &ctx->runs_e, &ctx->runs_p, &ctx->bl,
+                        &ctx->v_contig, &ctx->v_pos, &ctx->v_rl, &ctx->v_al, &ctx->v_ro, &ctx->v_ao,
+                        &ctx->v_alleles, &ctx->v_qual, &ctx->v_sor, &ctx->v_dp, &ctx->v_adr, &ctx->v_ada,
+                        &ctx->v_gq, &ctx->r_score, &ctx->r_filter, &ctx->r_flags, &ctx->x_mat, &ctx->x_group,
+                        &ctx->pl_off, &ctx->pl_obsb, &ctx->pl_out, &ctx->g_score, &ctx->g_filter, &ctx->g_flags};
+    for (auto* b : all) release(*b);
+    for (int t = 0; t < UGVC_MAX_TRACKS; ++t) {
+        release(ctx->trk_s[t]);
+        release(ctx->trk_e[t]);
+        release(ctx->trk_p[t]);
+    }
+    for (auto& m : ctx->model) {
+        release(m.nodes); release(m.roots); release(m.leaves); release(m.dense); release(m.dense_leaves);
+    }
+    (void)hipEventDestroy(ctx->ev0);
+    (void)hipEventDestroy(ctx->ev1);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return 0;
+}
+
+int ugvc_device_info(ugvc_ctx* ctx, char* name, int name_cap, int* n_cus, int64_t* hbm_bytes) {
+    if (!ctx) return fail("ctx is NULL");
+    hipDeviceProp_t prop;
+    UGVC_HIP(hipGetDeviceProperties(&prop, ctx->device));
+    if (name && name_cap > 0) {
+        std::string s = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+        strncpy(name, s.c_str(), name_cap - 1);
+        name[name_cap - 1] = 0;
+    }
+    if (n_cus) *n_cus = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return 0;
+}
+
+int ugvc_sync(ugvc_ctx* ctx) {
+    if (!ctx) return fail("ctx is NULL");
+    UGVC_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int ugvc_ref_upload(ugvc_ctx* ctx, const uint8_t* codes, int64_t total_len, const int64_t* contig_off,
+                    int n_contigs) {
+    if (!ctx || !codes || !contig_off) return fail("NULL argument");
+    if (n_contigs < 1 || n_contigs > 255) return fail("n_contigs must be in 1..255 (contig column is u8)");
+    if (contig_off[0] != 0 || contig_off[n_contigs] != total_len) return fail("contig_off must span [0, total_len]");
+    for (int c = 0; c < n_contigs; ++c)
+        if (contig_off[c + 1] < contig_off[c]) return fail("contig_off must be non-decreasing");
+    UGVC_HIP(hipSetDevice(ctx->device));
+    if (upload(ctx, ctx->ref, codes, (size_t)total_len)) return -1;
+    if (upload(ctx, ctx->contig_off, contig_off, sizeof(int64_t) * (n_contigs + 1))) return -1;
+    UGVC_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->n_contigs = n_contigs;
+    ctx->ref_len = total_len;
+    return 0;
+}
+
+static int check_track(ugvc_ctx* ctx, const int32_t* starts, const int32_t* ends, const int32_t* ptr, int64_t n) {
+    if (!ctx) return fail("ctx is NULL");
+    if (ctx->n_contigs == 0) return fail("upload the reference before interval tables");
+    if (n < 0 || n > std::numeric_limits<int32_t>::max()) return fail("interval count out of range");
+    if (n > 0 && (!starts || !ends)) return fail("NULL interval arrays");
+    if (!ptr) return fail("NULL contig_ptr");
+    if (ptr[0] != 0 || ptr[ctx->n_contigs] != n) return fail("contig_ptr must span [0, n]");
+    return 0;
+}
+
+int ugvc_runs_upload(ugvc_ctx* ctx, const int32_t* starts, const int32_t* ends, const int32_t* contig_ptr,
+                     int64_t n, int min_len, int max_dist, int mark_hpol) {
+    if (check_track(ctx, starts, ends, contig_ptr, n)) return -1;
+    UGVC_HIP(hipSetDevice(ctx->device));
+    // drop runs shorter than min_len (parse_runs_file(runfile, min_hmer_run_length))
+    std::vector<int32_t> s, e, p(ctx->n_contigs + 1, 0);
+    s.reserve(n);
+    e.reserve(n);
+    for (int c = 0; c < ctx->n_contigs; ++c) {
+        for (int64_t i = contig_ptr[c]; i < contig_ptr[c + 1]; ++i)
+            if (ends[i] - starts[i] >= min_len) {
+                s.push_back(starts[i]);
+                e.push_back(ends[i]);
+            }
+        p[c + 1] = (int32_t)s.size();
+    }
+    if (upload(ctx, ctx->runs_s, s.data(), s.size() * 4)) return -1;
+    if (upload(ctx, ctx->runs_e, e.data(), e.size() * 4)) return -1;
+    if (upload(ctx, ctx->runs_p, p.data(), p.size() * 4)) return -1;
+    UGVC_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->has_runs = 1;
+    ctx->hpol_dist = max_dist;
+    ctx->mark_hpol = mark_hpol;
+    return 0;
+}
+
+int ugvc_track_upload(ugvc_ctx* ctx, int track_id, const int32_t* starts, const int32_t* ends,
+                      const int32_t* contig_ptr, int64_t n) {
+    if (track_id < 0 || track_id >= UGVC_MAX_TRACKS) return fail("track_id out of range");
+    if (check_track(ctx, starts, ends, contig_ptr, n)) return -1;
+    UGVC_HIP(hipSetDevice(ctx->device));
+    if (upload(ctx, ctx->trk_s[track_id], starts, (size_t)n * 4)) return -1;
+    if (upload(ctx, ctx->trk_e[track_id], ends, (size_t)n * 4)) return -1;
+    if (upload(ctx, ctx->trk_p[track_id], contig_ptr, (size_t)(ctx->n_contigs + 1) * 4)) return -1;
+    UGVC_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->track_set[track_id] = 1;
+    if (track_id + 1 > ctx->n_tracks) ctx->n_tracks = track_id + 1;
+    return 0;
+}
+
+int ugvc_set_n_tracks(ugvc_ctx* ctx, int n_tracks) {
+    if (!ctx) return fail("ctx is NULL");
+    if (n_tracks < 0 || n_tracks > UGVC_MAX_TRACKS) return fail("n_tracks out of range");
+    ctx->n_tracks = n_tracks;
+    return 0;
+}
+
+int ugvc_blacklist_upload(ugvc_ctx* ctx, const uint64_t* keys, int64_t n) {
+    if (!ctx) return fail("ctx is NULL");
+    if (n < 0 || (n > 0 && !keys)) return fail("bad blacklist arguments");
+    for (int64_t i = 1; i < n; ++i)
+        if (keys[i] <= keys[i - 1]) return fail("blacklist keys must be sorted and unique");
+    UGVC_HIP(hipSetDevice(ctx->device));
+    if (upload(ctx, ctx->bl, keys, (size_t)n * 8)) return -1;
+    UGVC_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->n_bl = n;
+    return 0;
+}
+
+int ugvc_set_flow_order(ugvc_ctx* ctx, const char* flow4) {
+    if (!ctx || !flow4 || strlen(flow4) != 4) return fail("flow order must be 4 characters");
+    int seen = 0;
+    for (int k = 0; k < 4; ++k) {
+        int code = 0;
+        switch (flow4[k]) {
+            case 'A': case 'a': code = 1; break;
+            case 'C': case 'c': code = 2; break;
+            case 'G': case 'g': code = 3; break;
+            case 'T': case 't': code = 4; break;
+            default: return fail("flow order must be a permutation of ACGT");
+        }
+        seen |= 1 << code;
+        ctx->flow[k] = (uint8_t)code;
+    }
+    if (seen != 0x1e) return fail("flow order must be a permutation of ACGT");
+    return 0;
+}
+
+int ugvc_model_upload(ugvc_ctx* ctx, int group, int kind, const int32_t* feature, const float* threshold,
+                      const int32_t* left, const int32_t* right, int32_t n_nodes, const int32_t* tree_root,
+                      int32_t n_trees, const double* leaf_value, int32_t n_leaves, int32_t n_features,
+                      float base_score, int32_t max_depth) {
+    if (!ctx) return fail("ctx is NULL");
+    if (group < 0 || group >= UGVC_N_GROUPS) return fail("group out of range");
+    if (kind != UGVC_MODEL_RF && kind != UGVC_MODEL_GBT) return fail("unknown model kind");
+    if (n_nodes <= 0 || n_trees <= 0 || n_leaves <= 0) return fail("empty model");
+    if (n_features > kMaxFeatures) return fail("model has more features than the engine computes");
+    UGVC_HIP(hipSetDevice(ctx->device));
+    std::vector<Node> nodes(n_nodes);
+    const float inf = std::numeric_limits<float>::infinity();
+    for (int i = 0; i < n_nodes; ++i) {
+        if (feature[i] < 0) {
+            if (left[i] < 0 || left[i] >= n_leaves) return fail("leaf payload index out of range");
+            nodes[i] = Node{inf, 0, i, left[i]};
+        } else {
+            if (feature[i] >= n_features) return fail("node feature index out of range");
+            if (left[i] < 0 || left[i] >= n_nodes || right[i] < 0 || right[i] >= n_nodes)
+                return fail("child index out of range");
+            nodes[i] = Node{threshold[i], feature[i], left[i], right[i]};
+        }
+    }
+    // depth check (also guards against cycles)
+    int depth = 0;
+    {
+        std::vector<std::pair<int, int>> stack;
+        for (int t = 0; t < n_trees; ++t) {
+            if (tree_root[t] < 0 || tree_root[t] >= n_nodes) return fail("tree root out of range");
+            stack.push_back({tree_root[t], 0});
+            int64_t visited = 0;
+            while (!stack.empty()) {
+                auto [i, d] = stack.back();
+                stack.pop_back();
+                if (++visited > (int64_t)n_nodes) return fail("tree structure has a cycle");
+                if (feature[i] < 0) {
+                    depth = std::max(depth, d);
+                } else {
+                    stack.push_back({left[i], d + 1});
+                    stack.push_back({right[i], d + 1});
+                }
+            }
+        }
+    }
+    if (max_depth > 0 && max_depth != depth) return fail("max_depth does not match the node table");
+    auto& m = ctx->model[group];
+    if (upload(ctx, m.nodes, nodes.data(), nodes.size() * sizeof(Node))) return -1;
+    if (upload(ctx, m.roots, tree_root, (size_t)n_trees * 4)) return -1;
+    if (upload(ctx, m.leaves, leaf_value, (size_t)n_leaves * 16)) return -1;
+    UGVC_HIP(hipStreamSynchronize(ctx->stream));
+    m.n_trees = n_trees;
+    m.depth = depth;
+    m.kind = kind;
+    m.n_features = n_features;
+    m.base = base_score;
+    m.set = 1;
+    m.has_dense = 0;
+    return 0;
+}
+
+static int check_variants(const ugvc_variants* v) {
+    if (!v) return fail("variants is NULL");
+    if (v->n < 0) return fail("negative variant count");
+    if (v->n == 0) return 0;
+    if (!v->contig || !v->pos || !v->ref_len || !v->alt_len || !v->ref_off || !v->alt_off || !v->alleles ||
+        !v->qual || !v->sor || !v->dp || !v->ad_ref || !v->ad_alt || !v->gq)
+        return fail("NULL variant column");
+    return 0;
+}
+
+int ugvc_variants_upload(ugvc_ctx* ctx, const ugvc_variants* v) {
+    if (!ctx) return fail("ctx is NULL");
+    if (check_variants(v)) return -1;
+    if (ctx->n_contigs == 0) return fail("upload the reference before variants");
+    UGVC_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)v->n;
+    // host-side validation the kernel relies on (sortedness, contig range, allele bounds)
+    for (size_t i = 0; i < n; ++i) {
+        if (v->contig[i] >= ctx->n_contigs) return fail("contig index out of range at row " + std::to_string(i));
+        if (v->ref_len[i] == 0 || v->alt_len[i] == 0) return fail("empty allele at row " + std::to_string(i));
+        if ((int64_t)v->ref_off[i] + v->ref_len[i] > v->alleles_len ||
+            (int64_t)v->alt_off[i] + v->alt_len[i] > v->alleles_len)
+            return fail("allele offset outside the pool at row " + std::to_string(i));
+        if (v->pos[i] < 1) return fail("POS must be >= 1 at row " + std::to_string(i));
+        if (i && (v->contig[i] < v->contig[i - 1] ||
+                  (v->contig[i] == v->contig[i - 1] && v->pos[i] < v->pos[i - 1])))
+            return fail("variants must be sorted by (contig, pos); row " + std::to_string(i));
+    }
+    if (upload(ctx, ctx->v_contig, v->contig, n)) return -1;
+    if (upload(ctx, ctx->v_pos, v->pos, n * 4)) return -1;
+    if (upload(ctx, ctx->v_rl, v->ref_len, n * 2)) return -1;
+    if (upload(ctx, ctx->v_al, v->alt_len, n * 2)) return -1;
+    if (upload(ctx, ctx->v_ro, v->ref_off, n * 4)) return -1;
+    if (upload(ctx, ctx->v_ao, v->alt_off, n * 4)) return -1;
+    if (upload(ctx, ctx->v_alleles, v->alleles, (size_t)v->alleles_len)) return -1;
+    if (upload(ctx, ctx->v_qual, v->qual, n * 4)) return -1;
+    if (upload(ctx, ctx->v_sor, v->sor, n * 4)) return -1;
+    if (upload(ctx, ctx->v_dp, v->dp, n * 4)) return -1;
+    if (upload(ctx, ctx->v_adr, v->ad_ref, n * 4)) return -1;
+    if (upload(ctx, ctx->v_ada, v->ad_alt, n * 4)) return -1;
+    if (upload(ctx, ctx->v_gq, v->gq, n)) return -1;
+    if (ensure(ctx->r_score, n * 4) || ensure(ctx->r_filter, n) || ensure(ctx->r_flags, n)) return -1;
+    UGVC_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->n = v->n;
+    return 0;
+}
+
+int ugvc_filter_resident(ugvc_ctx* ctx) {
+    if (!ctx) return fail("ctx is NULL");
+    UGVC_HIP(hipSetDevice(ctx->device));
+    FilterArgs a;
+    if (build_args(ctx, a, false)) return -1;
+    return launch_filter(ctx, a, true, false);
+}
+
+int ugvc_results_download(ugvc_ctx* ctx, const ugvc_results* out) {
+    if (!ctx || !out) return fail("NULL argument");
+    UGVC_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)ctx->n;
+    if (n) {
+        if (out->tree_score) UGVC_HIP(hipMemcpyAsync(out->tree_score, ctx->r_score.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (out->filter) UGVC_HIP(hipMemcpyAsync(out->filter, ctx->r_filter.p, n, hipMemcpyDeviceToHost, ctx->stream));
+        if (out->flags) UGVC_HIP(hipMemcpyAsync(out->flags, ctx->r_flags.p, n, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    UGVC_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int ugvc_filter_variants(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_results* out) {
+    if (ugvc_variants_upload(ctx, v)) return -1;
+    if (ugvc_filter_resident(ctx)) return -1;
+    return ugvc_results_download(ctx, out);
+}
+
+int ugvc_timed_filter(ugvc_ctx* ctx, int iters, float* ms_total) {
+    if (!ctx || !ms_total || iters < 1) return fail("bad arguments");
+    UGVC_HIP(hipSetDevice(ctx->device));
+    FilterArgs a;
+    if (build_args(ctx, a, false)) return -1;
+    UGVC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    for (int it = 0; it < iters; ++it)
+        if (launch_filter(ctx, a, true, false)) return -1;
+    UGVC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    UGVC_HIP(hipEventSynchronize(ctx->ev1));
+    UGVC_HIP(hipEventElapsedTime(ms_total, ctx->ev0, ctx->ev1));
+    return 0;
+}
+
+int ugvc_device_sync(ugvc_ctx* ctx) {
+    if (!ctx) return fail("ctx is NULL");
+    UGVC_HIP(hipSetDevice(ctx->device));
+    UGVC_HIP(hipDeviceSynchronize());
+    return 0;
+}
+
+int ugvc_allgather_resident(ugvc_ctx* ctx, int64_t shard_cap);
+
+int ugvc_timed_steps(ugvc_ctx* ctx, int iters, int64_t shard_cap, int gather, float* ms_total, float* ms_kernel) {
+    if (!ctx || !ms_total || !ms_kernel || iters < 1) return fail("bad arguments");
+    UGVC_HIP(hipSetDevice(ctx->device));
+    FilterArgs a;
+    if (build_args(ctx, a, false)) return -1;
+    std::vector<hipEvent_t> ev(2 * (size_t)iters);
+    for (auto& e : ev) UGVC_HIP(hipEventCreate(&e));
+    int rc = 0;
+    UGVC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    for (int it = 0; it < iters && !rc; ++it) {
+        UGVC_HIP(hipEventRecord(ev[2 * it], ctx->stream));
+        rc = launch_filter(ctx, a, true, false);
+        UGVC_HIP(hipEventRecord(ev[2 * it + 1], ctx->stream));
+        if (!rc && gather) rc = ugvc_allgather_resident(ctx, shard_cap);
+    }
+    UGVC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    UGVC_HIP(hipEventSynchronize(ctx->ev1));
+    if (!rc) {
+        UGVC_HIP(hipEventElapsedTime(ms_total, ctx->ev0, ctx->ev1));
+        float sum = 0.f;
+        for (int it = 0; it < iters; ++it) {
+            float ms = 0.f;
+            UGVC_HIP(hipEventElapsedTime(&ms, ev[2 * it], ev[2 * it + 1]));
+            sum += ms;
+        }
+        *ms_kernel = sum;
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return rc;
+}
+
+int ugvc_n_features(ugvc_ctx* ctx) { return ctx ? UGVC_N_BASE_FEATURES + ctx->n_tracks : -1; }
+
+int ugvc_set_kernel_variant(ugvc_ctx* ctx, int variant) {
+    if (!ctx) return fail("ctx is NULL");
+    ctx->kernel_variant = variant;
+    return 0;
+}
+
+int ugvc_feature_matrix(ugvc_ctx* ctx, float* x_host, uint8_t* group_host) {
+    if (!ctx || !x_host) return fail("NULL argument");
+    UGVC_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)ctx->n;
+    const size_t F = (size_t)(UGVC_N_BASE_FEATURES + ctx->n_tracks);
+    if (ensure(ctx->x_mat, n * F * 4) || ensure(ctx->x_group, n)) return -1;
+    FilterArgs a;
+    if (build_args(ctx, a, true)) return -1;
+    if (launch_filter(ctx, a, false, true)) return -1;
+    if (n) {
+        UGVC_HIP(hipMemcpyAsync(x_host, ctx->x_mat.p, n * F * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (group_host) UGVC_HIP(hipMemcpyAsync(group_host, ctx->x_group.p, n, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    UGVC_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+}  // extern "C"

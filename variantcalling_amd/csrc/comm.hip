@@ -1,0 +1,140 @@
+// Multi-GPU reassembly of the scored callset: RCCL all-gather over xGMI.
+//
+// One process per GPU.  Every rank scores a contiguous, equal-count (+-1) slice of the sorted
+// callset; the per-variant result record (tree_score f32, filter u8, flags u8) is gathered
+// as three column all-gathers issued as one RCCL group, in place (each rank's slice sits at
+// rank*shard_cap of the gather buffers), so rank-order concatenation == callset order.
+// RCCL is bound lazily with dlopen so single-GPU use never loads it.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <string.h>
+
+#include "ugvc_device.hpp"
+
+namespace ugvc {
+
+struct Rccl {
+    void* h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+static Rccl g_rccl;
+
+static int load_rccl() {
+    if (g_rccl.h) return 0;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names) {
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) return fail(std::string("cannot load RCCL: ") + dlerror());
+#define UGVC_SYM(field, name)                                                          \
+    g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(h, name));          \
+    if (!g_rccl.field) return fail(std::string("RCCL symbol missing: ") + name)
+    UGVC_SYM(GetUniqueId, "ncclGetUniqueId");
+    UGVC_SYM(CommInitRank, "ncclCommInitRank");
+    UGVC_SYM(CommDestroy, "ncclCommDestroy");
+    UGVC_SYM(AllGather, "ncclAllGather");
+    UGVC_SYM(GroupStart, "ncclGroupStart");
+    UGVC_SYM(GroupEnd, "ncclGroupEnd");
+    UGVC_SYM(GetErrorString, "ncclGetErrorString");
+#undef UGVC_SYM
+    g_rccl.h = h;
+    return 0;
+}
+
+#define UGVC_NCCL(expr)                                                                  \
+    do {                                                                                 \
+        ncclResult_t _r = (expr);                                                        \
+        if (_r != ncclSuccess)                                                           \
+            return ugvc::fail(std::string(#expr) + ": " + g_rccl.GetErrorString(_r));    \
+    } while (0)
+
+}  // namespace ugvc
+
+using namespace ugvc;
+
+extern "C" {
+
+int ugvc_comm_unique_id(uint8_t id[128]) {
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    if (!id) return fail("id is NULL");
+    if (load_rccl()) return -1;
+    ncclUniqueId u;
+    UGVC_NCCL(g_rccl.GetUniqueId(&u));
+    memcpy(id, &u, 128);
+    return 0;
+}
+
+int ugvc_comm_init(ugvc_ctx* ctx, const uint8_t id[128], int rank, int world) {
+    if (!ctx || !id) return fail("NULL argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail("bad rank/world");
+    if (load_rccl()) return -1;
+    UGVC_HIP(hipSetDevice(ctx->device));
+    if (ctx->comm) return fail("communicator already initialised");
+    ncclUniqueId u;
+    memcpy(&u, id, 128);
+    ncclComm_t comm = nullptr;
+    UGVC_NCCL(g_rccl.CommInitRank(&comm, world, u, rank));
+    ctx->comm = comm;
+    ctx->rank = rank;
+    ctx->world = world;
+    return 0;
+}
+
+int ugvc_comm_destroy(ugvc_ctx* ctx) {
+    if (!ctx || !ctx->comm) return 0;
+    (void)hipSetDevice(ctx->device);
+    if (g_rccl.CommDestroy) g_rccl.CommDestroy(static_cast<ncclComm_t>(ctx->comm));
+    ctx->comm = nullptr;
+    ctx->world = 1;
+    ctx->rank = 0;
+    return 0;
+}
+
+int ugvc_allgather_resident(ugvc_ctx* ctx, int64_t shard_cap) {
+    if (!ctx) return fail("ctx is NULL");
+    if (shard_cap < ctx->n) return fail("shard_cap smaller than this rank's variant count");
+    UGVC_HIP(hipSetDevice(ctx->device));
+    const size_t cap = (size_t)shard_cap, W = (size_t)ctx->world, r = (size_t)ctx->rank, n = (size_t)ctx->n;
+    if (ensure(ctx->g_score, cap * W * 4) || ensure(ctx->g_filter, cap * W) || ensure(ctx->g_flags, cap * W)) return -1;
+    float* gs = ctx->g_score.as<float>();
+    uint8_t* gf = ctx->g_filter.as<uint8_t>();
+    uint8_t* gl = ctx->g_flags.as<uint8_t>();
+    if (n) {
+        UGVC_HIP(hipMemcpyAsync(gs + r * cap, ctx->r_score.p, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        UGVC_HIP(hipMemcpyAsync(gf + r * cap, ctx->r_filter.p, n, hipMemcpyDeviceToDevice, ctx->stream));
+        UGVC_HIP(hipMemcpyAsync(gl + r * cap, ctx->r_flags.p, n, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if (ctx->world == 1) return 0;
+    if (!ctx->comm) return fail("communicator not initialised (ugvc_comm_init)");
+    ncclComm_t comm = static_cast<ncclComm_t>(ctx->comm);
+    UGVC_NCCL(g_rccl.GroupStart());
+    UGVC_NCCL(g_rccl.AllGather(gs + r * cap, gs, cap, ncclFloat32, comm, ctx->stream));
+    UGVC_NCCL(g_rccl.AllGather(gf + r * cap, gf, cap, ncclUint8, comm, ctx->stream));
+    UGVC_NCCL(g_rccl.AllGather(gl + r * cap, gl, cap, ncclUint8, comm, ctx->stream));
+    UGVC_NCCL(g_rccl.GroupEnd());
+    return 0;
+}
+
+int ugvc_gathered_download(ugvc_ctx* ctx, int64_t shard_cap, int world, const ugvc_results* out) {
+    if (!ctx || !out) return fail("NULL argument");
+    if (world != ctx->world) return fail("world does not match the communicator");
+    UGVC_HIP(hipSetDevice(ctx->device));
+    const size_t tot = (size_t)shard_cap * (size_t)world;
+    if (ctx->g_score.cap < tot * 4) return fail("nothing gathered yet (ugvc_allgather_resident)");
+    if (out->tree_score) UGVC_HIP(hipMemcpyAsync(out->tree_score, ctx->g_score.p, tot * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out->filter) UGVC_HIP(hipMemcpyAsync(out->filter, ctx->g_filter.p, tot, hipMemcpyDeviceToHost, ctx->stream));
+    if (out->flags) UGVC_HIP(hipMemcpyAsync(out->flags, ctx->g_flags.p, tot, hipMemcpyDeviceToHost, ctx->stream));
+    UGVC_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,143 @@
+// Shared device-side views and host context for libugvc_mi355x.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/ugvc_mi355x.h"
+
+namespace ugvc {
+
+constexpr int kBlock = 256;                                   // variants per workgroup
+constexpr int kMaxFeatures = UGVC_N_BASE_FEATURES + UGVC_MAX_TRACKS;
+constexpr int kMotif = 5;
+constexpr int kGcWindow = 10;
+
+// 16-byte tree node.  Leaves self-loop (thr = +inf, left = self) so a fixed-depth walk needs
+// no leaf test; `right` of a leaf is its payload row.
+struct __attribute__((aligned(16))) Node {
+    float thr;
+    int feat;
+    int left;
+    int right;
+};
+
+struct ForestView {
+    const Node* nodes;
+    const int* roots;
+    const double2* leaves;     // RF: (p_class0, p_class1); GBT: (margin, 0)
+    int n_trees;
+    int depth;                 // max root->leaf edges
+    int kind;
+    float base;
+    // dense layout (every tree padded to a complete binary tree of `depth` levels, BFS order):
+    const float2* dense;       // {thr, feat-as-int-bits}, (2^depth - 1) per tree
+    const double2* dense_leaves;  // 2^depth per tree
+};
+
+struct TrackView {
+    const int32_t* starts;
+    const int32_t* ends;
+    const int32_t* ptr;        // CSR by contig
+};
+
+struct FilterArgs {
+    int64_t n;
+    const uint8_t* contig;
+    const int32_t* pos;
+    const uint16_t* ref_len;
+    const uint16_t* alt_len;
+    const uint32_t* ref_off;
+    const uint32_t* alt_off;
+    const uint8_t* alleles;
+    const float* qual;
+    const float* sor;
+    const int32_t* dp;
+    const int32_t* ad_ref;
+    const int32_t* ad_alt;
+    const uint8_t* gq;
+    // reference genome
+    const uint8_t* ref;
+    const int64_t* contig_off;
+    // side tables
+    TrackView runs;
+    int has_runs, hpol_dist, mark_hpol;
+    TrackView tracks[UGVC_MAX_TRACKS];
+    int n_tracks;
+    const uint64_t* bl;
+    int64_t n_bl;
+    ForestView forest[UGVC_N_GROUPS];
+    uint8_t flow[4];
+    // outputs
+    float* score;
+    uint8_t* filter;
+    uint8_t* flags;
+    float* X;                  // optional N x F
+    uint8_t* group;            // optional
+};
+
+struct DeviceBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+}  // namespace ugvc
+
+struct ugvc_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int n_cus = 0;
+    // resident tables
+    ugvc::DeviceBuf ref, contig_off;
+    int n_contigs = 0;
+    int64_t ref_len = 0;
+    ugvc::DeviceBuf runs_s, runs_e, runs_p;
+    int has_runs = 0, hpol_dist = 10, mark_hpol = 1;
+    ugvc::DeviceBuf trk_s[UGVC_MAX_TRACKS], trk_e[UGVC_MAX_TRACKS], trk_p[UGVC_MAX_TRACKS];
+    int track_set[UGVC_MAX_TRACKS] = {0, 0, 0, 0, 0};
+    int n_tracks = 0;
+    ugvc::DeviceBuf bl;
+    int64_t n_bl = 0;
+    uint8_t flow[4] = {4, 3, 2, 1};   // TGCA
+    struct Model {
+        ugvc::DeviceBuf nodes, roots, leaves, dense, dense_leaves;
+        int n_trees = 0, depth = 0, kind = 0, n_features = 0, set = 0, has_dense = 0;
+        float base = 0.f;
+    } model[UGVC_N_GROUPS];
+    // resident variants + results
+    int64_t n = 0;
+    ugvc::DeviceBuf v_contig, v_pos, v_rl, v_al, v_ro, v_ao, v_alleles, v_qual, v_sor, v_dp,
+        v_adr, v_ada, v_gq;
+    ugvc::DeviceBuf r_score, r_filter, r_flags, x_mat, x_group;
+    // pileup
+    int64_t pl_n = 0, pl_obs = 0;
+    ugvc::DeviceBuf pl_off, pl_obsb, pl_out;
+    // gather
+    ugvc::DeviceBuf g_score, g_filter, g_flags;
+    void* comm = nullptr;
+    int rank = 0, world = 1;
+    int kernel_variant = 0;
+};
+
+namespace ugvc {
+void set_error(const std::string& msg);
+int fail(const std::string& msg);
+int ensure(DeviceBuf& b, size_t bytes);
+int upload(ugvc_ctx* ctx, DeviceBuf& b, const void* src, size_t bytes);
+int build_args(ugvc_ctx* ctx, FilterArgs& a, bool want_x);
+int launch_filter(ugvc_ctx* ctx, const FilterArgs& a, bool score, bool write_x);
+int launch_pileup(ugvc_ctx* ctx);
+int launch_sec(ugvc_ctx* ctx, const int32_t* d_actual, const int32_t* d_expected, int64_t n, int k,
+               double* d_lik, double* d_ratio);
+}  // namespace ugvc
+
+#define UGVC_HIP(expr)                                                                     \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess)                                                              \
+            return ugvc::fail(std::string(#expr) + ": " + hipGetErrorString(_e));          \
+    } while (0)

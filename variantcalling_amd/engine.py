@@ -1,0 +1,352 @@
+"""ctypes binding of libugvc_mi355x.so (include/ugvc_mi355x.h) - the only compute path.
+
+There is NO CPU fallback: if the shared library is missing or no MI355X is visible this
+module raises, loudly.  Host side mirrors the reference's pandas-level calls
+(`annotate_concordance(df, fasta, ...)`, blacklist apply, `model.predict`;
+call pattern ugvc/pipelines/run_no_gt_report.py:92-94,314 and SURVEY.md §3.1) on SoA tables.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import schema as S
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libugvc_mi355x.so")
+
+_u8p, _u16p, _u32p, _u64p = (C.POINTER(t) for t in (C.c_uint8, C.c_uint16, C.c_uint32, C.c_uint64))
+_i32p, _i64p, _f32p, _f64p = (C.POINTER(t) for t in (C.c_int32, C.c_int64, C.c_float, C.c_double))
+
+
+class CVariants(C.Structure):
+    _fields_ = [("n", C.c_int64), ("contig", _u8p), ("pos", _i32p), ("ref_len", _u16p), ("alt_len", _u16p),
+                ("ref_off", _u32p), ("alt_off", _u32p), ("alleles", _u8p), ("alleles_len", C.c_int64),
+                ("qual", _f32p), ("sor", _f32p), ("dp", _i32p), ("ad_ref", _i32p), ("ad_alt", _i32p),
+                ("gq", _u8p)]
+
+
+class CResults(C.Structure):
+    _fields_ = [("tree_score", _f32p), ("filter", _u8p), ("flags", _u8p)]
+
+
+class CPileupOut(C.Structure):
+    _fields_ = [(k, _i32p) for k in ("ref_fwd", "ref_rev", "alt_fwd", "alt_rev", "other", "dp", "bq_ref", "bq_alt")] + \
+               [("vaf", _f32p), ("sor", _f32p)]
+
+
+class CBridgingParams(C.Structure):
+    _fields_ = [("min_initial_qual", C.c_double), ("min_tumor_vaf", C.c_double), ("max_normal_vaf", C.c_double),
+                ("min_query_hmer_size", C.c_int), ("min_normal_depth", C.c_int), ("min_distance_from_edge", C.c_int)]
+
+
+# every symbol include/ugvc_mi355x.h declares: (restype, argtypes)
+_ctx = C.c_void_p
+ABI = {
+    "ugvc_abi_version": (C.c_int, []),
+    "ugvc_last_error": (C.c_char_p, []),
+    "ugvc_ctx_create": (C.c_int, [C.c_int, C.POINTER(_ctx)]),
+    "ugvc_ctx_destroy": (C.c_int, [_ctx]),
+    "ugvc_device_info": (C.c_int, [_ctx, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
+    "ugvc_sync": (C.c_int, [_ctx]),
+    "ugvc_ref_upload": (C.c_int, [_ctx, _u8p, C.c_int64, _i64p, C.c_int]),
+    "ugvc_runs_upload": (C.c_int, [_ctx, _i32p, _i32p, _i32p, C.c_int64, C.c_int, C.c_int, C.c_int]),
+    "ugvc_track_upload": (C.c_int, [_ctx, C.c_int, _i32p, _i32p, _i32p, C.c_int64]),
+    "ugvc_set_n_tracks": (C.c_int, [_ctx, C.c_int]),
+    "ugvc_blacklist_upload": (C.c_int, [_ctx, _u64p, C.c_int64]),
+    "ugvc_set_flow_order": (C.c_int, [_ctx, C.c_char_p]),
+    "ugvc_model_upload": (C.c_int, [_ctx, C.c_int, C.c_int, _i32p, _f32p, _i32p, _i32p, C.c_int32, _i32p,
+                                    C.c_int32, _f64p, C.c_int32, C.c_int32, C.c_float, C.c_int32]),
+    "ugvc_filter_variants": (C.c_int, [_ctx, C.POINTER(CVariants), C.POINTER(CResults)]),
+    "ugvc_variants_upload": (C.c_int, [_ctx, C.POINTER(CVariants)]),
+    "ugvc_filter_resident": (C.c_int, [_ctx]),
+    "ugvc_results_download": (C.c_int, [_ctx, C.POINTER(CResults)]),
+    "ugvc_timed_filter": (C.c_int, [_ctx, C.c_int, _f32p]),
+    "ugvc_timed_steps": (C.c_int, [_ctx, C.c_int, C.c_int64, C.c_int, _f32p, _f32p]),
+    "ugvc_device_sync": (C.c_int, [_ctx]),
+    "ugvc_feature_matrix": (C.c_int, [_ctx, _f32p, _u8p]),
+    "ugvc_n_features": (C.c_int, [_ctx]),
+    "ugvc_set_kernel_variant": (C.c_int, [_ctx, C.c_int]),
+    "ugvc_pileup_tally": (C.c_int, [_ctx, _i64p, _u16p, C.c_int64, C.POINTER(CPileupOut)]),
+    "ugvc_pileup_upload": (C.c_int, [_ctx, _i64p, _u16p, C.c_int64]),
+    "ugvc_timed_pileup": (C.c_int, [_ctx, C.c_int, _f32p]),
+    "ugvc_sec_likelihood_ratio": (C.c_int, [_ctx, _i32p, _i32p, C.c_int64, C.c_int, _f64p, _f64p]),
+    "ugvc_bridging_snvs": (C.c_int, [_ctx, C.POINTER(CVariants), _u8p, _i32p, _i32p, _i32p,
+                                     C.POINTER(CBridgingParams), _u8p, _u8p]),
+    "ugvc_comm_unique_id": (C.c_int, [_u8p]),
+    "ugvc_comm_init": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int]),
+    "ugvc_comm_destroy": (C.c_int, [_ctx]),
+    "ugvc_allgather_resident": (C.c_int, [_ctx, C.c_int64]),
+    "ugvc_gathered_download": (C.c_int, [_ctx, C.c_int64, C.c_int, C.POINTER(CResults)]),
+}
+
+_lib = None
+
+
+def load_library(path: str = LIB_PATH):
+    """dlopen the engine and bind every ABI symbol; raises if the library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C variantcalling_amd/csrc`.  There is no CPU fallback.")
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in ABI.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ugvc_abi_version() != 1:
+        raise RuntimeError("libugvc_mi355x.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _p(a: np.ndarray, typ):
+    return a.ctypes.data_as(typ)
+
+
+def _col(a, dtype) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+class Engine:
+    """One GPU context (= one ugvc_ctx).  Methods raise RuntimeError(ugvc_last_error())."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = _ctx()
+        self._h = None
+        self._check(self.lib.ugvc_ctx_create(device, C.byref(h)))
+        self._h = h
+        self.n_tracks = 0
+        self._keep = []   # host arrays that must outlive async calls
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise RuntimeError(self.lib.ugvc_last_error().decode() or f"ugvc error {rc}")
+
+    def close(self):
+        if self._h is not None:
+            self.lib.ugvc_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- info
+    def device_info(self) -> dict:
+        name = C.create_string_buffer(256)
+        cus, mem = C.c_int(), C.c_int64()
+        self._check(self.lib.ugvc_device_info(self._h, name, 256, C.byref(cus), C.byref(mem)))
+        return dict(name=name.value.decode(), n_cus=cus.value, hbm_bytes=mem.value)
+
+    def sync(self):
+        self._check(self.lib.ugvc_sync(self._h))
+
+    # ---- resident tables
+    def set_reference(self, ref: S.Reference):
+        codes = _col(ref.codes, np.uint8)
+        off = _col(ref.contig_off, np.int64)
+        self._check(self.lib.ugvc_ref_upload(self._h, _p(codes, _u8p), codes.size, _p(off, _i64p), off.size - 1))
+        self.n_contigs = off.size - 1
+
+    def set_runs(self, runs: S.IntervalTrack, min_len: int = 10, max_dist: int = 10, mark_hpol: bool = True):
+        s, e, p = _col(runs.starts, np.int32), _col(runs.ends, np.int32), _col(runs.contig_ptr, np.int32)
+        self._check(self.lib.ugvc_runs_upload(self._h, _p(s, _i32p), _p(e, _i32p), _p(p, _i32p), s.size,
+                                              int(min_len), int(max_dist), int(bool(mark_hpol))))
+
+    def set_tracks(self, tracks: list):
+        if len(tracks) > S.MAX_TRACKS:
+            raise ValueError(f"at most {S.MAX_TRACKS} annotation tracks")
+        for t, tr in enumerate(tracks):
+            s, e, p = _col(tr.starts, np.int32), _col(tr.ends, np.int32), _col(tr.contig_ptr, np.int32)
+            self._check(self.lib.ugvc_track_upload(self._h, t, _p(s, _i32p), _p(e, _i32p), _p(p, _i32p), s.size))
+        self._check(self.lib.ugvc_set_n_tracks(self._h, len(tracks)))
+        self.n_tracks = len(tracks)
+
+    def set_blacklist(self, keys: np.ndarray | None):
+        k = _col(keys if keys is not None else np.zeros(0, np.uint64), np.uint64)
+        self._check(self.lib.ugvc_blacklist_upload(self._h, _p(k, _u64p), k.size))
+
+    def set_flow_order(self, flow: str):
+        self._check(self.lib.ugvc_set_flow_order(self._h, flow.encode()))
+
+    def set_model(self, group: int, f: S.FlatForest):
+        feat, thr = _col(f.feature, np.int32), _col(f.threshold, np.float32)
+        left, right = _col(f.left, np.int32), _col(f.right, np.int32)
+        roots, leaves = _col(f.tree_root, np.int32), _col(f.leaf_value, np.float64)
+        self._check(self.lib.ugvc_model_upload(
+            self._h, group, f.kind, _p(feat, _i32p), _p(thr, _f32p), _p(left, _i32p), _p(right, _i32p),
+            feat.size, _p(roots, _i32p), roots.size, _p(leaves, _f64p), leaves.shape[0], f.n_features,
+            float(f.base_score), 0))
+
+    def set_models(self, forests: list):
+        for g, f in enumerate(forests):
+            if f is not None:
+                self.set_model(g, f)
+
+    def set_kernel_variant(self, v: int):
+        self._check(self.lib.ugvc_set_kernel_variant(self._h, v))
+
+    # ---- hot path
+    def _cvariants(self, vt: S.VariantTable) -> CVariants:
+        cols = {c: _col(getattr(vt, c), S.VariantTable.DTYPES[c]) for c in S.VariantTable.COLS if c != "gt"}
+        alle = _col(vt.alleles, np.uint8)
+        self._keep = [cols, alle]
+        return CVariants(vt.n, _p(cols["contig"], _u8p), _p(cols["pos"], _i32p), _p(cols["ref_len"], _u16p),
+                         _p(cols["alt_len"], _u16p), _p(cols["ref_off"], _u32p), _p(cols["alt_off"], _u32p),
+                         _p(alle, _u8p), alle.size, _p(cols["qual"], _f32p), _p(cols["sor"], _f32p),
+                         _p(cols["dp"], _i32p), _p(cols["ad_ref"], _i32p), _p(cols["ad_alt"], _i32p),
+                         _p(cols["gq"], _u8p))
+
+    @staticmethod
+    def _alloc_results(n: int):
+        res = S.FilterResult(np.zeros(n, np.float32), np.zeros(n, np.uint8), np.zeros(n, np.uint8))
+        return res, CResults(_p(res.tree_score, _f32p), _p(res.filter, _u8p), _p(res.flags, _u8p))
+
+    def filter_variants(self, vt: S.VariantTable) -> S.FilterResult:
+        """featurize -> lookup -> score -> FILTER for one table (H2D + kernel + D2H)."""
+        cv = self._cvariants(vt)
+        res, cr = self._alloc_results(vt.n)
+        self._check(self.lib.ugvc_filter_variants(self._h, C.byref(cv), C.byref(cr)))
+        self.n = vt.n
+        return res
+
+    def upload_variants(self, vt: S.VariantTable):
+        cv = self._cvariants(vt)
+        self._check(self.lib.ugvc_variants_upload(self._h, C.byref(cv)))
+        self.n = vt.n
+
+    def filter_resident(self):
+        self._check(self.lib.ugvc_filter_resident(self._h))
+
+    def download_results(self) -> S.FilterResult:
+        res, cr = self._alloc_results(self.n)
+        self._check(self.lib.ugvc_results_download(self._h, C.byref(cr)))
+        return res
+
+    def timed_filter(self, iters: int) -> float:
+        """Total milliseconds of `iters` back-to-back kernel launches (hipEvents on the stream)."""
+        ms = C.c_float()
+        self._check(self.lib.ugvc_timed_filter(self._h, iters, C.byref(ms)))
+        return ms.value
+
+    def timed_steps(self, iters: int, shard_cap: int = 0, gather: bool = False):
+        """(ms_total, ms_kernel_sum) of `iters` steps = kernel [+ RCCL all-gather] on the stream."""
+        tot, ker = C.c_float(), C.c_float()
+        self._check(self.lib.ugvc_timed_steps(self._h, iters, shard_cap, int(gather), C.byref(tot), C.byref(ker)))
+        return tot.value, ker.value
+
+    def device_sync(self):
+        self._check(self.lib.ugvc_device_sync(self._h))
+
+    def n_features(self) -> int:
+        return self.lib.ugvc_n_features(self._h)
+
+    def feature_matrix(self, vt: S.VariantTable | None = None):
+        """(X float32 [n, F], group u8 [n]) - the matrix train_models_pipeline fits on."""
+        if vt is not None:
+            self.upload_variants(vt)
+        F = self.n_features()
+        X = np.zeros((self.n, F), np.float32)
+        g = np.zeros(self.n, np.uint8)
+        self._check(self.lib.ugvc_feature_matrix(self._h, _p(X, _f32p), _p(g, _u8p)))
+        return X, g
+
+    # ---- pileup
+    def pileup_tally(self, offsets: np.ndarray, obs: np.ndarray) -> dict:
+        off, ob = _col(offsets, np.int64), _col(obs, np.uint16)
+        n = off.size - 1
+        out = {k: np.zeros(n, np.int32) for k in ("ref_fwd", "ref_rev", "alt_fwd", "alt_rev", "other", "dp",
+                                                  "bq_ref", "bq_alt")}
+        out["vaf"] = np.zeros(n, np.float32)
+        out["sor"] = np.zeros(n, np.float32)
+        co = CPileupOut(*[_p(out[k], _i32p) for k in ("ref_fwd", "ref_rev", "alt_fwd", "alt_rev", "other", "dp",
+                                                      "bq_ref", "bq_alt")],
+                        _p(out["vaf"], _f32p), _p(out["sor"], _f32p))
+        self._check(self.lib.ugvc_pileup_tally(self._h, _p(off, _i64p), _p(ob, _u16p), n, C.byref(co)))
+        out["ad_ref"] = out["ref_fwd"] + out["ref_rev"]
+        out["ad_alt"] = out["alt_fwd"] + out["alt_rev"]
+        return out
+
+    def upload_pileup(self, offsets, obs):
+        off, ob = _col(offsets, np.int64), _col(obs, np.uint16)
+        self._check(self.lib.ugvc_pileup_upload(self._h, _p(off, _i64p), _p(ob, _u16p), off.size - 1))
+
+    def timed_pileup(self, iters: int) -> float:
+        ms = C.c_float()
+        self._check(self.lib.ugvc_timed_pileup(self._h, iters, C.byref(ms)))
+        return ms.value
+
+    # ---- SEC statistic
+    def sec_likelihood_ratio(self, actual: np.ndarray, expected: np.ndarray):
+        a, e = _col(actual, np.int32), _col(expected, np.int32)
+        if a.ndim != 2 or a.shape != e.shape:
+            raise ValueError("actual/expected must be [n_loci, k] of equal shape")
+        lik, ratio = np.zeros(a.shape[0]), np.zeros(a.shape[0])
+        self._check(self.lib.ugvc_sec_likelihood_ratio(self._h, _p(a, _i32p), _p(e, _i32p), a.shape[0], a.shape[1],
+                                                       _p(lik, _f64p), _p(ratio, _f64p)))
+        return lik, ratio
+
+    # ---- calibrate_bridging_snvs
+    def bridging_snvs(self, vt: S.VariantTable, is_pass, ad_alt_sum, bg_ad_alt_sum, bg_dp,
+                      min_query_hmer_size=5, min_initial_qual=5, min_tumor_vaf=0.2, max_normal_vaf=0.1,
+                      min_normal_depth=10, min_distance_from_edge=0):
+        cv = self._cvariants(vt)
+        ip, a, b, d = (_col(is_pass, np.uint8), _col(ad_alt_sum, np.int32), _col(bg_ad_alt_sum, np.int32),
+                       _col(bg_dp, np.int32))
+        prm = CBridgingParams(min_initial_qual, min_tumor_vaf, max_normal_vaf, min_query_hmer_size,
+                              min_normal_depth, min_distance_from_edge)
+        oh, op = np.zeros(vt.n, np.uint8), np.zeros(vt.n, np.uint8)
+        self._check(self.lib.ugvc_bridging_snvs(self._h, C.byref(cv), _p(ip, _u8p), _p(a, _i32p), _p(b, _i32p),
+                                                _p(d, _i32p), C.byref(prm), _p(oh, _u8p), _p(op, _u8p)))
+        self.n = vt.n
+        return oh.astype(bool), op.astype(bool)
+
+    # ---- multi-GPU
+    def comm_unique_id(self) -> bytes:
+        buf = np.zeros(128, np.uint8)
+        self._check(self.lib.ugvc_comm_unique_id(_p(buf, _u8p)))
+        return buf.tobytes()
+
+    def comm_init(self, uid: bytes, rank: int, world: int):
+        buf = np.frombuffer(uid, dtype=np.uint8).copy()
+        self._check(self.lib.ugvc_comm_init(self._h, _p(buf, _u8p), rank, world))
+        self.rank, self.world = rank, world
+
+    def allgather_resident(self, shard_cap: int):
+        self._check(self.lib.ugvc_allgather_resident(self._h, shard_cap))
+
+    def gathered_download(self, shard_cap: int, world: int, counts: list) -> S.FilterResult:
+        tot = shard_cap * world
+        res, cr = self._alloc_results(tot)
+        self._check(self.lib.ugvc_gathered_download(self._h, shard_cap, world, C.byref(cr)))
+        sel = np.concatenate([np.arange(r * shard_cap, r * shard_cap + c) for r, c in enumerate(counts)])
+        return S.FilterResult(res.tree_score[sel], res.filter[sel], res.flags[sel])
+
+
+def configure(engine: Engine, ref, runs, tracks, blacklist, forests, flow_order="TGCA", hpol_len=10,
+              hpol_dist=10, mark_hpol=True):
+    """Load every resident table of one filtering job (the reference builds the same state from
+    --reference_file/--runs_file/--annotate_intervals/--blacklist/--model_file)."""
+    engine.set_reference(ref)
+    if runs is not None:
+        engine.set_runs(runs, hpol_len, hpol_dist, mark_hpol)
+    engine.set_tracks(tracks or [])
+    engine.set_blacklist(blacklist)
+    engine.set_flow_order(flow_order)
+    engine.set_models(forests)
+    return engine
