@@ -95,6 +95,7 @@ int build_args(ugvc_ctx* ctx, FilterArgs& a, bool want_x) {
     a.flags = ctx->r_flags.as<uint8_t>();
     a.X = want_x ? ctx->x_mat.as<float>() : nullptr;
     a.group = want_x ? ctx->x_group.as<uint8_t>() : nullptr;
+    a.ablate = ctx->kernel_variant;
     return 0;
 }
 

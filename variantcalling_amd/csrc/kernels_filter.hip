@@ -167,7 +167,7 @@ __global__ __launch_bounds__(kBlock) void filter_kernel(const FilterArgs a) {
 
         // ---- is_hmer_indel
         int hmer_len = 0, hmer_nuc = 0;
-        if (indel) {
+        if (indel && !(a.ablate & 8)) {
             const uint8_t* alle = pool + (classify == 1 ? ao : ro);
             const int ln = classify == 1 ? al : rl;
             const int b = alle[1];
@@ -191,8 +191,8 @@ __global__ __launch_bounds__(kBlock) void filter_kernel(const FilterArgs a) {
         int lm = 0, rm = 0;
 #pragma unroll
         for (int k = 0; k < kMotif; ++k) {
-            lmb[k] = rw.at(lstart + k);
-            rmb[k] = rw.at(rstart + k);
+            lmb[k] = (a.ablate & 8) ? 1 : rw.at(lstart + k);
+            rmb[k] = (a.ablate & 8) ? 2 : rw.at(rstart + k);
             lm = lm * 5 + lmb[k];
             rm = rm * 5 + rmb[k];
         }
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(kBlock) void filter_kernel(const FilterArgs a) {
 #pragma unroll
         for (int k = 0; k < kGcWindow; ++k) {
             const int64_t w = g0 + 1 - kGcWindow / 2 + k;
-            const bool inb = w >= rw.lo && w < rw.hi;
+            const bool inb = w >= rw.lo && w < rw.hi && !(a.ablate & 8);
             const int b = inb ? rw.codes[w] : 0;
             gc_len += inb;
             gc_cnt += inb && b != 1 && b != 4;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kBlock) void filter_kernel(const FilterArgs a) {
 
         // ---- cycle skip (substitutions only)
         int css = 3;
-        if (!indel) {
+        if (!indel && !(a.ablate & 4)) {
             const int L = rl + 2 * kMotif;
             bool has_n = false;
 #pragma unroll
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(kBlock) void filter_kernel(const FilterArgs a) {
 
         // ---- hmer-run proximity (close_to_hmer_run) and interval tracks
         bool inside_run = false, close_run = false;
-        if (a.has_runs) {
+        if (a.has_runs && !(a.ablate & 2)) {
             const int lo = a.runs.ptr[c], hi = a.runs.ptr[c + 1];
             const int nr = hi - lo;
             if (nr > 0) {
@@ -265,13 +265,13 @@ __global__ __launch_bounds__(kBlock) void filter_kernel(const FilterArgs a) {
 #pragma unroll
         for (int t = 0; t < UGVC_MAX_TRACKS; ++t) {
             trk[t] = 0.f;
-            if (t < a.n_tracks) {
+            if (t < a.n_tracks && !(a.ablate & 2)) {
                 const bool in = inside_track(a.tracks[t], c, pos);
                 trk[t] = in ? 1.f : 0.f;
                 flags |= in ? (uint8_t)(1u << (UGVC_FLAG_TRACK0_SHIFT + t)) : 0;
             }
         }
-        if (a.n_bl > 0 && contains_u64(a.bl, a.n_bl, ((uint64_t)c << 32) | (uint32_t)pos))
+        if (a.n_bl > 0 && !(a.ablate & 2) && contains_u64(a.bl, a.n_bl, ((uint64_t)c << 32) | (uint32_t)pos))
             flags |= UGVC_FLAG_COHORT_FP;
 
         // ---- feature vector (schema.BASE_FEATURES order) into LDS
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(kBlock) void filter_kernel(const FilterArgs a) {
         uint8_t filt = UGVC_FILTER_PASS;
         // each lane only reads its own LDS column, written above by itself: no barrier needed
         const ForestView& f = a.forest[group];
-        if (f.n_trees > 0) {
+        if (f.n_trees > 0 && !(a.ablate & 1)) {
             if (f.kind == UGVC_MODEL_RF) walk_forest<UGVC_MODEL_RF>(f, xs + tid, score, filt);
             else walk_forest<UGVC_MODEL_GBT>(f, xs + tid, score, filt);
         }

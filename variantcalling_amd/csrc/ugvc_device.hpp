@@ -76,6 +76,8 @@ struct FilterArgs {
     uint8_t* flags;
     float* X;                  // optional N x F
     uint8_t* group;            // optional
+    int ablate;                // debug/profiling only: bit0 no forest walk, bit1 no side-table joins,
+                               // bit2 no cycle-skip, bit3 no reference-derived features
 };
 
 struct DeviceBuf {
