@@ -143,6 +143,11 @@ int ugvc_timed_steps(ugvc_ctx* ctx, int iters, int64_t shard_cap, int gather, fl
 int ugvc_device_sync(ugvc_ctx* ctx);   /* hipDeviceSynchronize on the context's device */
 int ugvc_feature_matrix(ugvc_ctx* ctx, float* x_host, uint8_t* group_host);
 int ugvc_n_features(ugvc_ctx* ctx);
+/* Host-only (no GPU): the single-base-substitution cycle-skip table the kernels use for a flow
+ * order; index = (last left base)<<6 | ref<<4 | alt<<2 | (first right base), bases A,C,G,T = 0..3,
+ * value 0 non-skip / 1 possible-cycle-skip / 2 cycle-skip.  Exposed so CPU tests can check it
+ * against the full flow-key computation. */
+int ugvc_host_css_lut(const char* flow4, uint8_t out[256]);
 int ugvc_set_kernel_variant(ugvc_ctx* ctx, int variant);
 
 /* ---- pileup allele/strand/base-quality tally (builder-defined) ---------

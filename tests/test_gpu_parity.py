@@ -40,10 +40,22 @@ def test_library_is_loaded_in_tree(engine):
         assert "libugvc_mi355x.so" in fh.read()
 
 
-def test_filter_synthetic_rf(engine, small_callset, frozen_models):
+PATHS = pytest.mark.parametrize("path", [0, 256], ids=["v2-lds-forest", "v1-universal"])
+
+
+@pytest.fixture(autouse=True)
+def _reset_variant(request):
+    yield
+    if "engine" in request.fixturenames:
+        request.getfixturevalue("engine").set_kernel_variant(0)
+
+
+@PATHS
+def test_filter_synthetic_rf(engine, small_callset, frozen_models, path):
     cs = small_callset
     O = _oracle()
     _configure(engine, cs.ref, cs.runs, cs.tracks, cs.blacklist, frozen_models[RF])
+    engine.set_kernel_variant(path)
     res = engine.filter_variants(cs.variants)
     exp = O.filter_variants(cs.variants, cs.ref, cs.runs, cs.tracks, cs.blacklist, frozen_models[RF])
     _assert_same(res, exp, "synthetic C3-shaped")
@@ -62,7 +74,8 @@ def test_feature_matrix_bit_exact(engine, small_callset, frozen_models):
     assert np.array_equal(g, ft["group"].astype(np.uint8))
 
 
-def test_filter_edge_cases_real_hg38(engine, frozen_models):
+@PATHS
+def test_filter_edge_cases_real_hg38(engine, frozen_models, path):
     """Contig ends, N runs, 50 kb 'N homopolymers', MNPs, 60 bp indels, dp = 0, empty track contig."""
     O = _oracle()
     ref = real_chr1_reference()
@@ -71,6 +84,7 @@ def test_filter_edge_cases_real_hg38(engine, frozen_models):
     bl = np.unique(np.concatenate([vt.keys()[::7], vt.keys()[::11] + np.uint64(1)]))
     for flow in ("TGCA", "ACGT", "GTAC"):
         _configure(engine, ref, runs, tracks, bl, frozen_models[RF], hpol_len=8, hpol_dist=12, flow=flow)
+        engine.set_kernel_variant(path)
         res = engine.filter_variants(vt)
         exp = O.filter_variants(vt, ref, runs, tracks, bl, frozen_models[RF], flow_order=flow, hpol_len=8, hpol_dist=12)
         _assert_same(res, exp, f"edge flow={flow}")
@@ -78,20 +92,24 @@ def test_filter_edge_cases_real_hg38(engine, frozen_models):
         assert np.array_equal(X, O.featurize(vt, ref, runs, tracks, flow, 8, 12)["X"])
 
 
-def test_snv_only_c2_shape(engine, frozen_models):
+@PATHS
+def test_snv_only_c2_shape(engine, frozen_models, path):
     from variantcalling_amd import synth
     O = _oracle()
     cs = synth.make_callset(50_000, genome_len=20_000_000, n_contigs=4, seed=77, snv_only=True)
     _configure(engine, cs.ref, cs.runs, cs.tracks, cs.blacklist, frozen_models[RF])
+    engine.set_kernel_variant(path)
     _assert_same(engine.filter_variants(cs.variants),
                  O.filter_variants(cs.variants, cs.ref, cs.runs, cs.tracks, cs.blacklist, frozen_models[RF]), "C2")
 
 
-def test_gbt_model(engine, small_callset, frozen_models):
+@PATHS
+def test_gbt_model(engine, small_callset, frozen_models, path):
     """XGBoost-shaped ensemble: FILTER bit-exact (decided on the f32 margin), score within 1e-6."""
     cs = small_callset
     O = _oracle()
     _configure(engine, cs.ref, cs.runs, cs.tracks, cs.blacklist, frozen_models[XGB])
+    engine.set_kernel_variant(path)
     res = engine.filter_variants(cs.variants)
     exp = O.filter_variants(cs.variants, cs.ref, cs.runs, cs.tracks, cs.blacklist, frozen_models[XGB])
     assert np.array_equal(res.filter, exp.filter)

@@ -6,7 +6,7 @@
 #include <algorithm>
 #include <limits>
 
-#include "ugvc_device.hpp"
+#include "ugvc_v2.hpp"
 
 namespace ugvc {
 
@@ -96,7 +96,16 @@ int build_args(ugvc_ctx* ctx, FilterArgs& a, bool want_x) {
     a.X = want_x ? ctx->x_mat.as<float>() : nullptr;
     a.group = want_x ? ctx->x_group.as<uint8_t>() : nullptr;
     a.ablate = ctx->kernel_variant;
+    a.n_contigs = ctx->n_contigs;
     return 0;
+}
+
+// The scoring pass: v2 (K0 brackets + K1 featurize/quantise + K2 LDS forest) whenever every
+// uploaded model packs into the LDS layout, else the universal v1 fused kernel.
+// kernel_variant bit 8 (256) forces v1 (A/B measurements, parity cross-checks).
+int launch_score(ugvc_ctx* ctx, const FilterArgs& a) {
+    if (!(ctx->kernel_variant & 256) && v2_available(ctx)) return launch_filter_v2(ctx, a);
+    return launch_filter(ctx, a, true, false);
 }
 
 }  // namespace ugvc
@@ -134,6 +143,7 @@ int ugvc_ctx_destroy(ugvc_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     ugvc_comm_destroy(ctx);
+    v2_destroy(ctx);
     DeviceBuf* all[] = {&ctx->ref, &ctx->contig_off, &ctx->runs_s, &ctx->runs_e, &ctx->runs_p, &ctx->bl,
                         &ctx->v_contig, &ctx->v_pos, &ctx->v_rl, &ctx->v_al, &ctx->v_ro, &ctx->v_ao,
                         &ctx->v_alleles, &ctx->v_qual, &ctx->v_sor, &ctx->v_dp, &ctx->v_adr, &ctx->v_ada,
@@ -183,6 +193,9 @@ int ugvc_ref_upload(ugvc_ctx* ctx, const uint8_t* codes, int64_t total_len, cons
     for (int c = 0; c < n_contigs; ++c)
         if (contig_off[c + 1] < contig_off[c]) return fail("contig_off must be non-decreasing");
     UGVC_HIP(hipSetDevice(ctx->device));
+    // 64 zero bytes of padding: the v2 kernel reads 16-byte aligned 64-byte windows
+    if (ensure(ctx->ref, (size_t)total_len + 64)) return -1;
+    UGVC_HIP(hipMemsetAsync(static_cast<uint8_t*>(ctx->ref.p) + total_len, 0, 64, ctx->stream));
     if (upload(ctx, ctx->ref, codes, (size_t)total_len)) return -1;
     if (upload(ctx, ctx->contig_off, contig_off, sizeof(int64_t) * (n_contigs + 1))) return -1;
     UGVC_HIP(hipStreamSynchronize(ctx->stream));
@@ -276,7 +289,7 @@ int ugvc_set_flow_order(ugvc_ctx* ctx, const char* flow4) {
         ctx->flow[k] = (uint8_t)code;
     }
     if (seen != 0x1e) return fail("flow order must be a permutation of ACGT");
-    return 0;
+    return build_css_lut(ctx);
 }
 
 int ugvc_model_upload(ugvc_ctx* ctx, int group, int kind, const int32_t* feature, const float* threshold,
@@ -336,7 +349,8 @@ int ugvc_model_upload(ugvc_ctx* ctx, int group, int kind, const int32_t* feature
     m.base = base_score;
     m.set = 1;
     m.has_dense = 0;
-    return 0;
+    return pack_model_group(ctx, group, feature, threshold, left, right, n_nodes, tree_root, n_trees, leaf_value,
+                            n_leaves, n_features, kind, base_score, depth);
 }
 
 static int check_variants(const ugvc_variants* v) {
@@ -391,7 +405,7 @@ int ugvc_filter_resident(ugvc_ctx* ctx) {
     UGVC_HIP(hipSetDevice(ctx->device));
     FilterArgs a;
     if (build_args(ctx, a, false)) return -1;
-    return launch_filter(ctx, a, true, false);
+    return launch_score(ctx, a);
 }
 
 int ugvc_results_download(ugvc_ctx* ctx, const ugvc_results* out) {
@@ -420,7 +434,7 @@ int ugvc_timed_filter(ugvc_ctx* ctx, int iters, float* ms_total) {
     if (build_args(ctx, a, false)) return -1;
     UGVC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     for (int it = 0; it < iters; ++it)
-        if (launch_filter(ctx, a, true, false)) return -1;
+        if (launch_score(ctx, a)) return -1;
     UGVC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     UGVC_HIP(hipEventSynchronize(ctx->ev1));
     UGVC_HIP(hipEventElapsedTime(ms_total, ctx->ev0, ctx->ev1));
@@ -447,7 +461,7 @@ int ugvc_timed_steps(ugvc_ctx* ctx, int iters, int64_t shard_cap, int gather, fl
     UGVC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     for (int it = 0; it < iters && !rc; ++it) {
         UGVC_HIP(hipEventRecord(ev[2 * it], ctx->stream));
-        rc = launch_filter(ctx, a, true, false);
+        rc = launch_score(ctx, a);
         UGVC_HIP(hipEventRecord(ev[2 * it + 1], ctx->stream));
         if (!rc && gather) rc = ugvc_allgather_resident(ctx, shard_cap);
     }

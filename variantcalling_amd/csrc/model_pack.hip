@@ -1,0 +1,332 @@
+// Host-side preparation of the v2 fast path: rank-quantised dense forests, per-feature code
+// tables (LUT / sorted thresholds), code bit-packing layout, cycle-skip LUT.  See ugvc_v2.hpp.
+#include <algorithm>
+#include <cmath>
+#include <map>
+
+#include "ugvc_v2.hpp"
+
+namespace ugvc {
+
+struct V2Group {
+    bool set = false, ok = false;
+    int kind = 0, T = 0, D = 0, n_pairs = 0, n_features = 0;
+    float base = 0.f;
+    std::string why;
+    std::vector<uint32_t> nodes;       // filled by finalize (needs the packing layout)
+    std::vector<uint16_t> leaf_idx;
+    std::vector<double> pairs;
+    std::vector<float> leaf_f32;
+    std::vector<std::vector<float>> uthr;   // sorted unique thresholds per feature
+    // pointer-layout copy kept to rebuild the dense tables when the layout changes
+    std::vector<int32_t> feature, left, right, roots;
+    std::vector<float> threshold;
+    std::vector<double> leaf_value;
+    int dword[kMaxFeatures], bit_off[kMaxFeatures], width[kMaxFeatures], plane[kMaxFeatures];
+    int n_planes = 0;
+    std::vector<uint32_t> plane_desc;
+    DeviceBuf d_nodes, d_leaf_idx, d_pairs, d_leaf_f32, d_plane_desc;
+};
+
+struct V2State {
+    V2Group g[UGVC_N_GROUPS];
+    DeviceBuf desc, lut, thr, css, brackets, counters;
+    DeviceBuf rec[UGVC_N_GROUPS];
+    int thr_lds_len = 0;
+    bool dirty = true, ok = false;
+    std::string why;
+};
+
+static V2State* state(ugvc_ctx* ctx) {
+    if (!ctx->v2) ctx->v2 = new V2State();
+    return static_cast<V2State*>(ctx->v2);
+}
+
+void v2_destroy(ugvc_ctx* ctx) {
+    if (!ctx->v2) return;
+    V2State* s = static_cast<V2State*>(ctx->v2);
+    DeviceBuf* bufs[] = {&s->desc, &s->lut, &s->thr, &s->css, &s->brackets, &s->counters};
+    for (auto* b : bufs) if (b->p) (void)hipFree(b->p);
+    for (auto& r : s->rec) if (r.p) (void)hipFree(r.p);
+    for (auto& g : s->g)
+        for (DeviceBuf* b : {&g.d_nodes, &g.d_leaf_idx, &g.d_pairs, &g.d_leaf_f32, &g.d_plane_desc}) if (b->p) (void)hipFree(b->p);
+    delete s;
+    ctx->v2 = nullptr;
+}
+
+static bool search_only_feature(int j) { return j == 0 || j == 1 || j == 5 || j == 13; }  // qual sor vaf gc
+
+int pack_model_group(ugvc_ctx* ctx, int gi, const int32_t* feature, const float* threshold, const int32_t* left,
+                     const int32_t* right, int n_nodes, const int32_t* tree_root, int n_trees,
+                     const double* leaf_value, int n_leaves, int n_features, int kind, float base, int depth) {
+    V2State* s = state(ctx);
+    V2Group& g = s->g[gi];
+    g = V2Group();
+    g.set = true;
+    g.kind = kind; g.T = n_trees; g.D = depth; g.base = base; g.n_features = n_features;
+    g.feature.assign(feature, feature + n_nodes);
+    g.threshold.assign(threshold, threshold + n_nodes);
+    g.left.assign(left, left + n_nodes);
+    g.right.assign(right, right + n_nodes);
+    g.roots.assign(tree_root, tree_root + n_trees);
+    g.leaf_value.assign(leaf_value, leaf_value + 2 * (size_t)n_leaves);
+    g.uthr.assign(kMaxFeatures, {});
+    for (int i = 0; i < n_nodes; ++i)
+        if (feature[i] >= 0) g.uthr[feature[i]].push_back(threshold[i]);
+    for (auto& v : g.uthr) {
+        std::sort(v.begin(), v.end());
+        v.erase(std::unique(v.begin(), v.end()), v.end());
+    }
+    s->dirty = true;
+    return 0;
+}
+
+static void fill_dense(V2Group& g, int t, int src, int level, int idx, std::vector<int>& slot_leaf) {
+    // idx: 1-based heap index (root 1, children 2i and 2i+1); level = floor(log2(idx))
+    const int D = g.D, NL = 1 << D;
+    if (g.feature[src] < 0) {                       // leaf: every slot below it carries its payload
+        const int p = idx - (1 << level);
+        const int lo = p << (D - level), hi = (p + 1) << (D - level);
+        for (int sl = lo; sl < hi; ++sl) slot_leaf[(size_t)t * NL + sl] = g.left[src];
+        return;
+    }
+    const int f = g.feature[src];
+    const auto& u = g.uthr[f];
+    const int rank = (int)(std::lower_bound(u.begin(), u.end(), g.threshold[src]) - u.begin());
+    g.nodes[(size_t)t * NL + idx] = (uint32_t)rank | ((uint32_t)(g.plane[f] * 128) << 16);
+    fill_dense(g, t, g.left[src], level + 1, 2 * idx, slot_leaf);
+    fill_dense(g, t, g.right[src], level + 1, 2 * idx + 1, slot_leaf);
+}
+
+static bool pack_group(V2Group& g) {
+    g.ok = false;
+    if (g.D < 1 || g.D > 10) { g.why = "tree depth outside 1..10"; return false; }
+    // code widths and first-fit-decreasing placement into three 32-bit words
+    std::vector<int> order;
+    for (int f = 0; f < kMaxFeatures; ++f) {
+        const int m = (int)g.uthr[f].size();
+        if (m > 4094) { g.why = "more than 4094 distinct thresholds on one feature"; return false; }
+        g.width[f] = m ? 32 - __builtin_clz((unsigned)m) : 0;
+        g.dword[f] = g.bit_off[f] = g.plane[f] = 0;
+        if (m) order.push_back(f);
+    }
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return g.width[a] > g.width[b]; });
+    int used[3] = {0, 0, 0};
+    for (int f : order) {
+        int d = 0;
+        while (d < 3 && used[d] + g.width[f] > 32) ++d;
+        if (d == 3) { g.why = "rank codes need more than 96 bits"; return false; }
+        g.dword[f] = d;
+        g.bit_off[f] = used[d];
+        used[d] += g.width[f];
+    }
+    g.n_planes = 0;
+    g.plane_desc.clear();
+    for (int f = 0; f < kMaxFeatures; ++f)
+        if (g.width[f]) {
+            g.plane[f] = g.n_planes++;
+            g.plane_desc.push_back((uint32_t)g.dword[f] | ((uint32_t)g.bit_off[f] << 2) | ((uint32_t)g.width[f] << 7));
+        }
+    if (g.n_planes == 0) { g.plane_desc.push_back(0); g.n_planes = 1; }   // stump forest: one dummy plane
+    const int D = g.D, T = g.T;
+    const size_t n_slot = (size_t)T << D, n_int = n_slot;
+    g.nodes.assign(n_int, 0xFFFFu);                 // padded node: rank 65535 on plane 0 -> always left
+    std::vector<int> slot_leaf(n_slot, 0);
+    for (int t = 0; t < T; ++t) fill_dense(g, t, g.roots[t], 0, 1, slot_leaf);
+    size_t lds = n_int * 4 + (size_t)8 * g.n_planes * 128;   // at least 8 waves of code planes must fit
+    if (g.kind == UGVC_MODEL_RF) {
+        std::map<std::pair<double, double>, int> uniq;
+        g.leaf_idx.resize(n_slot);
+        g.pairs.clear();
+        for (size_t i = 0; i < n_slot; ++i) {
+            const std::pair<double, double> key(g.leaf_value[2 * (size_t)slot_leaf[i]], g.leaf_value[2 * (size_t)slot_leaf[i] + 1]);
+            auto it = uniq.find(key);
+            if (it == uniq.end()) {
+                if (uniq.size() >= 65535) { g.why = "more than 65535 distinct leaf payloads"; return false; }
+                it = uniq.emplace(key, (int)uniq.size()).first;
+                g.pairs.push_back(key.first);
+                g.pairs.push_back(key.second);
+            }
+            g.leaf_idx[i] = (uint16_t)it->second;
+        }
+        g.n_pairs = (int)uniq.size();
+        lds += n_slot * 2 + (size_t)g.n_pairs * 16;
+    } else {
+        g.leaf_f32.resize(n_slot);
+        for (size_t i = 0; i < n_slot; ++i) g.leaf_f32[i] = (float)g.leaf_value[2 * (size_t)slot_leaf[i]];
+        lds += n_slot * 4;
+    }
+    if (lds > (size_t)kLdsBudget) { g.why = "forest does not fit the LDS budget"; return false; }
+    g.ok = true;
+    return true;
+}
+
+static int count_code(const V2Group& g, int f, float v) {   // rank code of value v for feature f
+    const auto& u = g.uthr[f];
+    if (g.kind == UGVC_MODEL_RF) return (int)(std::lower_bound(u.begin(), u.end(), v) - u.begin());
+    return (int)(std::upper_bound(u.begin(), u.end(), v) - u.begin());
+}
+
+int finalize_pack(ugvc_ctx* ctx) {
+    V2State* s = state(ctx);
+    if (!s->dirty) return 0;
+    s->ok = false;
+    s->why.clear();
+    std::vector<FeatDesc> desc((size_t)UGVC_N_GROUPS * kMaxFeatures, FeatDesc{0, 0, 0, 0});
+    std::vector<uint16_t> lut;
+    std::vector<float> thr;
+    bool all_ok = true;
+    for (auto& g : s->g)
+        if (g.set && !pack_group(g)) { all_ok = false; s->why = g.why; }
+    if (all_ok) {
+        // threshold table: search-only features of every group first (that prefix is staged in LDS)
+        for (int pass = 0; pass < 2; ++pass)
+            for (int gi = 0; gi < UGVC_N_GROUPS; ++gi) {
+                V2Group& g = s->g[gi];
+                if (!g.set) continue;
+                for (int f = 0; f < kMaxFeatures; ++f) {
+                    if (g.uthr[f].empty() || search_only_feature(f) != (pass == 0)) continue;
+                    FeatDesc& d = desc[(size_t)gi * kMaxFeatures + f];
+                    d.thr = (uint32_t)thr.size() | ((uint32_t)g.uthr[f].size() << 20);   // off 20 bits | len 12 bits
+                    thr.insert(thr.end(), g.uthr[f].begin(), g.uthr[f].end());
+                    d.pack = (uint32_t)g.dword[f] | ((uint32_t)g.bit_off[f] << 2) | ((uint32_t)g.width[f] << 7);
+                    if (pass == 0) {
+                        d.lut = 2u << 30;
+                    } else {
+                        const double top = std::floor((double)g.uthr[f].back());
+                        const int len = (int)std::min(8192.0, std::max(1.0, top + 2.0));
+                        d.lut = (uint32_t)lut.size() | (1u << 30);
+                        d.lut_len = (uint32_t)len;
+                        for (int v = 0; v < len; ++v) lut.push_back((uint16_t)count_code(g, f, (float)v));
+                    }
+                }
+                if (pass == 0 && gi == UGVC_N_GROUPS - 1) s->thr_lds_len = (int)thr.size();
+            }
+        if (thr.size() >= (1u << 20) || lut.size() >= (1u << 20)) { all_ok = false; s->why = "code tables too large"; }
+    }
+    if (all_ok) {
+        UGVC_HIP(hipSetDevice(ctx->device));
+        if (upload(ctx, s->desc, desc.data(), desc.size() * sizeof(FeatDesc))) return -1;
+        if (upload(ctx, s->lut, lut.data(), lut.size() * 2)) return -1;
+        if (upload(ctx, s->thr, thr.data(), thr.size() * 4)) return -1;
+        for (auto& g : s->g) {
+            if (!g.set) continue;
+            if (upload(ctx, g.d_nodes, g.nodes.data(), g.nodes.size() * 4)) return -1;
+            if (upload(ctx, g.d_plane_desc, g.plane_desc.data(), g.plane_desc.size() * 4)) return -1;
+            if (g.kind == UGVC_MODEL_RF) {
+                if (upload(ctx, g.d_leaf_idx, g.leaf_idx.data(), g.leaf_idx.size() * 2)) return -1;
+                if (upload(ctx, g.d_pairs, g.pairs.data(), g.pairs.size() * 8)) return -1;
+            } else if (upload(ctx, g.d_leaf_f32, g.leaf_f32.data(), g.leaf_f32.size() * 4)) return -1;
+        }
+        UGVC_HIP(hipStreamSynchronize(ctx->stream));
+        s->ok = true;
+    }
+    s->dirty = false;
+    return 0;
+}
+
+// ---- cycle-skip LUT ------------------------------------------------------------------------
+// For a single-base substitution the status depends only on (last left base, ref, alt, first
+// right base): the flow that consumes the left neighbour is the same for both alleles, and
+// both key streams re-synchronise on the right neighbour.  tests/test_host_logic.py checks the
+// table against the full 11-mer flow-key computation of the oracle on exhaustive contexts.
+static int flow_key(const int* seq, int n, const uint8_t flow[4], int* key) {
+    int p = 0, s = 0;
+    while (p < n) {
+        const int b = flow[s & 3];
+        int h = 0;
+        while (p + h < n && seq[p + h] == b) ++h;
+        key[s++] = h;
+        p += h;
+    }
+    return s;
+}
+
+void host_css_lut(const uint8_t flow[4], uint8_t out[256]) {
+    for (int l1 = 0; l1 < 4; ++l1) for (int r = 0; r < 4; ++r) for (int a = 0; a < 4; ++a) for (int r1 = 0; r1 < 4; ++r1) {
+        int sr[3] = {l1 + 1, r + 1, r1 + 1}, sa[3] = {l1 + 1, a + 1, r1 + 1};
+        int kr[16], ka[16];
+        const int nr = flow_key(sr, 3, flow, kr), na = flow_key(sa, 3, flow, ka);
+        int st = 0;
+        if (nr != na) st = 2;
+        else
+            for (int i = 0; i < nr; ++i)
+                if (kr[i] != ka[i] && (kr[i] == 0 || ka[i] == 0)) st = 1;
+        out[(l1 << 6) | (r << 4) | (a << 2) | r1] = (uint8_t)st;
+    }
+}
+
+int build_css_lut(ugvc_ctx* ctx) {
+    V2State* s = state(ctx);
+    uint8_t t[256];
+    host_css_lut(ctx->flow, t);
+    UGVC_HIP(hipSetDevice(ctx->device));
+    if (upload(ctx, s->css, t, 256)) return -1;
+    UGVC_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+bool v2_available(ugvc_ctx* ctx) {
+    V2State* s = state(ctx);
+    if (finalize_pack(ctx)) return false;
+    bool any = false;
+    for (auto& g : s->g) any |= g.set;
+    return s->ok && any;
+}
+
+const char* v2_reason(ugvc_ctx* ctx) { return state(ctx)->why.c_str(); }
+
+int v2_fill_args(ugvc_ctx* ctx, V2Args& v, int64_t n) {
+    V2State* s = state(ctx);
+    if (!s->css.p && build_css_lut(ctx)) return -1;
+    const int n_blocks = (int)((n + kBlock - 1) / kBlock);
+    const size_t shard_cap = (size_t)((n_blocks + kShards - 1) / kShards) * kBlock;
+    v.shard_cap = (int)shard_cap;
+    for (int gi = 0; gi < UGVC_N_GROUPS; ++gi) {
+        const V2Group& g = s->g[gi];
+        PackedGroupView& p = v.pg[gi];
+        p = PackedGroupView{};
+        if (!g.set) continue;
+        p.ok = 1; p.kind = g.kind; p.T = g.T; p.D = g.D; p.base = g.base; p.n_pairs = g.n_pairs;
+        p.n_planes = g.n_planes;
+        p.plane_desc = g.d_plane_desc.as<uint32_t>();
+        p.nodes = g.d_nodes.as<uint32_t>();
+        p.leaf_idx = g.d_leaf_idx.as<uint16_t>();
+        p.pairs = g.d_pairs.as<double2>();
+        p.leaf_f32 = g.d_leaf_f32.as<float>();
+        if (ensure(s->rec[gi], (size_t)kShards * shard_cap * 16)) return -1;
+        v.records[gi] = s->rec[gi].as<uint4>();
+    }
+    v.desc = s->desc.as<FeatDesc>();
+    v.lut = s->lut.as<uint16_t>();
+    v.thr = s->thr.as<float>();
+    v.thr_lds_len = std::min(s->thr_lds_len, 4096);   // kThrLds floats are staged in LDS; the rest is read from L2
+    v.css_lut = s->css.as<uint8_t>();
+    v.n_blocks = (int)((n + kBlock - 1) / kBlock);
+    if (ensure(s->brackets, (size_t)(v.n_blocks + 1) * kJoinArrays * 4)) return -1;
+    if (ensure(s->counters, (size_t)UGVC_N_GROUPS * kShards * kCounterStride * 4)) return -1;
+    v.brackets = s->brackets.as<int32_t>();
+    v.counters = s->counters.as<uint32_t>();
+    return 0;
+}
+
+}  // namespace ugvc
+
+extern "C" {
+// Host-only helper (no GPU needed): the single-base cycle-skip table for a flow order, so the
+// CPU tests can check it against the oracle's full flow-key computation.
+int ugvc_host_css_lut(const char* flow4, uint8_t out[256]) {
+    uint8_t f[4];
+    for (int k = 0; k < 4; ++k) {
+        switch (flow4 ? flow4[k] : 0) {
+            case 'A': f[k] = 1; break;
+            case 'C': f[k] = 2; break;
+            case 'G': f[k] = 3; break;
+            case 'T': f[k] = 4; break;
+            default: return ugvc::fail("flow order must be a permutation of ACGT");
+        }
+    }
+    ugvc::host_css_lut(f, out);
+    return 0;
+}
+}

@@ -76,6 +76,7 @@ struct FilterArgs {
     uint8_t* flags;
     float* X;                  // optional N x F
     uint8_t* group;            // optional
+    int n_contigs;
     int ablate;                // debug/profiling only: bit0 no forest walk, bit1 no side-table joins,
                                // bit2 no cycle-skip, bit3 no reference-derived features
 };
@@ -123,6 +124,7 @@ struct ugvc_ctx {
     void* comm = nullptr;
     int rank = 0, world = 1;
     int kernel_variant = 0;
+    void* v2 = nullptr;             // ugvc::V2State (model_pack.hip)
 };
 
 namespace ugvc {

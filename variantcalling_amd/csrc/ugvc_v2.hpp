@@ -1,0 +1,74 @@
+// v2 fast path: featurize/quantise kernel (K1) + LDS-resident forest kernel (K2).
+//
+// Tree walks are the dominant cost of the hot path (40 trees x depth 8 = 320 dependent node
+// visits per variant).  Global/L2 gathers of 16-byte nodes are bound by the per-CU L1 rate
+// (64 B/clk); LDS serves 128-256 B/clk, so v2 keeps one variant-type group's whole forest in
+// the LDS of a workgroup.  To make a forest fit (<= ~140 KB):
+//   * thresholds are replaced by their RANK among the sorted unique thresholds of that
+//     (group, feature): x <= thr_j  <=>  code(x) <= j  with code(x) = #{thr_k < x}  (exact);
+//     for XGBoost-style `<`: code(x) = #{thr_k <= x}.  A node is one dword:
+//         rank[0:16) | byte offset of the feature's code plane[16:32)
+//   * every tree is padded to a complete binary tree (level-order index, no child pointers,
+//     padded nodes always go left), so a walk is a fixed `depth` steps with no leaf test;
+//   * RF leaf payloads (p_class0, p_class1 as f64 - both needed to reproduce scikit-learn's
+//     argmax bit-for-bit) are de-duplicated; a leaf slot holds a u16 index into the unique table.
+// A variant's features are quantised once by K1 into <= 96 bits of packed rank codes; K1
+// appends a 16-byte record {code0, code1, code2, variant index} to its group's list, K2
+// workgroups are split over the groups in proportion to work and walk their list.
+#pragma once
+#include "ugvc_device.hpp"
+
+namespace ugvc {
+
+constexpr int kJoinArrays = 2 * (UGVC_MAX_TRACKS + 1) + 1;   // runs s/e, tracks s/e, blacklist
+constexpr int kStageCap = 320;                                // staged entries per array per block
+constexpr int kK2Threads = 1024;
+constexpr int kLdsBudget = 150 * 1024;
+constexpr int kShards = 256;          // record lists are sharded by (block & 255): spreads the atomics
+constexpr int kCounterStride = 16;    // shard counters sit 64 bytes apart
+
+struct __attribute__((aligned(16))) FeatDesc {
+    uint32_t lut;    // lut_off[0:20) | kind[30:32)   kind: 0 unused, 1 LUT(+search), 2 search only
+    uint32_t lut_len;
+    uint32_t thr;    // thr_off[0:20) | thr_len[20:32)
+    uint32_t pack;   // dword[0:2) | bit_off[2:7) | width[7:11)
+};
+
+struct PackedGroupView {
+    int ok, kind, T, D;
+    float base;
+    int n_pairs, n_planes;
+    const uint32_t* plane_desc;   // per code plane: dword[0:2) | bit_off[2:7) | width[7:11)
+    const uint32_t* nodes;        // T * 2^D, 1-based heap order: rank[0:16) | plane byte offset[16:32)
+    const uint16_t* leaf_idx;     // RF: T * 2^D
+    const double2* pairs;         // RF: n_pairs
+    const float* leaf_f32;        // GBT: T * 2^D
+};
+
+struct V2Args {
+    FilterArgs f;
+    PackedGroupView pg[UGVC_N_GROUPS];
+    const FeatDesc* desc;         // [3][kMaxFeatures]
+    const uint16_t* lut;
+    const float* thr;             // search-only features first: [0, thr_lds_len) is copied to LDS
+    int thr_lds_len;
+    const uint8_t* css_lut;       // 256 entries, index l1<<6 | ref<<4 | alt<<2 | r1 (bases - 1)
+    int32_t* brackets;            // [(n_blocks + 1)][kJoinArrays]
+    uint4* records[UGVC_N_GROUPS];
+    uint32_t* counters;           // [UGVC_N_GROUPS][kShards] x kCounterStride, zeroed every launch
+    int n_blocks;
+    int shard_cap;                // records per shard region
+};
+
+int pack_model_group(ugvc_ctx* ctx, int g, const int32_t* feature, const float* threshold,
+                     const int32_t* left, const int32_t* right, int n_nodes, const int32_t* tree_root,
+                     int n_trees, const double* leaf_value, int n_leaves, int n_features, int kind,
+                     float base, int depth);
+int finalize_pack(ugvc_ctx* ctx);
+int build_css_lut(ugvc_ctx* ctx);
+bool v2_available(ugvc_ctx* ctx);
+int launch_filter_v2(ugvc_ctx* ctx, const FilterArgs& a);
+void v2_destroy(ugvc_ctx* ctx);
+const char* v2_reason(ugvc_ctx* ctx);
+
+}  // namespace ugvc

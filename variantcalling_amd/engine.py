@@ -68,6 +68,7 @@ ABI = {
     "ugvc_device_sync": (C.c_int, [_ctx]),
     "ugvc_feature_matrix": (C.c_int, [_ctx, _f32p, _u8p]),
     "ugvc_n_features": (C.c_int, [_ctx]),
+    "ugvc_host_css_lut": (C.c_int, [C.c_char_p, _u8p]),
     "ugvc_set_kernel_variant": (C.c_int, [_ctx, C.c_int]),
     "ugvc_pileup_tally": (C.c_int, [_ctx, _i64p, _u16p, C.c_int64, C.POINTER(CPileupOut)]),
     "ugvc_pileup_upload": (C.c_int, [_ctx, _i64p, _u16p, C.c_int64]),
