@@ -1,0 +1,224 @@
+"""CPU tests of the host-side logic and of the C-ABI library as an artefact (no compute calls:
+there is no GPU here).  The library must load, export every symbol include/ugvc_mi355x.h
+declares, and FAIL LOUDLY - not fall back - when asked for a device that is not there."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from oracle import oracle as O
+from variantcalling_amd import engine as eng_mod
+from variantcalling_amd import model_io, schema as S, shard, synth
+
+HEADER = os.path.join(ROOT, "include", "ugvc_mi355x.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(eng_mod.LIB_PATH):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "variantcalling_amd", "csrc"), "-j4"], check=True)
+    return eng_mod.load_library()
+
+
+def _declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ugvc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    names = _declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/ugvc_mi355x.h but not exported"
+    # the ctypes binding table covers exactly the header
+    assert sorted(eng_mod.ABI) == names
+    assert lib.ugvc_abi_version() == 1
+    out = subprocess.run(["nm", "-D", "--defined-only", eng_mod.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (ugvc_\w+)", out))
+    assert set(names) <= exported
+
+
+def test_library_is_gfx950_only(lib):
+    """One code object, gfx950: no multi-arch fat binary, no host fallback kernels."""
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--list", "--type=o",
+                          f"--input={eng_mod.LIB_PATH}"], capture_output=True, text=True)
+    if out.returncode == 0 and out.stdout.strip():
+        targets = [t for t in out.stdout.split() if "amdgcn" in t]
+        assert targets and all("gfx950" in t for t in targets), targets
+    else:                                  # bundle section not listable on a .so: look for the ISA name
+        blob = open(eng_mod.LIB_PATH, "rb").read()
+        assert b"gfx950" in blob and b"gfx90a" not in blob and b"gfx942" not in blob
+
+
+def test_no_gpu_fails_loudly(lib):
+    """No silent CPU path: creating a context without a device is an error with a message."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    h = C.c_void_p()
+    rc = lib.ugvc_ctx_create(0, C.byref(h))
+    assert rc != 0 and lib.ugvc_last_error()
+    with pytest.raises(RuntimeError):
+        eng_mod.Engine(0)
+    assert lib.ugvc_filter_resident(None) != 0 and b"NULL" in lib.ugvc_last_error()
+
+
+def test_product_path_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under variantcalling_amd/ may import it."""
+    pkg = os.path.join(ROOT, "variantcalling_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(d, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(d, f)
+                assert "from oracle" not in src and "import oracle" not in src, os.path.join(d, f)
+    code = ("import sys; sys.path.insert(0, %r); import variantcalling_amd.engine, variantcalling_amd.dist, "
+            "variantcalling_amd.model_io, variantcalling_amd.synth; "
+            "assert not [m for m in sys.modules if m == 'oracle' or m.startswith('oracle.')]" % ROOT)
+    subprocess.run([sys.executable, "-c", code], check=True)
+
+
+# ------------------------------------------------------------------ cycle-skip LUT (host helper of the kernels)
+@pytest.mark.parametrize("flow", ["TGCA", "ACGT", "GTAC", "CATG"])
+def test_css_lut_matches_full_flow_key_computation(lib, flow):
+    """The kernels use a 256-entry table for single-base substitutions; it must equal the oracle's
+    full 11-mer flow-key comparison for EVERY context (exhaustive over l1, ref, alt, r1 and random
+    over the outer motif bases, which must not matter)."""
+    lut = np.zeros(256, np.uint8)
+    assert lib.ugvc_host_css_lut(flow.encode(), lut.ctypes.data_as(C.POINTER(C.c_uint8))) == 0
+    fo = S.encode_bases(flow)
+    rng = np.random.default_rng(1)
+    for l1 in range(4):
+        for r in range(4):
+            for a in range(4):
+                if a == r:
+                    continue
+                for r1 in range(4):
+                    want = None
+                    for _ in range(6):
+                        left = np.concatenate([rng.integers(1, 5, 4), [l1 + 1]]).astype(np.uint8)
+                        right = np.concatenate([[r1 + 1], rng.integers(1, 5, 4)]).astype(np.uint8)
+                        rs = np.concatenate([left, [r + 1], right]).astype(np.uint8)
+                        as_ = np.concatenate([left, [a + 1], right]).astype(np.uint8)
+                        st = O.cycle_skip_status(rs, as_, fo)
+                        assert want is None or st == want, "outer motif bases changed the status"
+                        want = st
+                    assert lut[(l1 << 6) | (r << 4) | (a << 2) | r1] == want
+    for bad in (b"AAGT", b"AXGT", b"ACG", b"ACGTA"):
+        assert lib.ugvc_host_css_lut(bad, lut.ctypes.data_as(C.POINTER(C.c_uint8))) != 0
+        assert b"permutation" in lib.ugvc_last_error()
+
+
+# ------------------------------------------------------------------ sharding (multi-GPU partition)
+def test_shard_bounds_and_reassembly():
+    for n, w in ((0, 1), (1, 8), (7, 8), (8, 8), (5_000_000, 8), (1_000_003, 4), (13, 2)):
+        b = shard.shard_bounds(n, w)
+        sizes = np.diff(b)
+        assert b[0] == 0 and b[-1] == n and sizes.max() - sizes.min() <= 1 and (sizes >= 0).all()
+        assert shard.shard_cap(n, w) == sizes.max()
+    with pytest.raises(ValueError):
+        shard.shard_bounds(10, 0)
+    cs = synth.make_callset(5000, genome_len=2_000_000, n_contigs=3, seed=3)
+    vt = cs.variants
+    parts = [shard.shard_of(vt, r, 3) for r in range(3)]
+    assert sum(p.n for p in parts) == vt.n
+    for p in parts:
+        p.validate()
+    assert np.array_equal(np.concatenate([p.pos for p in parts]), vt.pos)
+    # allele pools are re-based: every shard decodes the same alleles as the full table
+    lo = 0
+    for p in parts:
+        for k in (0, p.n // 2, p.n - 1):
+            i = lo + k
+            assert np.array_equal(p.alleles[p.alt_off[k]: p.alt_off[k] + p.alt_len[k]],
+                                  vt.alleles[vt.alt_off[i]: vt.alt_off[i] + vt.alt_len[i]])
+        lo += p.n
+    rng = np.random.default_rng(0)
+    full = S.FilterResult(rng.random(vt.n).astype(np.float32), rng.integers(0, 2, vt.n).astype(np.uint8),
+                          rng.integers(0, 255, vt.n).astype(np.uint8))
+    b = shard.shard_bounds(vt.n, 3)
+    cap = shard.shard_cap(vt.n, 3)
+    padded = [shard.pad_result(S.FilterResult(full.tree_score[b[r]:b[r + 1]], full.filter[b[r]:b[r + 1]],
+                                              full.flags[b[r]:b[r + 1]]), cap) for r in range(3)]
+    back = shard.reassemble(padded, [int(b[r + 1] - b[r]) for r in range(3)])
+    assert np.array_equal(back.tree_score, full.tree_score) and np.array_equal(back.flags, full.flags)
+
+
+# ------------------------------------------------------------------ model import
+def test_f32_threshold_rounding_decides_like_f64():
+    rng = np.random.default_rng(2)
+    thr = np.concatenate([rng.normal(size=2000), rng.normal(size=2000).astype(np.float32).astype(np.float64),
+                          [0.0, -0.0, 1e-40, 3.4e38, 0.1, 0.5]])
+    fl, ce = model_io.f32_floor(thr), model_io.f32_ceil(thr)
+    assert (fl.astype(np.float64) <= thr).all() and (ce.astype(np.float64) >= thr).all()
+    x = np.concatenate([fl, ce, np.nextafter(fl, np.float32(np.inf)), np.nextafter(ce, np.float32(-np.inf))])
+    for t, f, c in zip(thr[::37], fl[::37], ce[::37]):
+        assert np.array_equal(x.astype(np.float64) <= t, x <= f)
+        assert np.array_equal(x.astype(np.float64) < t, x < c)
+
+
+def test_model_file_round_trip(tmp_path, frozen_models):
+    import pickle
+
+    from sklearn.ensemble import RandomForestClassifier
+    p = tmp_path / "m.npz"
+    model_io.save_models(str(p), frozen_models)
+    back = model_io.load_models(str(p))
+    for name in frozen_models:
+        for a, b in zip(frozen_models[name], back[name]):
+            for k in ("feature", "threshold", "left", "right", "tree_root", "leaf_value"):
+                assert np.array_equal(getattr(a, k), getattr(b, k))
+            assert (a.kind, a.n_features, a.max_depth, a.base_score) == (b.kind, b.n_features, b.max_depth, b.base_score)
+    rng = np.random.default_rng(0)
+    X = rng.normal(size=(500, 20)).astype(np.float32)
+    y = (X[:, 0] > 0).astype(int)
+    clfs = {g: RandomForestClassifier(n_estimators=3, max_depth=3, random_state=i).fit(X, y)
+            for i, g in enumerate(S.GROUP_NAMES)}
+    pk = tmp_path / "m.pkl"
+    pk.write_bytes(pickle.dumps({"rf_model_ignore_gt_incl_hpol_runs": clfs}))
+    forests = model_io.load_model_file(str(pk), "rf_model_ignore_gt_incl_hpol_runs")
+    assert len(forests) == 3 and all(f.kind == S.MODEL_RF and f.n_trees == 3 for f in forests)
+    with pytest.raises(KeyError):
+        model_io.load_model_file(str(pk), "nope")
+
+
+def test_synthetic_callset_is_deterministic_and_wgs_shaped():
+    a = synth.make_callset(20_000, genome_len=12_000_000, n_contigs=4, seed=5)
+    b = synth.make_callset(20_000, genome_len=12_000_000, n_contigs=4, seed=5)
+    for c in S.VariantTable.COLS:
+        assert np.array_equal(getattr(a.variants, c), getattr(b.variants, c)), c
+    assert np.array_equal(a.blacklist, b.blacklist) and np.array_equal(a.ref.codes, b.ref.codes)
+    vt = a.variants
+    vt.validate()
+    indel = vt.ref_len != vt.alt_len
+    assert 0.15 < indel.mean() < 0.21
+    ft = O.featurize(vt, a.ref, a.runs, a.tracks)
+    assert 0.45 < (ft["group"][indel] == S.GROUP_HINDEL).mean() < 0.75
+    for t in a.tracks + [a.runs]:
+        assert (t.starts < t.ends).all() and t.contig_ptr[-1] == t.starts.size
+        for c in range(a.ref.n_contigs):
+            s, e = t.starts[t.contig_ptr[c]: t.contig_ptr[c + 1]], t.ends[t.contig_ptr[c]: t.contig_ptr[c + 1]]
+            assert (np.diff(s) > 0).all() and (e[:-1] <= s[1:]).all()
+    assert np.isin(vt.keys(), a.blacklist).sum() > 0
+    snv = synth.make_callset(5000, genome_len=3_000_000, n_contigs=2, seed=5, snv_only=True).variants
+    assert (snv.ref_len == 1).all() and (snv.alt_len == 1).all()
+
+
+def test_variant_table_validation():
+    cs = synth.make_callset(300, genome_len=2_000_000, n_contigs=2, seed=9)
+    import copy
+    vt = copy.copy(cs.variants)
+    vt.pos = vt.pos[::-1].copy()
+    with pytest.raises(ValueError, match="sorted"):
+        vt.validate()
+    vt = copy.copy(cs.variants)
+    vt.qual = vt.qual.astype(np.float64)
+    with pytest.raises(ValueError, match="qual"):
+        vt.validate()
+    assert cs.variants.slice(10, 10).n == 0

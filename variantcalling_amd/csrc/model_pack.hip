@@ -317,15 +317,19 @@ extern "C" {
 // CPU tests can check it against the oracle's full flow-key computation.
 int ugvc_host_css_lut(const char* flow4, uint8_t out[256]) {
     uint8_t f[4];
+    int seen = 0;
+    if (!out) return ugvc::fail("out is NULL");
     for (int k = 0; k < 4; ++k) {
         switch (flow4 ? flow4[k] : 0) {
-            case 'A': f[k] = 1; break;
-            case 'C': f[k] = 2; break;
-            case 'G': f[k] = 3; break;
-            case 'T': f[k] = 4; break;
+            case 'A': case 'a': f[k] = 1; break;
+            case 'C': case 'c': f[k] = 2; break;
+            case 'G': case 'g': f[k] = 3; break;
+            case 'T': case 't': f[k] = 4; break;
             default: return ugvc::fail("flow order must be a permutation of ACGT");
         }
+        seen |= 1 << f[k];
     }
+    if (seen != 0x1e || flow4[4] != 0) return ugvc::fail("flow order must be a permutation of ACGT");
     ugvc::host_css_lut(f, out);
     return 0;
 }
