@@ -100,6 +100,8 @@ int ugvc_sync(ugvc_ctx* ctx);
  *   runs shorter than min_len are dropped on upload; mark_hpol=0 keeps the two features but
  *   never sets UGVC_FLAG_HPOL_RUN.
  * ugvc_track_upload: one `--annotate_intervals` BED (docs/...md:45-46), track_id < UGVC_MAX_TRACKS.
+ *   Interval tables (runs and tracks) must have non-decreasing starts AND ends inside every contig
+ *   (sorted BED, nested intervals merged) - anything else is rejected with an error.
  * ugvc_blacklist_upload: `--blacklist` loci as sorted unique u64 keys contig<<32|pos (docs/...md:34-35).
  * ugvc_model_upload: one model of the `--model_file` dict entry `--model_name`, flattened
  *   (docs/...md:26-29; variantcalling_amd/model_io.py); one call per group.

@@ -40,7 +40,7 @@ def test_library_is_loaded_in_tree(engine):
         assert "libugvc_mi355x.so" in fh.read()
 
 
-PATHS = pytest.mark.parametrize("path", [0, 256], ids=["v2-lds-forest", "v1-universal"])
+PATHS = pytest.mark.parametrize("path", [0, 512, 256], ids=["v3-lockstep", "v2-lds-forest", "v1-universal"])
 
 
 @pytest.fixture(autouse=True)
@@ -115,6 +115,50 @@ def test_gbt_model(engine, small_callset, frozen_models, path):
     assert np.array_equal(res.filter, exp.filter)
     assert np.array_equal(res.flags, exp.flags)
     assert np.max(np.abs(res.tree_score - exp.tree_score)) <= 1e-6
+
+
+def test_v3_fallbacks_and_dense_tiles(engine, frozen_models):
+    """v3 preconditions: (i) a tile whose side-table slices overflow the LDS pool takes the HBM
+    search path; (ii) overlapping intervals with sorted ends stay on v3; (iii) a track whose ends
+    are not sorted is rejected, overlapping runs silently select v2 - results equal the oracle."""
+    from variantcalling_amd import schema as S, synth
+    O = _oracle()
+    cs = synth.make_callset(30_000, genome_len=3_000_000, n_contigs=2, seed=31)
+    ref, vt = cs.ref, cs.variants
+    rng = np.random.default_rng(8)
+
+    def track(starts, ends, contig_of):
+        order = np.lexsort((starts, contig_of))
+        starts, ends, contig_of = starts[order], ends[order], contig_of[order]
+        ptr = np.searchsorted(contig_of, np.arange(ref.n_contigs + 1)).astype(np.int32)
+        return S.IntervalTrack(starts.astype(np.int32), ends.astype(np.int32), ptr, "t")
+
+    L0 = ref.contig_len(0)
+    # (i) 40k tiny intervals packed into 200 kb of contig 0: > 2048 staged entries per tile there
+    st = np.sort(rng.choice(np.arange(100_000, 300_000), size=40_000, replace=False))
+    dense = track(st, st + 1, np.zeros(st.size, np.int64))
+    # (ii) overlapping but with sorted ends
+    st2 = np.sort(rng.integers(0, L0 - 2000, size=4000))
+    en2 = np.maximum.accumulate(st2 + rng.integers(1, 1500, size=4000))
+    overl = track(st2, en2, np.zeros(4000, np.int64))
+    bl = np.unique(np.concatenate([vt.keys()[::3], cs.blacklist]))
+    for tracks in ([dense, cs.tracks[0], cs.tracks[2]], [overl, dense, cs.tracks[1]]):
+        _configure(engine, ref, cs.runs, tracks, bl, frozen_models[RF])
+        got = engine.filter_variants(vt)
+        exp = O.filter_variants(vt, ref, cs.runs, tracks, bl, frozen_models[RF])
+        _assert_same(got, exp, "dense/overlapping tracks on v3")
+        assert (got.flags >> 3).any()
+    # (iii) nested intervals (ends not sorted) are rejected at upload; overlapping runs select v2
+    en3 = st2 + rng.integers(1, 3000, size=4000)
+    nested = track(st2, en3, np.zeros(4000, np.int64))
+    assert (np.diff(nested.ends) < 0).any()
+    with pytest.raises(RuntimeError, match="not sorted"):
+        engine.set_tracks([nested, cs.tracks[1], cs.tracks[2]])
+    ov_runs = track(st2, st2 + 400, np.zeros(4000, np.int64))
+    _configure(engine, ref, ov_runs, cs.tracks, None, frozen_models[RF], hpol_len=10, hpol_dist=25)
+    _assert_same(engine.filter_variants(vt),
+                 O.filter_variants(vt, ref, ov_runs, cs.tracks, None, frozen_models[RF], hpol_len=10, hpol_dist=25),
+                 "overlapping runs")
 
 
 def test_empty_no_tables_and_ragged(engine, small_callset, frozen_models):

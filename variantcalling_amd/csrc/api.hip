@@ -101,10 +101,15 @@ int build_args(ugvc_ctx* ctx, FilterArgs& a, bool want_x) {
 }
 
 // The scoring pass: v2 (K0 brackets + K1 featurize/quantise + K2 LDS forest) whenever every
-// uploaded model packs into the LDS layout, else the universal v1 fused kernel.
+// uploaded model packs into the LDS layout (v3 when the side tables are sorted/disjoint and the
+// float thresholds fit its LDS budget, else v2), else the universal v1 fused kernel.
 // kernel_variant bit 8 (256) forces v1 (A/B measurements, parity cross-checks).
+// kernel_variant bit 9 (512) forces v2 over v3.
 int launch_score(ugvc_ctx* ctx, const FilterArgs& a) {
-    if (!(ctx->kernel_variant & 256) && v2_available(ctx)) return launch_filter_v2(ctx, a);
+    if (!(ctx->kernel_variant & 256) && v2_available(ctx)) {
+        if (!(ctx->kernel_variant & 512) && v3_available(ctx)) return launch_filter_v3(ctx, a);
+        return launch_filter_v2(ctx, a);
+    }
     return launch_filter(ctx, a, true, false);
 }
 
@@ -211,6 +216,15 @@ static int check_track(ugvc_ctx* ctx, const int32_t* starts, const int32_t* ends
     if (n > 0 && (!starts || !ends)) return fail("NULL interval arrays");
     if (!ptr) return fail("NULL contig_ptr");
     if (ptr[0] != 0 || ptr[ctx->n_contigs] != n) return fail("contig_ptr must span [0, n]");
+    // the membership test is a pair of binary searches (over starts, over ends): both columns must be
+    // non-decreasing inside every contig (sort the BED and merge nested intervals on the host)
+    for (int c = 0; c < ctx->n_contigs; ++c) {
+        if (ptr[c + 1] < ptr[c]) return fail("contig_ptr must be non-decreasing");
+        for (int64_t i = ptr[c]; i + 1 < ptr[c + 1]; ++i)
+            if (starts[i] > starts[i + 1] || ends[i] > ends[i + 1])
+                return fail("interval table not sorted (starts and ends must be non-decreasing per contig; "
+                            "merge nested intervals) at row " + std::to_string(i + 1));
+    }
     return 0;
 }
 
@@ -234,6 +248,11 @@ int ugvc_runs_upload(ugvc_ctx* ctx, const int32_t* starts, const int32_t* ends, 
     if (upload(ctx, ctx->runs_e, e.data(), e.size() * 4)) return -1;
     if (upload(ctx, ctx->runs_p, p.data(), p.size() * 4)) return -1;
     UGVC_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->runs_n = (int64_t)s.size();
+    ctx->runs_fast = 1;           // the v3 kernel derives #ends < pos from #starts < pos: needs disjoint sorted runs
+    for (int c = 0; c < ctx->n_contigs && ctx->runs_fast; ++c)
+        for (int64_t i = p[c]; i < p[c + 1]; ++i)
+            if (s[i] >= e[i] || (i + 1 < p[c + 1] && e[i] > s[i + 1])) { ctx->runs_fast = 0; break; }
     ctx->has_runs = 1;
     ctx->hpol_dist = max_dist;
     ctx->mark_hpol = mark_hpol;
@@ -249,6 +268,8 @@ int ugvc_track_upload(ugvc_ctx* ctx, int track_id, const int32_t* starts, const 
     if (upload(ctx, ctx->trk_e[track_id], ends, (size_t)n * 4)) return -1;
     if (upload(ctx, ctx->trk_p[track_id], contig_ptr, (size_t)(ctx->n_contigs + 1) * 4)) return -1;
     UGVC_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->trk_n[track_id] = n;
+    ctx->trk_fast[track_id] = 1;
     ctx->track_set[track_id] = 1;
     if (track_id + 1 > ctx->n_tracks) ctx->n_tracks = track_id + 1;
     return 0;

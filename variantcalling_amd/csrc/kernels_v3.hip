@@ -1,0 +1,899 @@
+// v3 scoring pass (gfx950): K0 brackets of the searched side arrays, K1 persistent featurize +
+// lookup + quantise, K2 LDS-resident forest walk with paired child fetches.
+//
+// What changed against v2 (kernels_v2.hip) and why - measured on MI355X, 5 M variants:
+// v2's K1 ran at 3 waves/SIMD (52 KB LDS) and was bound by chains of dependent LDS/global
+// round trips (13 serial staging loops, 13 serial binary searches of ~9 dependent LDS reads,
+// 20 serial quantisation searches, 64-bit bounds-checked window accessors); K2 paid two
+// dependent LDS gathers per node visit with 2-4 way bank conflicts.
+//   K1: * persistent workgroups: thresholds / descriptors / contig table / cycle-skip LUT are
+//         loaded into LDS once per workgroup, not once per 256 variants;
+//       * all searches are power-of-two descents run in LOCK-STEP over the tables (7 joins,
+//         then 4 float features), so their LDS latencies overlap instead of adding up;
+//       * `inside interval` needs only the rank among STARTS plus two direct reads of ENDS
+//         (tables are validated sorted at upload), halving the searches;
+//       * the reference window is 48 B/lane in a conflict-free row-per-lane LDS layout read
+//         with byte loads at immediate offsets; contig-edge lanes patch their window once, so
+//         the common path has no bounds checks and no 64-bit arithmetic;
+//       * allele bytes, contig CSR pointers and LUT codes are fetched as batches of
+//         independent loads; one returning atomic per wave and group, issued before the joins
+//         and consumed after the quantisation.
+//   K2: * VALU-issue bound (rocprofv3 SQ counters: 73 % VALU busy, 62 % LDS busy): a node visit is
+//         cut to 4 VALU (address, code address via SDWA, compare via SDWA, v_addc index update);
+//         8 independent trees per lane cover the two dependent LDS latencies of a level;
+//       * code planes use a lane -> halfword permutation that is bank-conflict free.
+// Semantics are those of the oracle (oracle/oracle.py); parity tests run v3, v2 and v1.
+#include "ugvc_v2.hpp"
+
+namespace ugvc {
+
+int v2_fill_args(ugvc_ctx* ctx, V2Args& v, int64_t n);
+
+constexpr int kWinDw = 12;            // 48-byte reference window per variant
+constexpr int kWinStride = 13;        // dwords per lane row (odd: conflict-free column access)
+constexpr int kWinBytes = kWinDw * 4;
+
+__device__ __forceinline__ int rfl(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+// Raw LDS byte addresses (what ds_read takes).  A __shared__ object's generic pointer cast to the
+// local address space IS its LDS offset; the descents below carry such offsets in VGPRs so a
+// step is one v_add + one ds_read, with no re-derivation from an index.
+#define UGVC_LDS __attribute__((address_space(3)))
+template <class T> __device__ __forceinline__ uint32_t lds_addr(T* p) {
+    return (uint32_t)(uintptr_t)(UGVC_LDS T*)p;
+}
+__device__ __forceinline__ int lds_i32(uint32_t a) { return *(UGVC_LDS const int32_t*)(uintptr_t)a; }
+__device__ __forceinline__ uint32_t lds_u32(uint32_t a) { return *(UGVC_LDS const uint32_t*)(uintptr_t)a; }
+__device__ __forceinline__ uint64_t lds_u64(uint32_t a) { return *(UGVC_LDS const uint64_t*)(uintptr_t)a; }
+__device__ __forceinline__ float lds_f32(uint32_t a) { return *(UGVC_LDS const float*)(uintptr_t)a; }
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint2 lds_u32x2(uint32_t a) {
+    const u32x2_t x = *(UGVC_LDS const u32x2_t*)(uintptr_t)a;
+    return make_uint2(x.x, x.y);
+}
+__device__ __forceinline__ uint32_t lds_u16(uint32_t a) { return *(UGVC_LDS const uint16_t*)(uintptr_t)a; }
+
+__device__ __forceinline__ int lb_i32_g(const int32_t* __restrict__ a, int lo, int hi, int key) {
+    int base = lo, len = hi - lo;
+    while (len > 0) {
+        const int half = len >> 1;
+        const bool lt = a[base + half] < key;
+        base = lt ? base + half + 1 : base;
+        len = lt ? len - half - 1 : half;
+    }
+    return base;
+}
+
+__device__ __forceinline__ int lb_u64_g(const uint64_t* __restrict__ a, int lo, int hi, uint64_t key) {
+    int base = lo, len = hi - lo;
+    while (len > 0) {
+        const int half = len >> 1;
+        const bool lt = a[base + half] < key;
+        base = lt ? base + half + 1 : base;
+        len = lt ? len - half - 1 : half;
+    }
+    return base;
+}
+
+__device__ __forceinline__ const TrackView& table_view(const FilterArgs& f, int t) {   // t: 0 runs, 1.. tracks
+    return t == 0 ? f.runs : f.tracks[t - 1];
+}
+__device__ __forceinline__ bool table_present(const FilterArgs& f, int t) {
+    return t == 0 ? f.has_runs != 0 : (t - 1) < f.n_tracks;
+}
+
+// ---- K0: brackets3[b][a] = first index of searched array a (a < 6: starts of table a; a == 6:
+// blacklist keys) that is >= the first variant of tile b; row n_tiles holds the array lengths.
+__global__ void bracket3_kernel(const V2Args v) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nb = v.n_blocks;
+    const int b = (int)(gid >> 3), a = (int)(gid & 7);
+    if (b > nb || a >= kJoin3) return;
+    const FilterArgs& f = v.f;
+    int out = 0;
+    if (a == kJoin3 - 1) {
+        if (f.n_bl > 0) {
+            if (b == nb) out = (int)f.n_bl;
+            else {
+                const int64_t i = (int64_t)b * kBlock;
+                out = lb_u64_g(f.bl, 0, (int)f.n_bl, ((uint64_t)f.contig[i] << 32) | (uint32_t)f.pos[i]);
+            }
+        }
+    } else if (table_present(f, a)) {
+        const TrackView& tv = table_view(f, a);
+        if (b == nb) out = tv.ptr[f.n_contigs];
+        else {
+            const int64_t i = (int64_t)b * kBlock;
+            const int c = f.contig[i];
+            out = lb_i32_g(tv.starts, tv.ptr[c], tv.ptr[c + 1], f.pos[i]);
+        }
+    }
+    v.brackets3[gid] = out;
+}
+
+// ---- K1 ------------------------------------------------------------------------------------
+struct Plan3 {                 // staging plan of one tile (LDS)
+    int lo[8], hi[8];          // search brackets per searched array (global indices)
+    int base[8];               // global index of the first staged element
+    int offS[8], offE[8];      // pool offsets (dwords): starts / ends slices; blacklist in offS[6]
+    int cnt[8];                // staged elements
+    int bits[8];               // descent depth per array: 2^bits > its search range
+    int maxbits;
+    int staged;                // every slice fits the pool
+};
+
+template <class SeqR, class SeqA>
+__device__ __forceinline__ int cycle_skip_walk(int L, const uint8_t flow[4], SeqR seq_r, SeqA seq_a) {
+    int pr = 0, pa = 0, lr = 0, la = 0;
+    bool poss = false;
+    for (int s = 0; pr < L || pa < L; ++s) {
+        const int b = flow[s & 3];
+        const bool ar = pr < L, aa = pa < L;
+        int hr = 0, ha = 0;
+        if (ar) { while (pr + hr < L && seq_r(pr + hr) == b) ++hr; pr += hr; ++lr; }
+        if (aa) { while (pa + ha < L && seq_a(pa + ha) == b) ++ha; pa += ha; ++la; }
+        if (ar && aa && hr != ha && (hr == 0 || ha == 0)) poss = true;
+    }
+    if (lr != la) return 2;
+    return poss ? 1 : 0;
+}
+
+__global__ __launch_bounds__(kBlock, 4) void featurize3_kernel(const V2Args v) {
+    __shared__ uint32_t win[kBlock * kWinStride];                  // 13 KB
+    __shared__ int32_t pool[kPool3];                               // 8 KB
+    __shared__ float thr_lds[kThr3];                               // 14 KB
+    __shared__ uint2 desc_lds[UGVC_N_GROUPS * kMaxFeatures];
+    __shared__ int64_t coff_lds[257];
+    __shared__ uint8_t css_lds[256];
+    __shared__ Plan3 plan;
+
+    const FilterArgs& a = v.f;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int F = UGVC_N_BASE_FEATURES + a.n_tracks;
+    const uint8_t* __restrict__ apool = a.alleles;
+    const int okbits = (v.pg[0].ok ? 1 : 0) | (v.pg[1].ok ? 2 : 0) | (v.pg[2].ok ? 4 : 0);
+    const int gbtbits = (v.pg[0].kind == UGVC_MODEL_GBT ? 1 : 0) | (v.pg[1].kind == UGVC_MODEL_GBT ? 2 : 0) |
+                        (v.pg[2].kind == UGVC_MODEL_GBT ? 4 : 0);
+
+    // ---- once per workgroup: model-side tables into LDS
+    for (int k = tid; k < UGVC_N_GROUPS * kMaxFeatures; k += kBlock) desc_lds[k] = v.desc3[k];
+    for (int k = tid; k < v.thr_lds_len; k += kBlock) thr_lds[k] = v.thr[k];
+    for (int k = tid; k <= a.n_contigs; k += kBlock) coff_lds[k] = a.contig_off[k];
+    css_lds[tid] = v.css_lut[tid];
+    __syncthreads();
+
+    for (int tile = blockIdx.x; tile < v.n_blocks; tile += gridDim.x) {
+        const int64_t i_raw = (int64_t)tile * kBlock + tid;
+        const bool live = i_raw < a.n;
+        const int64_t i = live ? i_raw : a.n - 1;     // idle lanes of the last tile shadow the last variant
+
+        // ---- staging plan (one lane) and variant columns (all lanes), issued together
+        if (tid == 0) {
+            const int4* r0 = reinterpret_cast<const int4*>(v.brackets3 + (int64_t)tile * 8);
+            const int4 l0 = r0[0], l1 = r0[1], h0 = r0[2], h1 = r0[3];
+            const int lo[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, 0};
+            const int hi[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, 0};
+            int used = 0, maxlen = 0, ok = 1;
+            // blacklist first (8-byte elements, pool offset stays 8-byte aligned)
+            {
+                const int t = kJoin3 - 1, na = v.na3[t];
+                const int H = hi[t] + 1 < na ? hi[t] + 1 : na;
+                plan.lo[t] = lo[t]; plan.hi[t] = hi[t]; plan.base[t] = lo[t];
+                plan.cnt[t] = H - lo[t]; plan.offS[t] = used; plan.offE[t] = used;
+                used += 2 * (H - lo[t]);
+                maxlen = hi[t] - lo[t];
+                plan.bits[t] = maxlen > 0 ? 32 - __builtin_clz((unsigned)maxlen) : 0;
+            }
+            for (int t = 0; t < kJoin3 - 1; ++t) {
+                const int na = v.na3[t];
+                const int L = lo[t] - 2 > 0 ? lo[t] - 2 : 0;
+                const int H = hi[t] + 1 < na ? hi[t] + 1 : na;
+                plan.lo[t] = lo[t]; plan.hi[t] = hi[t]; plan.base[t] = L; plan.cnt[t] = H - L;
+                plan.offS[t] = used; plan.offE[t] = used + (H - L);
+                used += 2 * (H - L);
+                const int len = hi[t] - lo[t];
+                plan.bits[t] = len > 0 ? 32 - __builtin_clz((unsigned)len) : 0;
+                maxlen = len > maxlen ? len : maxlen;
+            }
+            ok = used <= kPool3;
+            plan.staged = ok;
+            plan.maxbits = maxlen > 0 ? 32 - __builtin_clz((unsigned)maxlen) : 0;
+        }
+        const int c = a.contig[i];
+        const int pos = a.pos[i];
+        const int rl = a.ref_len[i], al = a.alt_len[i];
+        const uint32_t ro = a.ref_off[i], ao = a.alt_off[i];
+        const float qual = a.qual[i], sor = a.sor[i];
+        const int dp = a.dp[i], adr = a.ad_ref[i], ada = a.ad_alt[i];
+        const int gq = a.gq[i];
+
+        // ---- classify_indel (lengths only), then the second batch of loads: reference window,
+        // allele bytes, CSR pointers of the side tables
+        const bool indel = rl != al;
+        const bool ins = rl < al;
+        const int classify = !indel ? 0 : (ins ? 1 : 2);
+        const int indel_length = ins ? al - rl : rl - al;
+        const int64_t clo = coff_lds[c], chi = coff_lds[c + 1];
+        const uint32_t clen = (uint32_t)(chi - clo);
+        const uint32_t p0 = (uint32_t)(pos - 1);              // 0-based offset inside the contig
+        const int64_t g0 = clo + p0;
+        int64_t ws = (g0 - 6) & ~(int64_t)15;
+        if (ws < 0) ws = 0;
+        const int o0 = (int)(g0 - ws);                        // byte of the variant's first base, 6..21 (less at genome start)
+        uint32_t* wrow = win + tid * kWinStride;
+        {
+            // the reference buffer is padded by 64 bytes: three aligned 16-byte loads never overrun
+            const uint4* src = reinterpret_cast<const uint4*>(a.ref + ws);
+            const uint4 x0 = src[0], x1 = src[1], x2 = src[2];
+            wrow[0] = x0.x; wrow[1] = x0.y; wrow[2] = x0.z; wrow[3] = x0.w;
+            wrow[4] = x1.x; wrow[5] = x1.y; wrow[6] = x1.z; wrow[7] = x1.w;
+            wrow[8] = x2.x; wrow[9] = x2.y; wrow[10] = x2.z; wrow[11] = x2.w;
+        }
+        // allele bytes: substitutions need ref[0], alt[0]; indels the tail of the longer allele
+        const uint32_t lo_off = ins ? ao : ro;
+        const int ln = ins ? al : rl;
+        uint32_t ab[8];
+        {
+            const uint32_t q0 = indel ? lo_off + 1 : ro;
+            const uint32_t q1 = indel ? lo_off + (2 < ln ? 2 : ln - 1) : ao;
+            ab[0] = apool[q0];
+            ab[1] = apool[q1];
+#pragma unroll
+            for (int k = 2; k < 8; ++k) ab[k] = apool[lo_off + (k + 1 < ln ? k + 1 : ln - 1)];
+        }
+        int plo[kJoin3 - 1], phi[kJoin3 - 1];
+#pragma unroll
+        for (int t = 0; t < kJoin3 - 1; ++t) {
+            plo[t] = phi[t] = 0;
+            if (table_present(a, t)) {
+                const TrackView& tv = table_view(a, t);
+                plo[t] = tv.ptr[(uint32_t)c];
+                phi[t] = tv.ptr[(uint32_t)c + 1u];
+            }
+        }
+        __syncthreads();                                      // plan visible
+
+        // ---- stage the slices this tile can touch: wave w copies segments w, w+4, w+8, w+12
+        const int staged = rfl(plan.staged);
+        if (staged) {
+            const int wave = tid >> 6;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int seg = wave + 4 * q;                 // 0..5 starts, 6..11 ends, 12 blacklist
+                if (seg > 12) break;
+                const int t = seg < 6 ? seg : (seg < 12 ? seg - 6 : 6);
+                int cnt = rfl(plan.cnt[t]);
+                if (cnt <= 0) continue;
+                const int32_t* src;
+                int dst;
+                if (seg == 12) {
+                    src = reinterpret_cast<const int32_t*>(a.bl) + 2 * (int64_t)rfl(plan.base[t]);
+                    dst = rfl(plan.offS[t]);
+                    cnt *= 2;
+                } else {
+                    const TrackView& tv = table_view(a, t);
+                    src = (seg < 6 ? tv.starts : tv.ends) + rfl(plan.base[t]);
+                    dst = seg < 6 ? rfl(plan.offS[t]) : rfl(plan.offE[t]);
+                }
+                const int k0 = lane, k1 = lane + 64;
+                const int x0 = k0 < cnt ? src[k0] : 0;
+                const int x1 = k1 < cnt ? src[k1] : 0;
+                if (k0 < cnt) pool[dst + k0] = x0;
+                if (k1 < cnt) pool[dst + k1] = x1;
+                for (int k = lane + 128; k < cnt; k += 64) pool[dst + k] = src[k];
+            }
+        }
+
+        // ---- contig-edge lanes blank the window bytes that lie outside their contig (reads as N)
+        if (ws < clo || ws + kWinBytes > chi) {
+#pragma unroll
+            for (int q = 0; q < kWinDw; ++q) {
+                uint32_t m = 0;
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    const int64_t gi = ws + 4 * q + bb;
+                    m |= (gi >= clo && gi < chi) ? (0xffu << (8 * bb)) : 0u;
+                }
+                wrow[q] &= m;
+            }
+        }
+        const uint8_t* wb = reinterpret_cast<const uint8_t*>(wrow);
+        // reference base at contig offset p0 + d (0 outside the contig); window first, HBM beyond it
+        auto ref_at = [&](int d) -> int {
+            const int o = o0 + d;
+            if (o >= 0 && o < kWinBytes) return wb[o];
+            const int64_t gi = g0 + d;
+            return (gi >= clo && gi < chi) ? (int)a.ref[gi] : 0;
+        };
+
+        // ---- is_hmer_indel.  so = window byte of the first base after the variant's alleles
+        // (insertion/substitution: pos+1; deletion: pos+len(ref)); an hmer indel's run starts there.
+        const int d_so = (indel && !ins) ? rl : 1;
+        const int so = o0 + d_so;
+        int hmer_len = 0, hmer_nuc = 0, run = 0;
+        if (indel) {
+            const int bb = ab[0];
+            bool mono = true;
+#pragma unroll
+            for (int k = 1; k < 8; ++k) mono &= ab[k] == (uint32_t)bb;     // clamped reads repeat the last byte
+            if (ln > 9)
+                for (int k = 9; k < ln; ++k) mono &= apool[lo_off + k] == bb;
+            const uint32_t pstart = p0 + (uint32_t)d_so;
+            if (mono && pstart < clen) {
+                if (so + 12 <= kWinBytes) {
+                    int nrun = 0;
+                    bool go = true;
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) {
+                        go = go && wb[so + k] == bb;
+                        nrun += go ? 1 : 0;
+                    }
+                    run = nrun;
+                    if (nrun == 12)
+                        while (ref_at(d_so + run) == bb && pstart + (uint32_t)run < clen) ++run;
+                } else {
+                    while (pstart + (uint32_t)run < clen && ref_at(d_so + run) == bb) ++run;
+                }
+                const uint32_t room = clen - pstart;           // an N run may not run past the contig end
+                if ((uint32_t)run > room) run = (int)room;
+                if (run > 0) {
+                    hmer_len = run + (ins ? 0 : rl - 1);
+                    hmer_nuc = bb;
+                }
+            }
+        }
+        const bool is_h = indel && hmer_len > 0;
+        const int group = !indel ? 0 : (is_h ? 1 : 2);
+
+        // ---- record slots: one returning atomic per wave and group, consumed after the quantisation
+        const bool pg_ok = (okbits >> group) & 1;
+        const bool mine = live && pg_ok;
+        unsigned slot_base = 0, grank = 0;
+        {
+            const int shard = tile & (kShards - 1);
+            unsigned long long m[UGVC_N_GROUPS];
+#pragma unroll
+            for (int g = 0; g < UGVC_N_GROUPS; ++g) m[g] = __ballot(mine && group == g);
+            const unsigned long long mg = lane == 0 ? m[0] : (lane == 1 ? m[1] : m[2]);
+            unsigned got = 0;
+            if (lane < UGVC_N_GROUPS && mg != 0)
+                got = atomicAdd(&v.counters[(lane * kShards + shard) * kCounterStride], (unsigned)__popcll(mg));
+            const unsigned long long mm = group == 0 ? m[0] : (group == 1 ? m[1] : m[2]);
+            grank = __popcll(mm & ((1ull << lane) - 1));
+            slot_base = got;                                  // lanes 0..2 hold the bases; shuffled out at the end
+        }
+
+        // ---- get_motif_around (5), gc_content (10)
+        int W[11];                                            // bases at pos-5 .. pos+5
+#pragma unroll
+        for (int k = 0; k < 11; ++k) W[k] = wb[o0 - 5 + k];
+        if (o0 < 5) {                                         // genome start: the window begins at base 0
+#pragma unroll
+            for (int k = 0; k < 11; ++k) W[k] = ref_at(k - 5);
+        }
+        int lmb[kMotif], rmb[kMotif];
+        // right motif starts at pos+1 (substitution), pos+len(ref) (non-hmer indel, also a complex
+        // insertion with len(ref) > 1) or just past the run (hmer indel: pos+1+hmer_len)
+        const int d_r = is_h ? d_so + run : (indel ? rl : 1);
+        if (o0 + d_r + kMotif <= kWinBytes) {
+#pragma unroll
+            for (int k = 0; k < kMotif; ++k) rmb[k] = wb[o0 + d_r + k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < kMotif; ++k) rmb[k] = ref_at(d_r + k);
+        }
+        int lm = 0, rm = 0;
+        bool motif_n = false;
+#pragma unroll
+        for (int k = 0; k < kMotif; ++k) {
+            lmb[k] = indel ? W[k + 1] : W[k];
+            lm = lm * 5 + lmb[k];
+            rm = rm * 5 + rmb[k];
+            motif_n |= lmb[k] == 0 || rmb[k] == 0;
+        }
+        int gc_cnt = 0, gc_len = 0;
+#pragma unroll
+        for (int k = 0; k < kGcWindow; ++k) {
+            const uint32_t pw = p0 + 1 - kGcWindow / 2 + k;   // wraps below 0 -> fails the bound test
+            const bool inb = pw < clen;
+            const int bb = W[k + 1];
+            gc_len += inb;
+            gc_cnt += inb && bb != 1 && bb != 4;
+        }
+        const float gc = gc_len > 0 ? (float)((double)gc_cnt / (double)gc_len) : 0.0f;
+
+        // ---- cycle skip
+        int css = 3;
+        if (!indel) {
+            if (rl == 1) {
+                const int rb = ab[0], abase = ab[1];
+                if (motif_n || rb == 0 || abase == 0) css = 0;
+                else css = css_lds[((lmb[kMotif - 1] - 1) << 6) | ((rb - 1) << 4) | ((abase - 1) << 2) | (rmb[0] - 1)];
+            } else {
+                bool has_n = motif_n;
+                for (int k = 0; k < rl; ++k) has_n |= apool[ro + k] == 0 || apool[ao + k] == 0;
+                if (has_n) css = 0;
+                else {
+                    auto mot = [&](const int (&mb)[kMotif], int q) -> int {
+                        return mb[0] * (q == 0) + mb[1] * (q == 1) + mb[2] * (q == 2) + mb[3] * (q == 3) + mb[4] * (q == 4);
+                    };
+                    auto seq_r = [&](int k) -> int {
+                        if (k < kMotif) return mot(lmb, k);
+                        if (k < kMotif + rl) return apool[ro + k - kMotif];
+                        return mot(rmb, k - kMotif - rl);
+                    };
+                    auto seq_a = [&](int k) -> int {
+                        if (k < kMotif) return mot(lmb, k);
+                        if (k < kMotif + rl) return apool[ao + k - kMotif];
+                        return mot(rmb, k - kMotif - rl);
+                    };
+                    css = cycle_skip_walk(rl + 2 * kMotif, a.flow, seq_r, seq_a);
+                }
+            }
+        }
+        __syncthreads();                                      // staged slices visible
+
+        // ---- joins: rank among the starts of every table + blacklist keys, all descents in lock-step
+        uint8_t flags = 0;
+        bool inside_run = false, close_run = false;
+        bool trk[UGVC_MAX_TRACKS] = {false, false, false, false, false};
+        const uint64_t key = ((uint64_t)c << 32) | (uint32_t)pos;
+        if (staged) {
+            const uint32_t pool_b = lds_addr(pool);                // LDS byte address of the pool
+            uint32_t p[kJoin3], pend[kJoin3];
+            int baseS[kJoin3];
+#pragma unroll
+            for (int t = 0; t < kJoin3; ++t) {
+                const int blo = rfl(plan.lo[t]), bhi = rfl(plan.hi[t]), bs = rfl(plan.base[t]);
+                const int esz = t == kJoin3 - 1 ? 8 : 4;
+                int slo = blo, shi = bhi;
+                if (t < kJoin3 - 1) {
+                    slo = blo > plo[t] ? blo : plo[t];
+                    shi = bhi < phi[t] ? bhi : phi[t];
+                    if (shi < slo) shi = slo;
+                }
+                baseS[t] = bs;
+                const uint32_t A = pool_b + 4u * (uint32_t)rfl(plan.offS[t]);
+                p[t] = A + (uint32_t)(esz * (slo - bs)) - esz;        // address of element slo-1
+                pend[t] = A + (uint32_t)(esz * (shi - bs)) - esz;     // address of element shi-1
+            }
+            const int bits = rfl(plan.maxbits);
+            int tb_[kJoin3];
+#pragma unroll
+            for (int t = 0; t < kJoin3; ++t) tb_[t] = rfl(plan.bits[t]);
+            for (int s = bits - 1; s >= 0; --s) {
+#pragma unroll
+                for (int t = 0; t < kJoin3 - 1; ++t) {
+                    if (s < tb_[t]) {                            // wave-uniform: short tables drop out early
+                        const uint32_t cand = p[t] + (4u << s);
+                        const int x = lds_i32(cand);
+                        p[t] = ((int32_t)(pend[t] - cand) >= 0 && x < pos) ? cand : p[t];
+                    }
+                }
+                if (s < tb_[kJoin3 - 1]) {
+                    const int t = kJoin3 - 1;
+                    const uint32_t cand = p[t] + (8u << s);
+                    const uint64_t x = lds_u64(cand);
+                    p[t] = ((int32_t)(pend[t] - cand) >= 0 && x < key) ? cand : p[t];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < kJoin3 - 1; ++t) {
+                if (!table_present(a, t)) continue;
+                const uint32_t A = pool_b + 4u * (uint32_t)rfl(plan.offS[t]);
+                const uint32_t dE = 4u * (uint32_t)(rfl(plan.offE[t]) - rfl(plan.offS[t]));
+                const int sg = baseS[t] + (int)((p[t] + 4 - A) >> 2);     // #starts < pos (global index)
+                const int e1v = lds_i32(p[t] + dE);                       // ends[sg-1]
+                const int e2v = lds_i32(p[t] + dE - 4);                   // ends[sg-2]
+                const bool valid = sg > plo[t];
+                if (t == 0) {
+                    // runs are disjoint: #ends < pos is sg-1 or sg
+                    const bool ins_run = valid && e1v >= pos;
+                    if (phi[t] > plo[t]) {
+                        const int eg = valid ? sg - 1 + (e1v < pos ? 1 : 0) : sg;
+                        const int D = a.hpol_dist;
+                        auto near = [&](int x) { const int d = pos - x; return (d < 0 ? -d : d) < D; };
+                        const int s1v = lds_i32(p[t]);                    // starts[sg-1]
+                        const int s0v = lds_i32(p[t] + 4);                // starts[sg]
+                        bool cd = (valid && near(s1v)) || (sg <= phi[t] - 1 && near(s0v));
+                        const uint32_t pe = p[t] + dE + 4u * (uint32_t)(eg - (sg - 1));   // address of ends[eg]
+                        const int ee = lds_i32(pe), em = lds_i32(pe - 4);
+                        cd = cd || (eg - 1 >= plo[t] && near(em)) || (eg <= phi[t] - 1 && near(ee));
+                        inside_run = ins_run;
+                        close_run = cd && !ins_run;
+                    }
+                } else {
+                    const bool in = valid && e1v >= pos && (sg - 1 == plo[t] || e2v < pos);
+                    trk[t - 1] = in;
+                    flags |= in ? (uint8_t)(1u << (UGVC_FLAG_TRACK0_SHIFT + t - 1)) : 0;
+                }
+            }
+            if (a.n_bl > 0) {
+                const int t = kJoin3 - 1;
+                const uint32_t A = pool_b + 4u * (uint32_t)rfl(plan.offS[t]);
+                const int r = (int)((p[t] + 8 - A) >> 3);                 // local rank
+                const uint64_t x = lds_u64(p[t] + 8);
+                if (r < rfl(plan.cnt[t]) && x == key) flags |= UGVC_FLAG_COHORT_FP;
+            }
+        } else {
+            // dense tile (slices exceed the pool): same arithmetic on the HBM copies
+#pragma unroll
+            for (int t = 0; t < kJoin3 - 1; ++t) {
+                if (!table_present(a, t)) continue;
+                const TrackView& tv = table_view(a, t);
+                const int sg = lb_i32_g(tv.starts, plo[t], phi[t], pos);
+                const bool valid = sg > plo[t];
+                const int e1v = valid ? tv.ends[sg - 1] : 0;
+                if (t == 0) {
+                    const bool ins_run = valid && e1v >= pos;
+                    if (phi[t] > plo[t]) {
+                        const int eg = valid ? sg - 1 + (e1v < pos ? 1 : 0) : sg;
+                        const int D = a.hpol_dist;
+                        auto near = [&](int x) { const int d = pos - x; return (d < 0 ? -d : d) < D; };
+                        bool cd = (valid && near(tv.starts[sg - 1])) || (sg <= phi[t] - 1 && near(tv.starts[sg]));
+                        cd = cd || (eg - 1 >= plo[t] && near(tv.ends[eg - 1])) || (eg <= phi[t] - 1 && near(tv.ends[eg]));
+                        inside_run = ins_run;
+                        close_run = cd && !ins_run;
+                    }
+                } else {
+                    const bool in = valid && e1v >= pos && (sg - 1 == plo[t] || tv.ends[sg - 2] < pos);
+                    trk[t - 1] = in;
+                    flags |= in ? (uint8_t)(1u << (UGVC_FLAG_TRACK0_SHIFT + t - 1)) : 0;
+                }
+            }
+            if (a.n_bl > 0) {
+                const int r = lb_u64_g(a.bl, 0, (int)a.n_bl, key);
+                if (r < (int)a.n_bl && a.bl[r] == key) flags |= UGVC_FLAG_COHORT_FP;
+            }
+        }
+        if (a.mark_hpol && (inside_run || close_run)) flags |= UGVC_FLAG_HPOL_RUN;
+        if (live) a.flags[i] = flags;
+        if (!pg_ok && live) {              // no model for this variant type: score 0, PASS
+            a.score[i] = 0.f;
+            a.filter[i] = UGVC_FILTER_PASS;
+        }
+
+        // ---- quantise: feature -> rank among the group's sorted thresholds
+        const float vaf = dp > 0 ? __fdiv_rn((float)ada, (float)dp) : 0.0f;
+        const uint2* dsc = desc_lds + group * kMaxFeatures;
+        uint32_t c0 = 0, c1 = 0, c2 = 0;
+        // the dword of a feature is the same for every group (host: joint_layout), so the
+        // accumulator is chosen with wave-uniform masks; only the bit offset is per lane
+        auto put = [&](int j, uint32_t dy, uint32_t code) {
+            const uint32_t val = code << ((dy >> 18) & 31);
+            const uint32_t dwj = v.dw3[j];
+            c0 |= val & (dwj == 0 ? ~0u : 0u);
+            c1 |= val & (dwj == 1 ? ~0u : 0u);
+            c2 |= val & (dwj == 2 ? ~0u : 0u);
+        };
+        const bool upper = (gbtbits >> group) & 1;
+        if (pg_ok) {
+            // float features: lock-step descent over the LDS threshold slices
+            {
+                const float fx[4] = {qual, sor, vaf, gc};
+                const int fj[4] = {0, 1, 5, 13};
+                const uint32_t thr_b = lds_addr(thr_lds);
+                uint32_t q[4], qend[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint2 d = dsc[fj[k]];
+                    q[k] = thr_b + 4u * (d.x & 0xFFFFFu) - 4;
+                    qend[k] = q[k] + 4u * (d.y & 0xFFFFu);
+                }
+                const int fb0 = v.thr_bits4[0], fb1 = v.thr_bits4[1], fb2 = v.thr_bits4[2], fb3 = v.thr_bits4[3];
+                const int fbm = max(max(fb0, fb1), max(fb2, fb3));
+                for (int s = fbm - 1; s >= 0; --s) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int fb = k == 0 ? fb0 : (k == 1 ? fb1 : (k == 2 ? fb2 : fb3));
+                        if (s < fb) {
+                            const uint32_t cand = q[k] + (4u << s);
+                            const float t = lds_f32(cand);
+                            const bool lt = upper ? t <= fx[k] : t < fx[k];
+                            q[k] = ((int32_t)(qend[k] - cand) >= 0 && lt) ? cand : q[k];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint2 d = dsc[fj[k]];
+                    uint32_t cd = (q[k] + 4 - (thr_b + 4u * (d.x & 0xFFFFFu))) >> 2;
+                    if (fx[k] != fx[k]) cd = d.y & 0xFFFFu;       // NaN compares false: always the right branch
+                    put(fj[k], d.y, cd);
+                }
+            }
+            // integer-valued features: one LUT load each, issued in two batches of independent loads
+            int iv[kMaxFeatures];
+            iv[0] = iv[1] = iv[5] = iv[13] = 0;
+            iv[2] = dp; iv[3] = adr; iv[4] = ada; iv[6] = gq; iv[7] = classify; iv[8] = indel_length;
+            iv[9] = hmer_len; iv[10] = hmer_nuc; iv[11] = lm; iv[12] = rm; iv[14] = css;
+#pragma unroll
+            for (int j = 15; j < kMaxFeatures; ++j) iv[j] = 0;
+            {
+                // the seven 0/1 features sit in fixed bits 25..31 of dword 2; rank code == value
+                // wherever the group's model tests them below 1 (boolmask3), else constant 0
+                const uint32_t bits7 = (inside_run ? 1u : 0u) | (close_run ? 2u : 0u) | ((uint32_t)(flags >> UGVC_FLAG_TRACK0_SHIFT) << 2);
+                const uint32_t bm = group == 0 ? v.boolmask3[0] : (group == 1 ? v.boolmask3[1] : v.boolmask3[2]);
+                c2 |= (bits7 & bm) << 25;
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int j0 = half == 0 ? 2 : 9, j1 = half == 0 ? 9 : 15;
+                uint32_t code[kMaxFeatures];
+                bool slow = false;
+#pragma unroll
+                for (int j = j0; j < j1; ++j) {
+                    if (j == 5 || j == 13) continue;
+                    if (j >= F) break;
+                    const uint2 d = dsc[j];
+                    const uint32_t len = d.y & 0xFFFFu;
+                    const uint32_t x = (uint32_t)iv[j];
+                    const uint32_t idx = x < len ? x : len - 1;
+                    code[j] = v.lut[(d.x & 0xFFFFFu) + idx];
+                    slow |= (d.x >> 30) == 1 && x >= len;
+                }
+                if (slow) {                                       // value beyond the LUT: search the thresholds in HBM
+#pragma unroll
+                    for (int j = j0; j < j1; ++j) {
+                        if (j == 5 || j == 13) continue;
+                        if (j >= F) break;
+                        const uint2 d = dsc[j];
+                        if ((d.x >> 30) == 1 && (uint32_t)iv[j] >= (d.y & 0xFFFFu)) {
+                            const FeatDesc fd = v.desc[group * kMaxFeatures + j];
+                            const uint32_t toff = fd.thr & 0xFFFFF, tlen = fd.thr >> 20;
+                            const float x = (float)iv[j];
+                            uint32_t bb = 0, len = tlen;
+                            while (len > 0) {
+                                const uint32_t hf = len >> 1;
+                                const float t = v.thr[toff + bb + hf];
+                                const bool lt = upper ? t <= x : t < x;
+                                bb = lt ? bb + hf + 1 : bb;
+                                len = lt ? len - hf - 1 : hf;
+                            }
+                            code[j] = bb;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = j0; j < j1; ++j) {
+                    if (j == 5 || j == 13) continue;
+                    if (j >= F) break;
+                    put(j, dsc[j].y, code[j]);
+                }
+            }
+        }
+
+        // ---- append {codes, variant index} to the group's sharded record list
+        {
+            const unsigned b0 = __shfl(slot_base, 0), b1 = __shfl(slot_base, 1), b2 = __shfl(slot_base, 2);
+            const unsigned sb = group == 0 ? b0 : (group == 1 ? b1 : b2);
+            const int shard = tile & (kShards - 1);
+            if (mine)
+                v.records[group][(size_t)shard * v.shard_cap + sb + grank] = make_uint4(c0, c1, c2, (uint32_t)i);
+        }
+        __syncthreads();                                      // plan / pool are rewritten by the next tile
+    }
+}
+
+// ---- K2 ------------------------------------------------------------------------------------
+// One workgroup per CU, one variant-type group per workgroup, whole forest in LDS (layout as v2:
+// u32 nodes in 1-based heap order, rank[0:16) | code-plane byte offset[16:32)).
+
+// idx' = 2 * idx + (lane's bit of mask): one v_addc_co_u32 (the compare result feeds the carry-in)
+__device__ __forceinline__ uint32_t twice_plus_carry(uint32_t idx, unsigned long long mask) {
+    uint32_t out;
+    unsigned long long cout;
+    asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(out), "=s"(cout) : "v"(idx), "s"(mask));
+    return out;
+}
+
+// A node visit is 4 VALU + 2 LDS reads: v_lshl_add (node address), ds_read_b32, v_add_sdwa (code
+// address from the node's high half), ds_read_u16, v_cmp_sdwa (code vs rank) and v_addc.  The
+// scoring pass is VALU-issue bound on gfx950 (one wave-instruction per 4 cycles per SIMD; measured
+// 73 % VALU busy at 7.3 VALU per visit), so the instruction count per visit is what matters; NT
+// independent trees per lane cover the two dependent LDS latencies of a level.
+template <int NT>
+__device__ __forceinline__ void walk3(uint32_t nodes_b, uint32_t planes_lane_b, int t, int D, int NL, int (&leaf)[NT]) {
+    uint32_t idx[NT], tb[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        tb[k] = nodes_b + 4u * (uint32_t)((t + k) * NL);
+        idx[k] = 1;
+    }
+    for (int d = 0; d < D; ++d) {
+        uint32_t w[NT], code[NT];
+#pragma unroll
+        for (int k = 0; k < NT; ++k) w[k] = lds_u32(tb[k] + 4u * idx[k]);
+#pragma unroll
+        for (int k = 0; k < NT; ++k) code[k] = lds_u16(planes_lane_b + (w[k] >> 16));
+#pragma unroll
+        for (int k = 0; k < NT; ++k)
+            idx[k] = twice_plus_carry(idx[k], __builtin_amdgcn_ballot_w64(code[k] > (w[k] & 0xFFFFu)));
+    }
+#pragma unroll
+    for (int k = 0; k < NT; ++k) leaf[k] = (t + k) * NL + (int)idx[k] - NL;
+}
+
+__global__ __launch_bounds__(kK2Threads) void forest3_kernel(const V2Args v) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned shard_off[kShards + 1];
+    __shared__ unsigned totals[UGVC_N_GROUPS];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int n_waves = blockDim.x >> 6;
+    if (tid < UGVC_N_GROUPS) totals[tid] = 0;
+    __syncthreads();
+    for (int k = tid; k < UGVC_N_GROUPS * kShards; k += blockDim.x) {
+        const unsigned cshard = v.counters[k * kCounterStride];
+        if (cshard) atomicAdd(&totals[k / kShards], cshard);
+    }
+    __syncthreads();
+    // workgroups are split over the groups in proportion to count x trees x depth
+    const int B = gridDim.x;
+    unsigned cnt[UGVC_N_GROUPS];
+    double work[UGVC_N_GROUPS], tot = 0.0;
+    for (int g = 0; g < UGVC_N_GROUPS; ++g) {
+        cnt[g] = v.pg[g].ok ? totals[g] : 0u;
+        work[g] = (double)cnt[g] * v.pg[g].T * v.pg[g].D;
+        tot += work[g];
+    }
+    if (tot == 0.0) return;
+    int nb[UGVC_N_GROUPS], used = 0, big = 0;
+    for (int g = 0; g < UGVC_N_GROUPS; ++g) {
+        nb[g] = cnt[g] ? (int)(B * (work[g] / tot) + 0.5) : 0;
+        if (cnt[g] && nb[g] < 1) nb[g] = 1;
+        used += nb[g];
+        if (work[g] > work[big]) big = g;
+    }
+    nb[big] += B - used;
+    if (nb[big] < 1) return;
+    int g = 0, lb = blockIdx.x;
+    while (g < UGVC_N_GROUPS - 1 && lb >= nb[g]) { lb -= nb[g]; ++g; }
+    const PackedGroupView pg = v.pg[g];
+    const unsigned n = cnt[g];
+    if (n == 0 || nb[g] == 0) return;
+
+    if (wave == 0) {                                             // exclusive scan of the group's shard counts
+        unsigned x[4], s = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { x[k] = v.counters[(g * kShards + lane * 4 + k) * kCounterStride]; s += x[k]; }
+        unsigned incl = s;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned y = __shfl_up(incl, d);
+            if (lane >= d) incl += y;
+        }
+        unsigned runv = incl - s;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { shard_off[lane * 4 + k] = runv; runv += x[k]; }
+        if (lane == 63) shard_off[kShards] = runv;
+    }
+
+    const int D = pg.D, NL = 1 << D;
+    const size_t n_nodes = (size_t)pg.T * NL;
+    uint32_t* nodes = reinterpret_cast<uint32_t*>(smem);
+    size_t off = (n_nodes * 4 + 15) & ~(size_t)15;
+    double2* pairs = reinterpret_cast<double2*>(smem + off);
+    float* leaf_f32 = reinterpret_cast<float*>(smem + off);
+    off += pg.kind == UGVC_MODEL_RF ? (size_t)pg.n_pairs * 16 : ((n_nodes * 4 + 15) & ~(size_t)15);
+    uint16_t* leaf_idx = reinterpret_cast<uint16_t*>(smem + off);
+    if (pg.kind == UGVC_MODEL_RF) off += (n_nodes * 2 + 15) & ~(size_t)15;
+    uint16_t* planes_all = reinterpret_cast<uint16_t*>(smem + off);
+    for (size_t k = tid; k < n_nodes; k += blockDim.x) nodes[k] = pg.nodes[k];
+    if (pg.kind == UGVC_MODEL_RF) {
+        for (size_t k = tid; k < (size_t)pg.n_pairs; k += blockDim.x) pairs[k] = pg.pairs[k];
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(pg.leaf_idx);      // T * 2^D halfwords: an even count
+        uint32_t* dst = reinterpret_cast<uint32_t*>(leaf_idx);
+        for (size_t k = tid; k < n_nodes / 2; k += blockDim.x) dst[k] = src[k];
+    } else {
+        for (size_t k = tid; k < n_nodes; k += blockDim.x) leaf_f32[k] = pg.leaf_f32[k];
+    }
+    __syncthreads();
+
+    const int P = pg.n_planes;
+    uint16_t* planes = planes_all + (size_t)wave * P * 64;
+    // lane -> halfword slot of a plane: lanes 0..31 take the low halves of the 32 dwords, lanes
+    // 32..63 the high halves, so both lane groups of a ds_read_u16 hit 32 distinct banks
+    const int hslot = ((lane & 31) << 1) | (lane >> 5);
+    const uint32_t nodes_b = lds_addr(nodes);
+    const uint32_t planes_lane_b = lds_addr(planes + hslot);
+    const unsigned waves = (unsigned)nb[g] * n_waves;
+    const uint4* __restrict__ rec = v.records[g];
+    const int T = pg.T;
+    for (unsigned chunk = (unsigned)lb * n_waves + wave; (uint64_t)chunk * 64 < n; chunk += waves) {
+        const unsigned r = chunk * 64 + lane;
+        const bool live = r < n;
+        const unsigned rr = live ? r : n - 1;
+        int lo = 0, len = kShards;
+        while (len > 1) {                                        // shard of record rr
+            const int half = len >> 1;
+            const bool ge = shard_off[lo + half] <= rr;
+            lo = ge ? lo + half : lo;
+            len = ge ? len - half : half;
+        }
+        const uint4 q = rec[(size_t)lo * v.shard_cap + (rr - shard_off[lo])];
+        for (int p = 0; p < P; ++p) {
+            const uint32_t pd = pg.plane_desc[p];                // dword[0:2) | bit_off[2:7) | width[7:11)
+            const uint32_t dw = pd & 3;
+            const uint32_t word = dw == 0 ? q.x : (dw == 1 ? q.y : q.z);
+            planes[p * 64 + hslot] = (uint16_t)__builtin_amdgcn_ubfe(word, (pd >> 2) & 31, (pd >> 7) & 15);
+        }
+        double a0 = 0.0, a1 = 0.0;
+        float margin = pg.base;
+        int t = 0;
+        for (; t + 8 <= T; t += 8) {
+            int leaf[8];
+            walk3<8>(nodes_b, planes_lane_b, t, D, NL, leaf);
+            if (pg.kind == UGVC_MODEL_RF) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const double2 pv = pairs[leaf_idx[leaf[k]]]; a0 += pv.x; a1 += pv.y; }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) margin += leaf_f32[leaf[k]];
+            }
+        }
+        for (; t < T; ++t) {
+            int leaf[1];
+            walk3<1>(nodes_b, planes_lane_b, t, D, NL, leaf);
+            if (pg.kind == UGVC_MODEL_RF) { const double2 pv = pairs[leaf_idx[leaf[0]]]; a0 += pv.x; a1 += pv.y; }
+            else margin += leaf_f32[leaf[0]];
+        }
+        float score;
+        uint8_t filt;
+        if (pg.kind == UGVC_MODEL_RF) {
+            const double pr0 = a0 / (double)T, pr1 = a1 / (double)T;
+            score = (float)pr1;
+            filt = pr1 > pr0 ? UGVC_FILTER_PASS : UGVC_FILTER_LOW_SCORE;
+        } else {
+            score = 1.0f / (1.0f + expf(-margin));
+            filt = margin > 0.0f ? UGVC_FILTER_PASS : UGVC_FILTER_LOW_SCORE;
+        }
+        if (live) {
+            v.f.score[q.w] = score;
+            v.f.filter[q.w] = filt;
+        }
+    }
+}
+
+static size_t k3_lds_bytes(const PackedGroupView& pg, int n_waves) {
+    const size_t NL = (size_t)1 << pg.D, n_nodes = (size_t)pg.T * NL;
+    size_t b = (n_nodes * 4 + 15) & ~(size_t)15;
+    if (pg.kind == UGVC_MODEL_RF) b += (size_t)pg.n_pairs * 16 + ((n_nodes * 2 + 15) & ~(size_t)15);
+    else b += (n_nodes * 4 + 15) & ~(size_t)15;
+    return b + (size_t)n_waves * pg.n_planes * 128;
+}
+
+int launch_filter_v3(ugvc_ctx* ctx, const FilterArgs& a) {
+    if (a.n == 0) return 0;
+    V2Args v;
+    v.f = a;
+    if (v2_fill_args(ctx, v, a.n)) return -1;
+    UGVC_HIP(hipMemsetAsync(v.counters, 0, (size_t)UGVC_N_GROUPS * kShards * kCounterStride * 4, ctx->stream));
+    const int64_t nbr = (int64_t)(v.n_blocks + 1) * 8;
+    hipLaunchKernelGGL(bracket3_kernel, dim3((unsigned)((nbr + 255) / 256)), dim3(256), 0, ctx->stream, v);
+    const int k1_grid = std::min(v.n_blocks, ctx->n_cus * 4);
+    hipLaunchKernelGGL(featurize3_kernel, dim3((unsigned)k1_grid), dim3(kBlock), 0, ctx->stream, v);
+    int n_waves = 0;
+    size_t lds = 0;
+    for (int w : {16, 12, 8, 4}) {
+        size_t need = 0;
+        for (int g = 0; g < UGVC_N_GROUPS; ++g)
+            if (v.pg[g].ok) need = std::max(need, k3_lds_bytes(v.pg[g], w));
+        if (need + 2048 <= 160 * 1024) { n_waves = w; lds = need; break; }
+    }
+    if (n_waves == 0) return fail("internal: packed forest does not fit LDS");
+    if (lds) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            UGVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(forest3_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(forest3_kernel, dim3((unsigned)ctx->n_cus), dim3(n_waves * 64), lds, ctx->stream, v);
+    }
+    UGVC_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace ugvc

@@ -23,14 +23,20 @@ struct V2Group {
     std::vector<float> threshold;
     std::vector<double> leaf_value;
     int dword[kMaxFeatures], bit_off[kMaxFeatures], width[kMaxFeatures], plane[kMaxFeatures];
+    int jdword[kMaxFeatures], jbit[kMaxFeatures];
     int n_planes = 0;
+    bool layout_done = false;               // dword / bit_off already chosen by the joint (group-uniform) layout
     std::vector<uint32_t> plane_desc;
     DeviceBuf d_nodes, d_leaf_idx, d_pairs, d_leaf_f32, d_plane_desc;
 };
 
 struct V2State {
     V2Group g[UGVC_N_GROUPS];
-    DeviceBuf desc, lut, thr, css, brackets, counters;
+    DeviceBuf desc, desc3, lut, thr, css, brackets, brackets3, counters;
+    int thr_bits4[4] = {0, 0, 0, 0};        // descent depth per float feature (qual, sor, vaf, gc), max over groups
+    bool uniform_layout = false;            // every group uses the same dword per feature; booleans in fixed slots
+    int dw3[kMaxFeatures];                  // that dword
+    uint32_t boolmask3[UGVC_N_GROUPS] = {0, 0, 0};
     DeviceBuf rec[UGVC_N_GROUPS];
     int thr_lds_len = 0;
     bool dirty = true, ok = false;
@@ -45,7 +51,7 @@ static V2State* state(ugvc_ctx* ctx) {
 void v2_destroy(ugvc_ctx* ctx) {
     if (!ctx->v2) return;
     V2State* s = static_cast<V2State*>(ctx->v2);
-    DeviceBuf* bufs[] = {&s->desc, &s->lut, &s->thr, &s->css, &s->brackets, &s->counters};
+    DeviceBuf* bufs[] = {&s->desc, &s->desc3, &s->lut, &s->thr, &s->css, &s->brackets, &s->brackets3, &s->counters};
     for (auto* b : bufs) if (b->p) (void)hipFree(b->p);
     for (auto& r : s->rec) if (r.p) (void)hipFree(r.p);
     for (auto& g : s->g)
@@ -111,14 +117,18 @@ static bool pack_group(V2Group& g) {
         if (m) order.push_back(f);
     }
     std::sort(order.begin(), order.end(), [&](int a, int b) { return g.width[a] > g.width[b]; });
-    int used[3] = {0, 0, 0};
-    for (int f : order) {
-        int d = 0;
-        while (d < 3 && used[d] + g.width[f] > 32) ++d;
-        if (d == 3) { g.why = "rank codes need more than 96 bits"; return false; }
-        g.dword[f] = d;
-        g.bit_off[f] = used[d];
-        used[d] += g.width[f];
+    if (g.layout_done) {
+        for (int f = 0; f < kMaxFeatures; ++f) { g.dword[f] = g.jdword[f]; g.bit_off[f] = g.jbit[f]; }
+    } else {
+        int used[3] = {0, 0, 0};
+        for (int f : order) {
+            int d = 0;
+            while (d < 3 && used[d] + g.width[f] > 32) ++d;
+            if (d == 3) { g.why = "rank codes need more than 96 bits"; return false; }
+            g.dword[f] = d;
+            g.bit_off[f] = used[d];
+            used[d] += g.width[f];
+        }
     }
     g.n_planes = 0;
     g.plane_desc.clear();
@@ -167,15 +177,79 @@ static int count_code(const V2Group& g, int f, float v) {   // rank code of valu
     return (int)(std::upper_bound(u.begin(), u.end(), v) - u.begin());
 }
 
+static bool boolean_feature(int f) { return f >= 15; }   // inside_hmer_run, close_to_hmer_run, track0..4
+
+// Group-uniform layout used by the v3 kernel: every feature sits in the SAME dword for all
+// variant-type groups (bit offsets stay per group), so the packing code selects the accumulator
+// with wave-uniform masks; the seven 0/1 features occupy fixed bits 25..31 of dword 2 and are
+// packed with one AND (their rank code equals their value when the single threshold lies in
+// [0, 1); a constant code 0 when it lies above).  Returns false when the models do not allow it
+// (then every group packs on its own and the scoring pass uses the v2 kernel).
+static bool joint_layout(V2State* s) {
+    int width[UGVC_N_GROUPS][kMaxFeatures] = {};
+    int maxw[kMaxFeatures] = {};
+    for (int gi = 0; gi < UGVC_N_GROUPS; ++gi) {
+        V2Group& g = s->g[gi];
+        g.layout_done = false;
+        s->boolmask3[gi] = 0;
+        if (!g.set) continue;
+        for (int f = 0; f < kMaxFeatures; ++f) {
+            const int m = (int)g.uthr[f].size();
+            if (m > 4094) return false;
+            width[gi][f] = m ? 32 - __builtin_clz((unsigned)m) : 0;
+            maxw[f] = std::max(maxw[f], width[gi][f]);
+            if (boolean_feature(f) && m) {
+                if (m > 1 || g.uthr[f][0] < 0.0f) return false;
+                if (g.uthr[f][0] < 1.0f) s->boolmask3[gi] |= 1u << (f - 15);
+            }
+        }
+    }
+    std::vector<int> order;
+    for (int f = 0; f < 15; ++f) if (maxw[f]) order.push_back(f);
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return maxw[a] > maxw[b]; });
+    const int cap[3] = {32, 32, 25};
+    int used[UGVC_N_GROUPS][3] = {};
+    int dw[kMaxFeatures] = {}, bit[UGVC_N_GROUPS][kMaxFeatures] = {};
+    for (int f : order) {
+        int d = 0;
+        for (; d < 3; ++d) {
+            bool fits = true;
+            for (int gi = 0; gi < UGVC_N_GROUPS; ++gi) fits &= used[gi][d] + width[gi][f] <= cap[d];
+            if (fits) break;
+        }
+        if (d == 3) return false;
+        dw[f] = d;
+        for (int gi = 0; gi < UGVC_N_GROUPS; ++gi) { bit[gi][f] = used[gi][d]; used[gi][d] += width[gi][f]; }
+    }
+    for (int f = 15; f < kMaxFeatures; ++f) {
+        dw[f] = 2;
+        for (int gi = 0; gi < UGVC_N_GROUPS; ++gi) bit[gi][f] = 25 + (f - 15);
+    }
+    for (int gi = 0; gi < UGVC_N_GROUPS; ++gi) {
+        V2Group& g = s->g[gi];
+        if (!g.set) continue;
+        for (int f = 0; f < kMaxFeatures; ++f) { g.jdword[f] = dw[f]; g.jbit[f] = bit[gi][f]; }
+        g.layout_done = true;
+    }
+    for (int f = 0; f < kMaxFeatures; ++f) s->dw3[f] = dw[f];
+    return true;
+}
+
 int finalize_pack(ugvc_ctx* ctx) {
     V2State* s = state(ctx);
     if (!s->dirty) return 0;
     s->ok = false;
     s->why.clear();
     std::vector<FeatDesc> desc((size_t)UGVC_N_GROUPS * kMaxFeatures, FeatDesc{0, 0, 0, 0});
-    std::vector<uint16_t> lut;
+    std::vector<uint2> desc3((size_t)UGVC_N_GROUPS * kMaxFeatures, make_uint2(0u, 1u));   // unused: dummy LUT entry 0
+    std::vector<uint16_t> lut(1, 0);              // entry 0: the code of every feature a group's model never tests
     std::vector<float> thr;
     bool all_ok = true;
+    int thr_bits4[4] = {0, 0, 0, 0};
+    s->uniform_layout = joint_layout(s);
+    for (int gi = 0; gi < UGVC_N_GROUPS; ++gi)
+        for (int f = 0; f < kMaxFeatures; ++f)
+            if (search_only_feature(f)) desc3[(size_t)gi * kMaxFeatures + f] = make_uint2(0u, 0u);   // empty threshold slice
     for (auto& g : s->g)
         if (g.set && !pack_group(g)) { all_ok = false; s->why = g.why; }
     if (all_ok) {
@@ -190,14 +264,21 @@ int finalize_pack(ugvc_ctx* ctx) {
                     d.thr = (uint32_t)thr.size() | ((uint32_t)g.uthr[f].size() << 20);   // off 20 bits | len 12 bits
                     thr.insert(thr.end(), g.uthr[f].begin(), g.uthr[f].end());
                     d.pack = (uint32_t)g.dword[f] | ((uint32_t)g.bit_off[f] << 2) | ((uint32_t)g.width[f] << 7);
+                    uint2& d3 = desc3[(size_t)gi * kMaxFeatures + f];
+                    const uint32_t pk3 = ((uint32_t)g.dword[f] << 16) | ((uint32_t)g.bit_off[f] << 18);
                     if (pass == 0) {
                         d.lut = 2u << 30;
+                        d3 = make_uint2((d.thr & 0xFFFFFu) | (2u << 30), (uint32_t)g.uthr[f].size() | pk3);
+                        const int m = (int)g.uthr[f].size();
+                        const int k4 = f == 0 ? 0 : (f == 1 ? 1 : (f == 5 ? 2 : 3));
+                        thr_bits4[k4] = std::max(thr_bits4[k4], m > 0 ? 32 - __builtin_clz((unsigned)m) : 0);
                     } else {
                         const double top = std::floor((double)g.uthr[f].back());
                         const int len = (int)std::min(8192.0, std::max(1.0, top + 2.0));
                         d.lut = (uint32_t)lut.size() | (1u << 30);
                         d.lut_len = (uint32_t)len;
                         for (int v = 0; v < len; ++v) lut.push_back((uint16_t)count_code(g, f, (float)v));
+                        d3 = make_uint2((d.lut & 0xFFFFFu) | (1u << 30), (uint32_t)len | pk3);
                     }
                 }
                 if (pass == 0 && gi == UGVC_N_GROUPS - 1) s->thr_lds_len = (int)thr.size();
@@ -207,6 +288,8 @@ int finalize_pack(ugvc_ctx* ctx) {
     if (all_ok) {
         UGVC_HIP(hipSetDevice(ctx->device));
         if (upload(ctx, s->desc, desc.data(), desc.size() * sizeof(FeatDesc))) return -1;
+        if (upload(ctx, s->desc3, desc3.data(), desc3.size() * sizeof(uint2))) return -1;
+        for (int k = 0; k < 4; ++k) s->thr_bits4[k] = thr_bits4[k];
         if (upload(ctx, s->lut, lut.data(), lut.size() * 2)) return -1;
         if (upload(ctx, s->thr, thr.data(), thr.size() * 4)) return -1;
         for (auto& g : s->g) {
@@ -307,7 +390,30 @@ int v2_fill_args(ugvc_ctx* ctx, V2Args& v, int64_t n) {
     if (ensure(s->counters, (size_t)UGVC_N_GROUPS * kShards * kCounterStride * 4)) return -1;
     v.brackets = s->brackets.as<int32_t>();
     v.counters = s->counters.as<uint32_t>();
+    // v3
+    if (ensure(s->brackets3, (size_t)(v.n_blocks + 1) * 8 * 4 + 64)) return -1;
+    v.brackets3 = s->brackets3.as<int32_t>();
+    v.desc3 = s->desc3.as<uint2>();
+    for (int k = 0; k < 4; ++k) v.thr_bits4[k] = s->thr_bits4[k];
+    for (int f = 0; f < kMaxFeatures; ++f) v.dw3[f] = (uint8_t)s->dw3[f];
+    for (int g = 0; g < UGVC_N_GROUPS; ++g) v.boolmask3[g] = s->boolmask3[g];
+    for (int t = 0; t < 8; ++t) v.na3[t] = 0;
+    v.na3[0] = ctx->has_runs ? (int)ctx->runs_n : 0;
+    for (int t = 0; t < ctx->n_tracks; ++t) v.na3[1 + t] = (int)ctx->trk_n[t];
+    v.na3[kJoin3 - 1] = (int)ctx->n_bl;
     return 0;
+}
+
+bool v3_available(ugvc_ctx* ctx) {
+    V2State* s = state(ctx);
+    if (!v2_available(ctx)) return false;
+    if (s->thr_lds_len > kThr3) return false;                 // float-feature thresholds must fit K1's LDS slice
+    if (!s->uniform_layout) return false;
+    if (ctx->n_contigs > 256) return false;
+    if (ctx->has_runs && !ctx->runs_fast) return false;
+    for (int t = 0; t < ctx->n_tracks; ++t)
+        if (!ctx->trk_fast[t]) return false;
+    return true;
 }
 
 }  // namespace ugvc

@@ -103,6 +103,9 @@ struct ugvc_ctx {
     ugvc::DeviceBuf trk_s[UGVC_MAX_TRACKS], trk_e[UGVC_MAX_TRACKS], trk_p[UGVC_MAX_TRACKS];
     int track_set[UGVC_MAX_TRACKS] = {0, 0, 0, 0, 0};
     int n_tracks = 0;
+    int64_t runs_n = 0, trk_n[UGVC_MAX_TRACKS] = {0, 0, 0, 0, 0};
+    // v3 needs: runs disjoint and sorted; tracks with non-decreasing starts AND ends per contig
+    int runs_fast = 1, trk_fast[UGVC_MAX_TRACKS] = {1, 1, 1, 1, 1};
     ugvc::DeviceBuf bl;
     int64_t n_bl = 0;
     uint8_t flow[4] = {4, 3, 2, 1};   // TGCA

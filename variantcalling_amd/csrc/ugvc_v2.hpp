@@ -26,6 +26,10 @@ constexpr int kK2Threads = 1024;
 constexpr int kLdsBudget = 150 * 1024;
 constexpr int kShards = 256;          // record lists are sharded by (block & 255): spreads the atomics
 constexpr int kCounterStride = 16;    // shard counters sit 64 bytes apart
+// v3 (kernels_v3.hip)
+constexpr int kJoin3 = UGVC_MAX_TRACKS + 2;   // searched arrays: starts of runs + 5 tracks, blacklist keys
+constexpr int kPool3 = 2048;                  // dwords of LDS for the staged side-table slices of one tile
+constexpr int kThr3 = 3584;                   // floats of LDS for the float-feature thresholds of all groups
 
 struct __attribute__((aligned(16))) FeatDesc {
     uint32_t lut;    // lut_off[0:20) | kind[30:32)   kind: 0 unused, 1 LUT(+search), 2 search only
@@ -58,6 +62,13 @@ struct V2Args {
     uint32_t* counters;           // [UGVC_N_GROUPS][kShards] x kCounterStride, zeroed every launch
     int n_blocks;
     int shard_cap;                // records per shard region
+    // v3
+    const uint2* desc3;           // [3][kMaxFeatures]: {off[0:20) | kind[30:32), len[0:16) | dword[16:18) | bit_off[18:23)}
+    int thr_bits4[4];             // descent depth of the float-feature searches (qual, sor, vaf, gc)
+    uint8_t dw3[kMaxFeatures + 2];// group-uniform dword of every feature's code
+    uint32_t boolmask3[UGVC_N_GROUPS];   // which of the seven 0/1 features (bit f-15) a group's model tests below 1
+    int32_t* brackets3;           // [(n_blocks + 1)][8]
+    int na3[8];                   // lengths of the searched arrays
 };
 
 int pack_model_group(ugvc_ctx* ctx, int g, const int32_t* feature, const float* threshold,
@@ -68,6 +79,8 @@ int finalize_pack(ugvc_ctx* ctx);
 int build_css_lut(ugvc_ctx* ctx);
 bool v2_available(ugvc_ctx* ctx);
 int launch_filter_v2(ugvc_ctx* ctx, const FilterArgs& a);
+int launch_filter_v3(ugvc_ctx* ctx, const FilterArgs& a);
+bool v3_available(ugvc_ctx* ctx);
 void v2_destroy(ugvc_ctx* ctx);
 const char* v2_reason(ugvc_ctx* ctx);
 
