@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Headline benchmark: variants/sec filtered on a 5 M-call WGS-shaped callset (BASELINE.json).
 
-One "step" = one pass of the fused featurize -> lookup -> score -> FILTER kernel over the
-whole callset (C3: 5 M SNV+indel, 3.1 Gb genome, runs + 3 annotation tracks, 1 M-locus
+One "step" = one scoring pass (featurize -> lookup -> quantise kernel, then the LDS-resident
+forest kernel; featurize -> lookup -> score -> FILTER) over the whole callset (C3: 5 M SNV+indel, 3.1 Gb genome, runs + 3 annotation tracks, 1 M-locus
 blacklist, 40-tree depth-8 forest per variant-type group), inputs already resident in HBM.
 With --gpus N > 1 (launched by torch.distributed.run, one process per GPU) the SAME callset is
 cut into N equal-count shards ("strong" scaling, BASELINE.json config C4) and every step ends
@@ -144,7 +144,9 @@ def main():
                         device=info["name"], kernel_variant=args.variant),
             roofline=dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBPS, unit="GB/s",
                           frac=achieved / HBM_PEAK_GBPS, traffic=traffic,
-                          kernel="filter_kernel<true,false>", kernel_ms=kern_ms, alg_bytes_per_variant=alg,
+                          kernel="one scoring pass = bracket3_kernel + featurize3_kernel + forest3_kernel "
+                                 "(HIP events around the three launches on the context stream)",
+                          kernel_ms=kern_ms, alg_bytes_per_variant=alg,
                           variants_per_launch=mine.n),
             parity=dict(oracle_slice_bit_exact=check, gather_consistent=ok_all),
             setup_s=round(t_setup, 1))

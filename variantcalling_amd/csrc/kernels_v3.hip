@@ -255,8 +255,9 @@ __global__ __launch_bounds__(kBlock, 4) void featurize3_kernel(const V2Args v) {
         __syncthreads();                                      // plan visible
 
         // ---- stage the slices this tile can touch: wave w copies segments w, w+4, w+8, w+12
+        const int abl = a.ablate;       // profiling only (tools/ablate3.py): 2 joins, 4 quantise, 8 window features, 16 append
         const int staged = rfl(plan.staged);
-        if (staged) {
+        if (staged && !(abl & 2)) {
             const int wave = tid >> 6;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(kBlock, 4) void featurize3_kernel(const V2Args v) {
         const int d_so = (indel && !ins) ? rl : 1;
         const int so = o0 + d_so;
         int hmer_len = 0, hmer_nuc = 0, run = 0;
-        if (indel) {
+        if (indel && !(abl & 8)) {
             const int bb = ab[0];
             bool mono = true;
 #pragma unroll
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(kBlock, 4) void featurize3_kernel(const V2Args v) {
             for (int g = 0; g < UGVC_N_GROUPS; ++g) m[g] = __ballot(mine && group == g);
             const unsigned long long mg = lane == 0 ? m[0] : (lane == 1 ? m[1] : m[2]);
             unsigned got = 0;
-            if (lane < UGVC_N_GROUPS && mg != 0)
+            if (lane < UGVC_N_GROUPS && mg != 0 && !(abl & 16))
                 got = atomicAdd(&v.counters[(lane * kShards + shard) * kCounterStride], (unsigned)__popcll(mg));
             const unsigned long long mm = group == 0 ? m[0] : (group == 1 ? m[1] : m[2]);
             grank = __popcll(mm & ((1ull << lane) - 1));
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(kBlock, 4) void featurize3_kernel(const V2Args v) {
         // ---- get_motif_around (5), gc_content (10)
         int W[11];                                            // bases at pos-5 .. pos+5
 #pragma unroll
-        for (int k = 0; k < 11; ++k) W[k] = wb[o0 - 5 + k];
+        for (int k = 0; k < 11; ++k) W[k] = (abl & 8) ? 1 + (k & 3) : wb[o0 - 5 + k];
         if (o0 < 5) {                                         // genome start: the window begins at base 0
 #pragma unroll
             for (int k = 0; k < 11; ++k) W[k] = ref_at(k - 5);
@@ -376,7 +377,10 @@ __global__ __launch_bounds__(kBlock, 4) void featurize3_kernel(const V2Args v) {
         // right motif starts at pos+1 (substitution), pos+len(ref) (non-hmer indel, also a complex
         // insertion with len(ref) > 1) or just past the run (hmer indel: pos+1+hmer_len)
         const int d_r = is_h ? d_so + run : (indel ? rl : 1);
-        if (o0 + d_r + kMotif <= kWinBytes) {
+        if (abl & 8) {
+#pragma unroll
+            for (int k = 0; k < kMotif; ++k) rmb[k] = 2;
+        } else if (o0 + d_r + kMotif <= kWinBytes) {
 #pragma unroll
             for (int k = 0; k < kMotif; ++k) rmb[k] = wb[o0 + d_r + k];
         } else {
@@ -405,7 +409,7 @@ __global__ __launch_bounds__(kBlock, 4) void featurize3_kernel(const V2Args v) {
 
         // ---- cycle skip
         int css = 3;
-        if (!indel) {
+        if (!indel && !(abl & 8)) {
             if (rl == 1) {
                 const int rb = ab[0], abase = ab[1];
                 if (motif_n || rb == 0 || abase == 0) css = 0;
@@ -439,7 +443,8 @@ __global__ __launch_bounds__(kBlock, 4) void featurize3_kernel(const V2Args v) {
         bool inside_run = false, close_run = false;
         bool trk[UGVC_MAX_TRACKS] = {false, false, false, false, false};
         const uint64_t key = ((uint64_t)c << 32) | (uint32_t)pos;
-        if (staged) {
+        if (abl & 2) {
+        } else if (staged) {
             const uint32_t pool_b = lds_addr(pool);                // LDS byte address of the pool
             uint32_t p[kJoin3], pend[kJoin3];
             int baseS[kJoin3];
@@ -458,14 +463,22 @@ __global__ __launch_bounds__(kBlock, 4) void featurize3_kernel(const V2Args v) {
                 p[t] = A + (uint32_t)(esz * (slo - bs)) - esz;        // address of element slo-1
                 pend[t] = A + (uint32_t)(esz * (shi - bs)) - esz;     // address of element shi-1
             }
+            // Levels above the shortest non-empty table's depth: only the longer tables take part
+            // (wave-uniform branches).  Below it every table steps in lock-step, all reads issued
+            // before the first compare so their LDS latencies overlap; empty/absent tables ride
+            // along as no-ops (their range test never passes).
             const int bits = rfl(plan.maxbits);
-            int tb_[kJoin3];
+            int tb_[kJoin3], common = 32;
 #pragma unroll
-            for (int t = 0; t < kJoin3; ++t) tb_[t] = rfl(plan.bits[t]);
-            for (int s = bits - 1; s >= 0; --s) {
+            for (int t = 0; t < kJoin3; ++t) {
+                tb_[t] = rfl(plan.bits[t]);
+                common = tb_[t] > 0 && tb_[t] < common ? tb_[t] : common;
+            }
+            if (common > bits) common = bits;
+            for (int s = bits - 1; s >= common; --s) {
 #pragma unroll
                 for (int t = 0; t < kJoin3 - 1; ++t) {
-                    if (s < tb_[t]) {                            // wave-uniform: short tables drop out early
+                    if (s < tb_[t]) {
                         const uint32_t cand = p[t] + (4u << s);
                         const int x = lds_i32(cand);
                         p[t] = ((int32_t)(pend[t] - cand) >= 0 && x < pos) ? cand : p[t];
@@ -477,6 +490,21 @@ __global__ __launch_bounds__(kBlock, 4) void featurize3_kernel(const V2Args v) {
                     const uint64_t x = lds_u64(cand);
                     p[t] = ((int32_t)(pend[t] - cand) >= 0 && x < key) ? cand : p[t];
                 }
+            }
+            for (int s = common - 1; s >= 0; --s) {
+                uint32_t cand[kJoin3];
+                int x[kJoin3 - 1];
+#pragma unroll
+                for (int t = 0; t < kJoin3 - 1; ++t) {
+                    cand[t] = p[t] + (4u << s);
+                    x[t] = lds_i32(cand[t]);
+                }
+                cand[kJoin3 - 1] = p[kJoin3 - 1] + (8u << s);
+                const uint64_t xk = lds_u64(cand[kJoin3 - 1]);
+#pragma unroll
+                for (int t = 0; t < kJoin3 - 1; ++t)
+                    p[t] = ((int32_t)(pend[t] - cand[t]) >= 0 && x[t] < pos) ? cand[t] : p[t];
+                p[kJoin3 - 1] = ((int32_t)(pend[kJoin3 - 1] - cand[kJoin3 - 1]) >= 0 && xk < key) ? cand[kJoin3 - 1] : p[kJoin3 - 1];
             }
 #pragma unroll
             for (int t = 0; t < kJoin3 - 1; ++t) {
@@ -568,7 +596,7 @@ __global__ __launch_bounds__(kBlock, 4) void featurize3_kernel(const V2Args v) {
             c2 |= val & (dwj == 2 ? ~0u : 0u);
         };
         const bool upper = (gbtbits >> group) & 1;
-        if (pg_ok) {
+        if (pg_ok && !(abl & 4)) {
             // float features: lock-step descent over the LDS threshold slices
             {
                 const float fx[4] = {qual, sor, vaf, gc};
@@ -583,16 +611,19 @@ __global__ __launch_bounds__(kBlock, 4) void featurize3_kernel(const V2Args v) {
                 }
                 const int fb0 = v.thr_bits4[0], fb1 = v.thr_bits4[1], fb2 = v.thr_bits4[2], fb3 = v.thr_bits4[3];
                 const int fbm = max(max(fb0, fb1), max(fb2, fb3));
+                // an empty slice (feature unused by the lane's group) never passes the range test
                 for (int s = fbm - 1; s >= 0; --s) {
+                    uint32_t cand[4];
+                    float t[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const int fb = k == 0 ? fb0 : (k == 1 ? fb1 : (k == 2 ? fb2 : fb3));
-                        if (s < fb) {
-                            const uint32_t cand = q[k] + (4u << s);
-                            const float t = lds_f32(cand);
-                            const bool lt = upper ? t <= fx[k] : t < fx[k];
-                            q[k] = ((int32_t)(qend[k] - cand) >= 0 && lt) ? cand : q[k];
-                        }
+                        cand[k] = q[k] + (4u << s);
+                        t[k] = lds_f32(cand[k]);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const bool lt = upper ? t[k] <= fx[k] : t[k] < fx[k];
+                        q[k] = ((int32_t)(qend[k] - cand[k]) >= 0 && lt) ? cand[k] : q[k];
                     }
                 }
 #pragma unroll
@@ -669,7 +700,7 @@ __global__ __launch_bounds__(kBlock, 4) void featurize3_kernel(const V2Args v) {
             const unsigned b0 = __shfl(slot_base, 0), b1 = __shfl(slot_base, 1), b2 = __shfl(slot_base, 2);
             const unsigned sb = group == 0 ? b0 : (group == 1 ? b1 : b2);
             const int shard = tile & (kShards - 1);
-            if (mine)
+            if (mine && !(abl & 16))
                 v.records[group][(size_t)shard * v.shard_cap + sb + grank] = make_uint4(c0, c1, c2, (uint32_t)i);
         }
         __syncthreads();                                      // plan / pool are rewritten by the next tile
@@ -883,7 +914,7 @@ int launch_filter_v3(ugvc_ctx* ctx, const FilterArgs& a) {
         if (need + 2048 <= 160 * 1024) { n_waves = w; lds = need; break; }
     }
     if (n_waves == 0) return fail("internal: packed forest does not fit LDS");
-    if (lds) {
+    if (lds && !(a.ablate & 1)) {
         static bool attr_set = false;
         if (!attr_set) {
             UGVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(forest3_kernel),
