@@ -1,0 +1,103 @@
+"""GPU end-to-end tests of the drop-in tools (config C1: a chr20-shaped 50 k-variant VCF through
+filter_variants_pipeline with a pre-trained model; and train_models_pipeline -> filter_variants_pipeline)."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from variantcalling_amd import model_io, schema as S, synth
+from variantcalling_amd.io import bed, fasta, vcf as vcfio
+
+pytestmark = pytest.mark.gpu
+RF = "rf_model_ignore_gt_incl_hpol_runs"
+
+
+def _write_inputs(tmp_path, cs, ids=None, gz=True):
+    d = {}
+    d["fa"] = str(tmp_path / "ref.fa"); fasta.write_fasta(d["fa"], cs.ref)
+    d["vcf"] = str(tmp_path / ("calls.vcf.gz" if gz else "calls.vcf"))
+    vcfio.write_vcf_from_table(d["vcf"], cs.variants, cs.ref.names, ids=ids)
+    d["runs"] = str(tmp_path / "runs.bed"); bed.write_bed(d["runs"], cs.runs, cs.ref.names)
+    d["ann"] = []
+    for t, tr in zip(("LCR-hs38", "exome.twist", "mappability.0"), cs.tracks):
+        p = str(tmp_path / f"{t}.bed"); bed.write_bed(p, tr, cs.ref.names); d["ann"] += ["--annotate_intervals", p]
+    d["bl"] = str(tmp_path / "blacklist.npy"); np.save(d["bl"], cs.blacklist)
+    return d
+
+
+def _parse_out(path, n):
+    op = gzip.open if path.endswith(".gz") else open
+    recs = [x.split("\t") for x in op(path, "rt").read().splitlines() if not x.startswith("#")]
+    assert len(recs) == n
+    score = np.array([np.float32(dict(kv.split("=") for kv in r[7].split(";") if "=" in kv)["TREE_SCORE"]) for r in recs])
+    tags = [set(r[6].split(";")) for r in recs]
+    return score, tags
+
+
+def test_c1_filter_variants_pipeline_chr20_50k(tmp_path, frozen_models):
+    from oracle import oracle as O
+    from variantcalling_amd.pipelines import filter_variants_pipeline
+    cs = synth.make_callset(50_000, genome_len=64_444_167, n_contigs=1, seed=20)      # one chr20-sized contig
+    cs.genome.ref.names[:] = ["chr20"]
+    d = _write_inputs(tmp_path, cs)
+    out = str(tmp_path / "filtered.vcf.gz")
+    rc = filter_variants_pipeline.run(["filter_variants_pipeline", "--input_file", d["vcf"], "--model_file",
+                                       os.path.join(GOLDEN, "synth_rf_v1.npz"), "--model_name", RF, "--runs_file", d["runs"],
+                                       "--hpol_filter_length_dist", "10", "10", "--blacklist", d["bl"], "--reference_file",
+                                       d["fa"], "--flow_order", "TGCA", "--output_file", out] + d["ann"])
+    assert rc == 0
+    exp = O.filter_variants(cs.variants, cs.ref, cs.runs, cs.tracks, cs.blacklist, frozen_models[RF])
+    score, tags = _parse_out(out, cs.variants.n)
+    assert np.array_equal(score, exp.tree_score)
+    low = np.array(["LOW_SCORE" in t for t in tags]); hp = np.array(["HPOL_RUN" in t for t in tags])
+    fp = np.array(["COHORT_FP" in t for t in tags]); ps = np.array([t == {"PASS"} for t in tags])
+    assert np.array_equal(low, exp.filter == S.FILTER_LOW_SCORE)
+    assert np.array_equal(hp, (exp.flags & S.FLAG_HPOL_RUN) > 0) and np.array_equal(fp, (exp.flags & S.FLAG_COHORT_FP) > 0)
+    assert np.array_equal(ps, (exp.filter == 0) & (exp.flags & 3 == 0))
+    assert 0.2 < ps.mean() < 0.8 and fp.sum() > 0 and hp.sum() > 0
+
+
+def test_train_then_filter(tmp_path):
+    """Approximate-ground-truth training (dbSNP id => TP, blacklist => FP) on the GPU feature matrix, then the
+    trained pickle drives filter_variants_pipeline; the result equals the oracle evaluated with the same
+    scikit-learn estimators."""
+    import pickle
+
+    from oracle import oracle as O
+    from variantcalling_amd.pipelines import filter_variants_pipeline, train_models_pipeline
+    cs = synth.make_callset(30_000, genome_len=20_000_000, n_contigs=2, seed=33)
+    rng = np.random.default_rng(3)
+    # labels correlated with qual so the forests have something to learn
+    is_tp = (cs.variants.qual + rng.normal(0, 25, cs.variants.n)) > 45
+    bl = np.unique(cs.variants.keys()[~is_tp & (rng.random(cs.variants.n) < 0.8)])
+    cs.blacklist = bl
+    d = _write_inputs(tmp_path, cs, ids=is_tp & (rng.random(cs.variants.n) < 0.8), gz=False)
+    prefix = str(tmp_path / "test.model")
+    rc = train_models_pipeline.run(["train_models_pipeline", "--input_file", d["vcf"], "--reference", d["fa"],
+                                    "--runs_intervals", d["runs"], "--blacklist", d["bl"], "--flow_order", "TGCA",
+                                    "--exome_weight", "100", "--exome_weight_annotation", "exome.twist",
+                                    "--output_file_prefix", prefix, "--evaluate_concordance"] + d["ann"])
+    assert rc == 0
+    models = pickle.load(open(prefix + ".pkl", "rb"))
+    assert set(models) == {"rf_model_ignore_gt_incl_hpol_runs", "dt_model_ignore_gt_incl_hpol_runs",
+                           "rf_model_ignore_gt_excl_hpol_runs", "dt_model_ignore_gt_excl_hpol_runs"}
+    rows = [x.split(";") for x in open(prefix + ".stats.csv").read().splitlines()]
+    assert rows[0][0] == "group" and rows[1][0] == "SNP" and float(rows[1][6]) > 0.7      # SNP f1 after filtering
+    res = np.load(prefix + ".results.npz")
+    ft = O.featurize(cs.variants, cs.ref, cs.runs, cs.tracks)
+    assert np.array_equal(res["X"], ft["X"]) and np.array_equal(res["group"], ft["group"].astype(np.uint8))
+    for name in ("dt_model_ignore_gt_excl_hpol_runs", "rf_model_ignore_gt_incl_hpol_runs"):
+        out = str(tmp_path / f"{name}.vcf")
+        filter_variants_pipeline.run(["filter_variants_pipeline", "--input_file", d["vcf"], "--model_file", prefix + ".pkl",
+                                      "--model_name", name, "--runs_file", d["runs"], "--blacklist", d["bl"],
+                                      "--reference_file", d["fa"], "--output_file", out] + d["ann"])
+        forests = [model_io.flatten_sklearn(models[name][g]) if g in models[name] else None for g in S.GROUP_NAMES]
+        exp = O.filter_variants(cs.variants, cs.ref, cs.runs, cs.tracks, bl, forests)
+        score, tags = _parse_out(out, cs.variants.n)
+        assert np.array_equal(score, exp.tree_score)
+        assert np.array_equal(np.array(["LOW_SCORE" in t for t in tags]), exp.filter == 1)
+        # and against scikit-learn itself
+        g0 = ft["group"] == 0
+        assert np.array_equal(exp.tree_score[g0], models[name]["snp"].predict_proba(ft["X"][g0])[:, 1].astype(np.float32))

@@ -1,0 +1,216 @@
+"""VCF <-> SoA `schema.VariantTable` and FILTER/INFO write-back (host logic, pure Python + numpy).
+
+Replaces the two per-record pysam loops that bracket the hot path in the reference:
+  * read: `ugbio_core.vcfbed.vcftools.get_vcf_df` - per record INFO + first sample's FORMAT + QUAL,
+    CHROM, POS, REF, ALLELES, FILTER (call sites ugvc/pipelines/run_no_gt_report.py:307-312; shape quoted
+    in ugvc/reports/report_wo_gt.ipynb:1207-1210).  Only the fields the model features need are kept:
+    QUAL, INFO/SOR (INFO/TLOD for mutect), FORMAT/DP, AD, GQ, GT (field dictionary:
+    test/resources/unit/vcfbed/test_vcftools/header.txt:3369-3398).
+  * write: header lines + per record `LOW_SCORE|PASS`, `TREE_SCORE`, `HPOL_RUN`, `COHORT_FP`
+    (docs/howto-callset-filter.md:65; ugvc/pipelines/evaluate_concordance.py:47), same order as the input;
+    the in-tree example of the write pattern is ugvc/pipelines/vcfbed/calibrate_bridging_snvs.py:101-130.
+Multi-allelic records are featurised on their first ALT allele (BUILDER-DEFINED).  Output `.gz` files are
+BGZF (htslib-compatible blocks + EOF marker); no tabix index is written (the GPU
+codec is the next row, this is the host reference for it)."""
+from __future__ import annotations
+
+import gzip
+import struct
+import zlib
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from .. import schema as S
+
+NEW_HEADER = [
+    '##FILTER=<ID=LOW_SCORE,Description="Low decision tree score">',
+    '##FILTER=<ID=HPOL_RUN,Description="Homopolymer run">',
+    '##FILTER=<ID=COHORT_FP,Description="Common false positive in the cohort (blacklist)">',
+    '##INFO=<ID=TREE_SCORE,Number=1,Type=Float,Description="Filtering score">',
+    '##INFO=<ID=HPOL_RUN,Number=0,Type=Flag,Description="In or close to homopolymer run">',
+]
+
+
+@dataclass
+class VcfFile:
+    header: list                    # header lines without newline, including #CHROM
+    records: list                   # raw record lines (bytes), file order
+    table: S.VariantTable           # sorted by (contig, pos)
+    order: np.ndarray               # table row k came from records[order[k]]
+    ids: np.ndarray = field(default_factory=lambda: np.zeros(0, bool))    # ID column != '.', table order
+    orig_filter: list = field(default_factory=list)
+    tlod: np.ndarray | None = None
+
+
+def _open(path: str):
+    with open(path, "rb") as fh:
+        magic = fh.read(2)
+    return gzip.open(path, "rb") if magic == b"\x1f\x8b" else open(path, "rb")
+
+
+def _fnum(x: bytes, default=0.0) -> float:
+    try:
+        return float(x)
+    except ValueError:
+        return default
+
+
+def read_vcf(path: str, contig_names: list, is_mutect: bool = False, sample: int = 0) -> VcfFile:
+    idx = {n.encode(): i for i, n in enumerate(contig_names)}
+    header, records = [], []
+    with _open(path) as fh:
+        for line in fh:
+            if line.startswith(b"#"):
+                header.append(line.rstrip(b"\r\n").decode())
+            elif line.strip():
+                records.append(line.rstrip(b"\r\n"))
+    n = len(records)
+    contig = np.zeros(n, np.uint8); pos = np.zeros(n, np.int32)
+    qual = np.zeros(n, np.float32); sor = np.zeros(n, np.float32)
+    dp = np.zeros(n, np.int32); adr = np.zeros(n, np.int32); ada = np.zeros(n, np.int32)
+    gq = np.zeros(n, np.uint8); gt = np.zeros(n, np.uint8)
+    tlod = np.zeros(n, np.float32)
+    has_id = np.zeros(n, bool)
+    refs, alts, flt = [], [], []
+    for k, line in enumerate(records):
+        f = line.split(b"\t")
+        if len(f) < 8:
+            raise ValueError(f"{path}: record {k + 1} has {len(f)} columns")
+        if f[0] not in idx:
+            raise ValueError(f"{path}: contig {f[0].decode()!r} is not in the reference")
+        contig[k] = idx[f[0]]
+        pos[k] = int(f[1])
+        has_id[k] = f[2] != b"."
+        refs.append(f[3])
+        alts.append(f[4].split(b",")[0])
+        qual[k] = _fnum(f[5])
+        flt.append(f[6].decode())
+        for kv in f[7].split(b";"):
+            if kv.startswith(b"SOR="):
+                sor[k] = _fnum(kv[4:])
+            elif kv.startswith(b"TLOD="):
+                tlod[k] = max(_fnum(x) for x in kv[5:].split(b","))
+        if len(f) > 9 + sample - 0 and len(f) > 9:
+            keys = f[8].split(b":")
+            vals = f[9 + sample].split(b":")
+            for key, val in zip(keys, vals):
+                if key == b"DP":
+                    dp[k] = int(_fnum(val))
+                elif key == b"AD":
+                    a = val.split(b",")
+                    adr[k] = int(_fnum(a[0]))
+                    ada[k] = int(_fnum(a[1])) if len(a) > 1 else 0
+                elif key == b"GQ":
+                    gq[k] = min(255, max(0, int(_fnum(val))))
+                elif key == b"GT":
+                    g = val.replace(b"|", b"/").split(b"/")
+                    gt[k] = 2 if g == [b"1", b"1"] else (1 if b"1" in g else 0)
+    if is_mutect:
+        qual = (10.0 * tlod).astype(np.float32)          # qual := 10 * max(TLOD)
+    order = np.lexsort((np.arange(n), pos, contig)).astype(np.int64) if n else np.zeros(0, np.int64)
+    rl = np.array([len(refs[j]) for j in order], np.uint16)
+    al = np.array([len(alts[j]) for j in order], np.uint16)
+    tot = rl.astype(np.int64) + al
+    off = np.concatenate([[0], np.cumsum(tot)])
+    pool = np.frombuffer(b"".join(refs[j] + alts[j] for j in order), dtype=np.uint8) if n else np.zeros(0, np.uint8)
+    table = S.VariantTable(
+        contig=contig[order], pos=pos[order], ref_len=rl, alt_len=al,
+        ref_off=off[:-1].astype(np.uint32), alt_off=(off[:-1] + rl).astype(np.uint32),
+        alleles=S._ASCII_TO_CODE[pool], qual=np.ascontiguousarray(qual[order]), sor=np.ascontiguousarray(sor[order]),
+        dp=dp[order], ad_ref=adr[order], ad_alt=ada[order], gq=gq[order], gt=gt[order])
+    table.validate()
+    return VcfFile(header, records, table, order, has_id[order], [flt[j] for j in order],
+                   tlod[order] if is_mutect else None)
+
+
+# ------------------------------------------------------------------------------------------ BGZF
+_BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+def _bgzf_block(data: bytes) -> bytes:
+    comp = zlib.compressobj(6, zlib.DEFLATED, -15)
+    body = comp.compress(data) + comp.flush()
+    bsize = len(body) + 25
+    return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize) + body +
+            struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data) & 0xFFFFFFFF))
+
+
+class _BgzfWriter:
+    def __init__(self, path):
+        self.fh = open(path, "wb")
+        self.buf = bytearray()
+
+    def write(self, b: bytes):
+        self.buf += b
+        while len(self.buf) >= 65280:
+            self.fh.write(_bgzf_block(bytes(self.buf[:65280])))
+            del self.buf[:65280]
+
+    def close(self):
+        if self.buf:
+            self.fh.write(_bgzf_block(bytes(self.buf)))
+        self.fh.write(_BGZF_EOF)
+        self.fh.close()
+
+
+def write_filtered_vcf(path: str, vcf: VcfFile, res: S.FilterResult, blacklist_cg: np.ndarray | None = None) -> None:
+    """Input records in their original order with the new FILTER value and INFO tags."""
+    out = _BgzfWriter(path) if path.endswith(".gz") else open(path, "wb")
+    have = set(vcf.header)
+    hdr = [h for h in vcf.header if not h.startswith("#CHROM")]
+    for h in NEW_HEADER:
+        key = h.split(",")[0]
+        if not any(x.startswith(key) for x in have):
+            hdr.append(h)
+    hdr += [h for h in vcf.header if h.startswith("#CHROM")]
+    out.write(("\n".join(hdr) + "\n").encode())
+    n = len(vcf.records)
+    row_of = np.empty(n, dtype=np.int64)
+    row_of[vcf.order] = np.arange(n)
+    for j, line in enumerate(vcf.records):
+        k = int(row_of[j])
+        f = line.split(b"\t")
+        tags = []
+        fl = int(res.flags[k])
+        if fl & S.FLAG_HPOL_RUN:
+            tags.append("HPOL_RUN")
+        if fl & S.FLAG_COHORT_FP or (blacklist_cg is not None and blacklist_cg[k]):
+            tags.append("COHORT_FP")
+        if res.filter[k] == S.FILTER_LOW_SCORE:
+            tags.append("LOW_SCORE")
+        f[6] = (";".join(tags) if tags else "PASS").encode()
+        info = [] if f[7] in (b".", b"") else [x for x in f[7].split(b";")
+                                               if not x.startswith(b"TREE_SCORE=") and x != b"HPOL_RUN"]
+        info.append(b"TREE_SCORE=" + np.format_float_positional(res.tree_score[k], unique=True, trim="0").encode())
+        if fl & S.FLAG_HPOL_RUN:
+            info.append(b"HPOL_RUN")
+        f[7] = b";".join(info)
+        out.write(b"\t".join(f) + b"\n")
+    out.close()
+
+
+def write_vcf_from_table(path: str, vt: S.VariantTable, contig_names: list, sample: str = "sample",
+                         ids: np.ndarray | None = None) -> None:
+    """Minimal single-sample VCF of a variant table (fixtures, synthetic C1 input)."""
+    out = _BgzfWriter(path) if path.endswith(".gz") else open(path, "wb")
+    hdr = ["##fileformat=VCFv4.2", '##INFO=<ID=SOR,Number=1,Type=Float,Description="Symmetric Odds Ratio">',
+           '##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">',
+           '##FORMAT=<ID=AD,Number=R,Type=Integer,Description="Allelic depths">',
+           '##FORMAT=<ID=DP,Number=1,Type=Integer,Description="Read depth">',
+           '##FORMAT=<ID=GQ,Number=1,Type=Integer,Description="Genotype quality">']
+    hdr += [f"##contig=<ID={n}>" for n in contig_names]
+    hdr.append("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + sample)
+    out.write(("\n".join(hdr) + "\n").encode())
+    table = np.frombuffer(S.CODE_TO_CHAR.encode(), dtype=np.uint8)
+    txt = table[vt.alleles].tobytes()
+    for i in range(vt.n):
+        r = txt[vt.ref_off[i]: vt.ref_off[i] + vt.ref_len[i]]
+        a = txt[vt.alt_off[i]: vt.alt_off[i] + vt.alt_len[i]]
+        gt = "1/1" if vt.gt[i] == 2 else ("0/1" if vt.gt[i] == 1 else "0/0")
+        vid = f"rs{i}" if ids is not None and ids[i] else "."
+        out.write(("\t".join([contig_names[int(vt.contig[i])], str(int(vt.pos[i])), vid, r.decode(), a.decode(),
+                              repr(float(vt.qual[i])), ".", f"SOR={float(vt.sor[i])!r}", "GT:AD:DP:GQ",
+                              f"{gt}:{int(vt.ad_ref[i])},{int(vt.ad_alt[i])}:{int(vt.dp[i])}:{int(vt.gq[i])}"])
+                   + "\n").encode())
+    out.close()

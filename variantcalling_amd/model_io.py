@@ -185,10 +185,10 @@ def load_model_file(path: str, model_name: str | None = None):
         models = {}
         for name, m in (raw.items() if isinstance(raw, dict) else [("model", raw)]):
             if isinstance(m, dict):
-                m = [m[g] for g in S.GROUP_NAMES]
+                m = [m.get(g) for g in S.GROUP_NAMES]       # a group without a model scores 0 / PASS
             if not isinstance(m, (list, tuple)):
                 m = [m] * S.N_GROUPS
-            models[name] = [x if isinstance(x, S.FlatForest) else flatten_sklearn(x) for x in m]
+            models[name] = [x if x is None or isinstance(x, S.FlatForest) else flatten_sklearn(x) for x in m]
     if model_name is None:
         return models
     if model_name not in models:

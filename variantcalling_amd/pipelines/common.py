@@ -1,0 +1,49 @@
+"""Shared host plumbing of the two pipelines: load the side files named on the command line and
+configure one GPU context.  Host logic only; the compute is `engine.Engine` (libugvc_mi355x.so)."""
+from __future__ import annotations
+
+import logging
+
+import numpy as np
+
+from .. import schema as S
+from ..io import bed, fasta
+
+logger = logging.getLogger("ugvc")
+
+
+def load_side_tables(reference_file, runs_file, annotate_intervals, blacklist_file):
+    ref = fasta.read_fasta(reference_file)
+    if ref.n_contigs > 255:
+        # the contig column is u8: keep the primary contigs, as the reference's own
+        # per-contig keys do (HDF5 keyed per chromosome, docs/train_models_pipeline.md:58-59)
+        keep = ref.names[:255]
+        logger.warning("reference has %d contigs; using the first 255", ref.n_contigs)
+        ref = fasta.read_fasta(reference_file, contigs=keep)
+    # homopolymer runs are disjoint by nature; book-ended runs of different bases must stay separate
+    runs = bed.read_intervals(runs_file, ref.names, merge=False) if runs_file else None
+    tracks = [bed.read_intervals(p, ref.names, merge=True) for p in (annotate_intervals or [])]
+    if len(tracks) > S.MAX_TRACKS:
+        raise ValueError(f"at most {S.MAX_TRACKS} --annotate_intervals files are supported")
+    bl = bed.read_blacklist(blacklist_file, ref.names) if blacklist_file else None
+    return ref, runs, tracks, bl
+
+
+def cg_insertion_mask(vt: S.VariantTable) -> np.ndarray:
+    """`--blacklist_cg_insertions` "Should CCG/GGC insertions be filtered out?"
+    (docs/filter_variants_pipeline.md:36-37).  BUILDER-DEFINED reading (the body is in the absent
+    submodule): an insertion whose inserted bases are exactly CCG or GGC."""
+    out = np.zeros(vt.n, dtype=bool)
+    ins = np.flatnonzero((vt.alt_len == vt.ref_len + 3) & (vt.ref_len == 1))
+    ccg, ggc = S.encode_bases("CCG"), S.encode_bases("GGC")
+    for i in ins:
+        tail = vt.alleles[vt.alt_off[i] + 1: vt.alt_off[i] + 4]
+        out[i] = bool(np.array_equal(tail, ccg) or np.array_equal(tail, ggc))
+    return out
+
+
+def check_model_tracks(forests, n_tracks: int, tool: str):
+    want = max((f.n_features for f in forests if f is not None), default=S.N_BASE_FEATURES)
+    if want > S.N_BASE_FEATURES + n_tracks:
+        raise ValueError(f"{tool}: the model was trained with {want - S.N_BASE_FEATURES} annotation track(s) "
+                         f"(--annotate_intervals), {n_tracks} given")

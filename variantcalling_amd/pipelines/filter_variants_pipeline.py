@@ -1,0 +1,66 @@
+"""filter_variants_pipeline: apply a trained filtering model to a raw callset VCF on an MI355X.
+
+Drop-in for `ugbio_filtering.filter_variants_pipeline.run(argv)` (registered at
+/root/reference/ugvc/__main__.py:18,47; script setup.py:42), flags exactly as documented in
+docs/filter_variants_pipeline.md:9-46.  VCF -> SoA columns -> ONE call into libugvc_mi355x.so
+(featurize, interval / blacklist lookup, per-variant-type model score, FILTER) -> VCF with
+PASS|LOW_SCORE, TREE_SCORE, HPOL_RUN, COHORT_FP (docs/howto-callset-filter.md:61-65)."""
+from __future__ import annotations
+
+import argparse
+import logging
+import sys
+
+from .. import model_io
+from ..io import vcf as vcfio
+from . import common
+
+logger = logging.getLogger("ugvc")
+
+
+def get_parser() -> argparse.ArgumentParser:
+    ap = argparse.ArgumentParser(prog="filter_variants_pipeline.py", description="Filter VCF")
+    ap.add_argument("--input_file", help="Name of the input VCF file", type=str, required=True)
+    ap.add_argument("--model_file", help="Pickle model file", type=str, required=True)
+    ap.add_argument("--model_name", help="Model file", type=str, required=True)
+    ap.add_argument("--hpol_filter_length_dist", nargs=2, type=int, help="Length and distance to the hpol run to mark",
+                    default=[10, 10])
+    ap.add_argument("--runs_file", help="Homopolymer runs file", type=str, required=True)
+    ap.add_argument("--blacklist", help="Blacklist file", type=str, required=False)
+    ap.add_argument("--blacklist_cg_insertions", help="Should CCG/GGC insertions be filtered out?", action="store_true")
+    ap.add_argument("--reference_file", help="Indexed reference FASTA file", type=str, required=True)
+    ap.add_argument("--output_file", help="Output VCF file", type=str, required=True)
+    ap.add_argument("--is_mutect", help="Is the input a result of mutect", action="store_true")
+    ap.add_argument("--flow_order", help="Sequencing flow order (4 cycle)", type=str, default="TGCA")
+    ap.add_argument("--annotate_intervals", help="interval files for annotation (multiple possible)", type=str,
+                    action="append", default=[])
+    ap.add_argument("--device", help="GPU index (MI355X)", type=int, default=0)
+    return ap
+
+
+def run(argv: list[str]):
+    """Filter VCF"""
+    args = get_parser().parse_args(argv[1:])
+    from ..engine import Engine, configure     # fails loudly if the library or the GPU is missing
+
+    logger.info("reading side tables")
+    ref, runs, tracks, bl = common.load_side_tables(args.reference_file, args.runs_file, args.annotate_intervals,
+                                                    args.blacklist)
+    forests = model_io.load_model_file(args.model_file, args.model_name)
+    common.check_model_tracks(forests, len(tracks), "filter_variants_pipeline")
+    logger.info("reading %s", args.input_file)
+    vcf = vcfio.read_vcf(args.input_file, ref.names, is_mutect=args.is_mutect)
+    hp_len, hp_dist = args.hpol_filter_length_dist
+    with Engine(args.device) as eng:
+        configure(eng, ref, runs, tracks, bl, forests, args.flow_order, hp_len, hp_dist, True)
+        res = eng.filter_variants(vcf.table)
+    cg = common.cg_insertion_mask(vcf.table) if args.blacklist_cg_insertions else None
+    logger.info("writing %s", args.output_file)
+    vcfio.write_filtered_vcf(args.output_file, vcf, res, cg)
+    n_pass = int(((res.filter == 0) & (res.flags & 3 == 0)).sum())
+    logger.info("%d variants, %d PASS", vcf.table.n, n_pass)
+    return 0
+
+
+if __name__ == "__main__":
+    run(sys.argv)

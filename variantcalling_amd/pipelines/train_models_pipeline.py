@@ -1,0 +1,168 @@
+"""train_models_pipeline: train per-variant-type filtering models; features and evaluation on an MI355X.
+
+Drop-in for `ugbio_filtering.train_models_pipeline.run(argv)` (registered at
+/root/reference/ugvc/__main__.py:18,48; script setup.py:41), flags exactly as documented in
+docs/train_models_pipeline.md:17-81.  Two modes (docs :5-10): approximate ground truth from a call VCF
+(dbSNP id => true positive, `--blacklist` member => false positive) or exact labels.  The N x F feature
+matrix is built on the GPU (`ugvc_feature_matrix`); fitting is scikit-learn on the host as in the reference
+(random forest / decision tree, one model per variant-type group, exome re-weighting docs :66-72); the
+optional `--evaluate_concordance` pass scores on the GPU.
+Deviations forced by this environment (no pytables/h5py): exact-label input is an `.npz` dump of the SoA
+table with a `label` column instead of the comparison HDF5, and the results table is written as
+`PREFIX.results.npz` + `PREFIX.stats.csv` instead of `PREFIX.h5`."""
+from __future__ import annotations
+
+import argparse
+import csv
+import logging
+import pickle
+import sys
+
+import numpy as np
+
+from .. import evaluate, model_io, schema as S
+from ..io import vcf as vcfio
+from . import common
+
+logger = logging.getLogger("ugvc")
+N_TREES, MAX_DEPTH = 40, 8
+
+
+def get_parser() -> argparse.ArgumentParser:
+    ap = argparse.ArgumentParser(prog="train_models_pipeline.py", description="Train filtering models on the concordance file")
+    ap.add_argument("--input_file", help="Name of the input h5/vcf file. h5 is output of comparison", type=str)
+    ap.add_argument("--blacklist", help="blacklist file by which we decide variants as FP", type=str)
+    ap.add_argument("--output_file_prefix", help="Output .pkl file with models, .h5 file with results", type=str, required=True)
+    ap.add_argument("--mutect", action="store_true")
+    ap.add_argument("--evaluate_concordance", help="Should the results of the model be applied to the concordance dataframe",
+                    action="store_true")
+    ap.add_argument("--apply_model", help="If evaluate_concordance - which model should be applied", type=str)
+    ap.add_argument("--evaluate_concordance_contig", help="Which contig the evaluation of the model should be done on", type=str)
+    ap.add_argument("--input_interval", help="bed file of intersected intervals from run_comparison pipeline", type=str)
+    ap.add_argument("--list_of_contigs_to_read", nargs="*", help="List of contigs to read from the DF", default=[])
+    ap.add_argument("--reference", help="Reference genome", type=str, required=True)
+    ap.add_argument("--runs_intervals", help="Runs intervals (bed/interval_list)", type=str)
+    ap.add_argument("--annotate_intervals", help="interval files for annotation (multiple possible)", type=str,
+                    action="append", default=[])
+    ap.add_argument("--exome_weight", help="weight of exome variants in comparison to whole genome variant", type=int, default=1)
+    ap.add_argument("--flow_order", help="Sequencing flow order (4 cycle)", type=str, default="TGCA")
+    ap.add_argument("--exome_weight_annotation", help="annotation name by which we decide the weight of exome variants", type=str)
+    ap.add_argument("--vcf_type", help='VCF type - "single_sample" or "joint"', type=str, default="single_sample")
+    ap.add_argument("--ignore_filter_status", help="Ignore the `filter` and `tree_score` columns", action="store_true")
+    ap.add_argument("--verbosity", help="Verbosity: ERROR, WARNING, INFO, DEBUG", default="INFO")
+    ap.add_argument("--device", help="GPU index (MI355X)", type=int, default=0)
+    return ap
+
+
+def _read_labelled(args, ref, bl):
+    """-> (VariantTable, label i8: 1 tp / 0 fp / -1 unlabelled)."""
+    if args.input_file.endswith(".npz"):
+        z = np.load(args.input_file)
+        vt = S.VariantTable(**{c: np.ascontiguousarray(z[c]) for c in S.VariantTable.COLS}, alleles=z["alleles"])
+        vt.validate()
+        return vt, z["label"].astype(np.int8)
+    vcf = vcfio.read_vcf(args.input_file, ref.names, is_mutect=args.mutect)
+    vt = vcf.table
+    label = np.full(vt.n, -1, dtype=np.int8)
+    label[vcf.ids] = 1                                    # dbSNP => TP   (docs/train_models_pipeline.md:8-10)
+    if bl is not None and bl.size:
+        k = vt.keys()
+        i = np.minimum(np.searchsorted(bl, k), bl.size - 1)
+        label[bl[i] == k] = 0                             # blacklist => FP
+    return vt, label
+
+
+def fit_models(X, group, label, weights, hpol_flag):
+    from sklearn.ensemble import RandomForestClassifier
+    from sklearn.tree import DecisionTreeClassifier
+    models = {}
+    for incl in (True, False):
+        use = (label >= 0) & (incl | ~hpol_flag)
+        suffix = "ignore_gt_" + ("incl" if incl else "excl") + "_hpol_runs"
+        rf, dt = {}, {}
+        for g, gname in enumerate(S.GROUP_NAMES):
+            m = use & (group == g)
+            if m.sum() < 2 or np.unique(label[m]).size < 2:
+                logger.warning("group %s (%s): not enough labelled variants of both classes, no model", gname, suffix)
+                continue
+            rf[gname] = RandomForestClassifier(n_estimators=N_TREES, max_depth=MAX_DEPTH, random_state=g, n_jobs=-1).fit(
+                X[m], label[m], sample_weight=weights[m])
+            dt[gname] = DecisionTreeClassifier(max_depth=MAX_DEPTH, random_state=g).fit(X[m], label[m], sample_weight=weights[m])
+        models["rf_model_" + suffix] = rf
+        models["dt_model_" + suffix] = dt
+    return models
+
+
+def _flatten(model: dict):
+    return [model_io.flatten_sklearn(model[g]) if g in model else None for g in S.GROUP_NAMES]
+
+
+def run(argv: list[str]):
+    """Train filtering models on the concordance file"""
+    args = get_parser().parse_args(argv[1:])
+    logger.setLevel(getattr(logging, str(args.verbosity).upper(), logging.INFO))
+    if not args.input_file:
+        raise ValueError("--input_file is required")
+    from ..engine import Engine, configure     # fails loudly if the library or the GPU is missing
+
+    ref, runs, tracks, bl = common.load_side_tables(args.reference, args.runs_intervals, args.annotate_intervals, args.blacklist)
+    vt, label = _read_labelled(args, ref, bl)
+    if args.list_of_contigs_to_read:
+        keep = np.isin(vt.contig, [ref.names.index(c) for c in args.list_of_contigs_to_read if c in ref.names])
+        rows = np.flatnonzero(keep)
+        if rows.size and rows.size < vt.n:
+            parts = [vt.slice(int(a), int(b) + 1) for a, b in zip(rows[np.r_[True, np.diff(rows) > 1]],
+                                                                  rows[np.r_[np.diff(rows) > 1, True]])]
+            vt = parts[0] if len(parts) == 1 else _concat(parts)
+            label = label[rows]
+    with Engine(args.device) as eng:
+        configure(eng, ref, runs, tracks, None, [None] * S.N_GROUPS, args.flow_order, 10, 10, True)
+        X, group = eng.feature_matrix(vt)                  # N x F on the GPU
+        names = S.feature_names(len(tracks))
+        weights = np.ones(vt.n)
+        if args.exome_weight != 1 and args.exome_weight_annotation:
+            stems = [t.name for t in tracks]
+            if args.exome_weight_annotation not in stems:
+                raise ValueError(f"--exome_weight_annotation {args.exome_weight_annotation!r} is not one of {stems}")
+            weights[X[:, S.N_BASE_FEATURES + stems.index(args.exome_weight_annotation)] > 0] = args.exome_weight
+        hpol = (X[:, names.index("inside_hmer_run")] > 0) | (X[:, names.index("close_to_hmer_run")] > 0)
+        logger.info("fitting on %d labelled of %d variants", int((label >= 0).sum()), vt.n)
+        models = fit_models(X, group, label, weights, hpol)
+        with open(args.output_file_prefix + ".pkl", "wb") as fh:
+            pickle.dump(models, fh)
+        flat = {k: _flatten(v) for k, v in models.items() if len(v) == S.N_GROUPS}
+        if flat:
+            model_io.save_models(args.output_file_prefix + ".npz", flat, meta=dict(features=list(names)))
+        np.savez_compressed(args.output_file_prefix + ".results.npz", X=X, group=group, label=label,
+                            contig=vt.contig, pos=vt.pos)
+        if args.evaluate_concordance:
+            name = args.apply_model or "rf_model_ignore_gt_incl_hpol_runs"
+            if name not in models:
+                raise KeyError(f"--apply_model {name!r}; trained: {sorted(models)}")
+            eng.set_models(_flatten(models[name]))
+            eng.set_blacklist(bl)
+            res = eng.filter_variants(vt)
+            sel = label >= 0
+            if args.evaluate_concordance_contig and args.evaluate_concordance_contig in ref.names:
+                sel &= vt.contig == ref.names.index(args.evaluate_concordance_contig)
+            rows = evaluate.accuracy_table(res.tree_score[sel], res.filter[sel] == S.FILTER_PASS, label[sel] == 1,
+                                           group[sel] != S.GROUP_SNP, X[sel, names.index("hmer_indel_length")])
+            with open(args.output_file_prefix + ".stats.csv", "w", newline="") as fh:
+                w = csv.DictWriter(fh, fieldnames=list(rows[0]), delimiter=";")
+                w.writeheader()
+                w.writerows(rows)
+            np.savez_compressed(args.output_file_prefix + ".scored.npz", tree_score=res.tree_score, filter=res.filter,
+                                flags=res.flags, label=label)
+    return 0
+
+
+def _concat(parts):
+    kw = {c: np.concatenate([getattr(p, c) for p in parts]) for c in S.VariantTable.COLS}
+    base = np.cumsum([0] + [p.alleles.size for p in parts[:-1]])
+    kw["ref_off"] = np.concatenate([p.ref_off + np.uint32(b) for p, b in zip(parts, base)]).astype(np.uint32)
+    kw["alt_off"] = np.concatenate([p.alt_off + np.uint32(b) for p, b in zip(parts, base)]).astype(np.uint32)
+    return S.VariantTable(alleles=np.concatenate([p.alleles for p in parts]), **kw)
+
+
+if __name__ == "__main__":
+    run(sys.argv)
