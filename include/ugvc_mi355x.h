@@ -145,6 +145,14 @@ int ugvc_timed_steps(ugvc_ctx* ctx, int iters, int64_t shard_cap, int gather, fl
 int ugvc_device_sync(ugvc_ctx* ctx);   /* hipDeviceSynchronize on the context's device */
 int ugvc_feature_matrix(ugvc_ctx* ctx, float* x_host, uint8_t* group_host);
 int ugvc_n_features(ugvc_ctx* ctx);
+/* Config C5 (train_models_pipeline: on-GPU feature matrix + tree-ensemble inference as a leaf-matrix
+ * GEMM on the matrix cores; docs/train_models_pipeline.md:46-54 `--evaluate_concordance`): evaluate the
+ * uploaded additive (UGVC_MODEL_GBT, depth <= 6) ensemble of `group` on rows of the RESIDENT feature
+ * matrix left by ugvc_feature_matrix.  rows == NULL: every row.  use_mfma 1: path-matrix GEMM
+ * (v_mfma_i32_16x16x64_i8), 0: row traversal - identical f32 margins.  ms_per_launch (optional): mean
+ * kernel time of `iters` launches (HIP events). */
+int ugvc_forest_gemm(ugvc_ctx* ctx, int group, const int32_t* rows, int64_t n_rows, int use_mfma, int iters,
+                     float* margin_out, float* ms_per_launch);
 /* Host-only (no GPU): the single-base-substitution cycle-skip table the kernels use for a flow
  * order; index = (last left base)<<6 | ref<<4 | alt<<2 | (first right base), bases A,C,G,T = 0..3,
  * value 0 non-skip / 1 possible-cycle-skip / 2 cycle-skip.  Exposed so CPU tests can check it

@@ -305,3 +305,33 @@ def test_full_size_properties(engine, frozen_models):
     assert np.array_equal(full.flags[lo:lo + 20_000], exp.flags)
     assert np.array_equal(full.tree_score[lo:lo + 20_000], exp.tree_score)
     assert 0.05 < (full.filter == 0).mean() < 0.95
+
+
+def test_c5_leaf_matrix_gemm(engine, small_callset, frozen_models):
+    """Config C5: the XGBoost-shaped ensemble (T = 100, depth 6) evaluated on the resident feature matrix
+    as a leaf-matrix GEMM on MFMA and as a row traversal: both bit-identical to the oracle's f32 margins."""
+    from variantcalling_amd import schema as S
+    O = _oracle()
+    cs = small_callset
+    forests = frozen_models[XGB]
+    assert all(f.n_trees == 100 and f.max_depth <= 6 for f in forests)
+    _configure(engine, cs.ref, cs.runs, cs.tracks, cs.blacklist, forests)
+    X, group = engine.feature_matrix(cs.variants)
+    for g in range(S.N_GROUPS):
+        rows = np.flatnonzero(group == g).astype(np.int32)
+        exp_margin, exp_score = O.forest_predict(forests[g], X[rows])
+        for mfma in (True, False):
+            got, ms = engine.forest_gemm(g, rows, use_mfma=mfma)
+            assert np.array_equal(got, exp_margin), (g, mfma, np.flatnonzero(got != exp_margin)[:5])
+            assert ms > 0
+    # all rows with one group's model, ragged tail (n not a multiple of 16), tiny inputs
+    got, _ = engine.forest_gemm(0, None, use_mfma=True)
+    assert np.array_equal(got, O.forest_predict(forests[0], X)[0])
+    for k in (1, 15, 17):
+        got, _ = engine.forest_gemm(2, np.arange(k, dtype=np.int32), use_mfma=True)
+        assert np.array_equal(got, O.forest_predict(forests[2], X[:k])[0])
+    # RF / deep trees are refused, not approximated
+    _configure(engine, cs.ref, cs.runs, cs.tracks, cs.blacklist, frozen_models[RF])
+    engine.feature_matrix(cs.variants)
+    with pytest.raises(RuntimeError, match="additive|depth"):
+        engine.forest_gemm(0, None)

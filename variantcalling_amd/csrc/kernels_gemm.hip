@@ -1,0 +1,217 @@
+// Config C5: tree-ensemble inference on the resident N x F feature matrix, cast as a leaf-matrix GEMM
+// on the matrix cores (BASELINE.json configs[4]; SURVEY.md 8(d) "Algorithmic FLOPs for C5"), next to a
+// plain traversal kernel over the same matrix.  gfx950 only.
+//
+// Path-matrix formulation for complete binary trees of depth 6 (I = 63 internal nodes, L = 64 leaves;
+// shallower trees are padded, the padding replicates leaf payloads so padded decisions are immaterial):
+//   t[n][i] = 1 if variant n goes RIGHT at node i (exact f32 compare on the VALU), else 0;
+//   C[i][l] = +1 / -1 if leaf l lies in the right / left subtree of node i, 0 if i is not an ancestor;
+//   S = t . C  (N x 64 by 64 x 64, int8 x int8 -> int32 on v_mfma_i32_16x16x64_i8: K = 64 nodes in ONE
+//   instruction, 4 instructions for the 64 leaves); leaf l is the exit leaf iff S[n][l] == popcount(l)
+//   (every one of its 6 ancestors agrees).  Sums are at most 6 in magnitude: exact.
+// The exit leaf's f32 margin is added per tree IN TREE ORDER, so the result is bit-identical to the
+// traversal kernel and to the oracle.  C is the same for every tree (heap-ordered complete trees), so
+// the B operand lives in 16 VGPRs for the whole kernel.  The GEMM does 2*64*64 = 8192 int-ops per tree and
+// variant against 6 node visits for the traversal: it is reported beside it, not instead of it.
+#include "ugvc_v2.hpp"
+
+namespace ugvc {
+
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int kGemmThreads = 512;       // 8 waves, one 16-row tile per wave and step
+constexpr int kGemmXStride = 25;        // dwords per staged feature row (F <= 22; odd: conflict-free)
+
+struct GemmArgs {
+    const float* X;            // N x F row-major (resident feature matrix)
+    int F;
+    const int32_t* rows;       // optional row index list
+    int64_t n;                 // rows to evaluate
+    const float2* nodes;       // [T][64]: {threshold, feature-as-int bits}; slot 63 is padding
+    const float* leaves;       // [T][64]
+    int T, kind;
+    float base;
+    float* out;                // margin per evaluated row
+};
+
+__device__ __forceinline__ int path_entry(int i, int l) {          // C[i][l], node i = heap index - 1
+    if (i >= 63) return 0;
+    const int d = 31 - __builtin_clz(i + 1);                        // level of node i
+    const int p = i + 1 - (1 << d);                                 // position inside the level
+    if ((l >> (6 - d)) != p) return 0;
+    return ((l >> (5 - d)) & 1) ? 1 : -1;
+}
+
+__global__ __launch_bounds__(kGemmThreads) void forest_gemm_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2* nodes = reinterpret_cast<float2*>(smem);
+    float* leaves = reinterpret_cast<float*>(smem + (size_t)g.T * 64 * 8);
+    float* xs_all = leaves + (size_t)g.T * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int k = tid; k < g.T * 64; k += kGemmThreads) { nodes[k] = g.nodes[k]; leaves[k] = g.leaves[k]; }
+    __syncthreads();
+    float* xs = xs_all + wave * 16 * kGemmXStride;
+
+    // B operand: lane holds C[k = (lane>>4)*16 .. +16][leaf = 16*j + (lane&15)] for the four leaf blocks j
+    i32x4_t B[4];
+    const int col = lane & 15, kb = (lane >> 4) * 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 16; ++q) w[q >> 2] |= (path_entry(kb + q, 16 * j + col) & 0xff) << (8 * (q & 3));
+        B[j] = i32x4_t{w[0], w[1], w[2], w[3]};
+    }
+    int want[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) want[j] = __popc(16 * j + col);
+
+    const int64_t n_tiles = (g.n + 15) / 16;
+    const int row = lane & 15;
+    for (int64_t tile = (int64_t)blockIdx.x * (kGemmThreads / 64) + wave; tile < n_tiles;
+         tile += (int64_t)gridDim.x * (kGemmThreads / 64)) {
+        // stage the tile's 16 feature rows (lane -> (row, 4 consecutive features) pieces)
+        for (int e = lane; e < 16 * g.F; e += 64) {
+            const int r = e / g.F, f = e - r * g.F;
+            int64_t gr = tile * 16 + r;
+            if (gr >= g.n) gr = g.n - 1;
+            const int64_t src = g.rows ? (int64_t)g.rows[gr] : gr;
+            xs[r * kGemmXStride + f] = g.X[src * g.F + f];
+        }
+        const float* xrow = xs + row * kGemmXStride;
+        float margin[4] = {g.base, g.base, g.base, g.base};        // rows (lane>>4)*4 + r of the tile
+        for (int t = 0; t < g.T; ++t) {
+            const float2* tn = nodes + t * 64 + kb;
+            int a[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float2 nd = tn[q];
+                const float x = xrow[__float_as_int(nd.y)];
+                const bool left = g.kind == UGVC_MODEL_RF ? x <= nd.x : x < nd.x;
+                a[q >> 2] |= (left ? 0 : 1) << (8 * (q & 3));
+            }
+            const i32x4_t A = i32x4_t{a[0], a[1], a[2], a[3]};
+            const i32x4_t zero = i32x4_t{0, 0, 0, 0};
+            float hit[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const i32x4_t S = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, B[j], zero, 0, 0, 0);
+                const float lv = leaves[t * 64 + 16 * j + col];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hit[r] += S[r] == want[j] ? lv : 0.0f;    // at most one non-zero term per row
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = hit[r];                                   // exactly one lane of the 16 holds the leaf value
+                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+                margin[r] += v;                                     // tree order, f32: as the traversal
+            }
+        }
+        if (col < 4) {
+            const int64_t gr = tile * 16 + (lane >> 4) * 4 + col;
+            const float m = col == 0 ? margin[0] : (col == 1 ? margin[1] : (col == 2 ? margin[2] : margin[3]));
+            if (gr < g.n) g.out[gr] = m;
+        }
+    }
+}
+
+// Traversal over the same matrix and the same dense node table: one lane per row, fixed 6-level walk.
+__global__ __launch_bounds__(256) void forest_rows_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2* nodes = reinterpret_cast<float2*>(smem);
+    float* leaves = reinterpret_cast<float*>(smem + (size_t)g.T * 64 * 8);
+    for (int k = threadIdx.x; k < g.T * 64; k += 256) { nodes[k] = g.nodes[k]; leaves[k] = g.leaves[k]; }
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < g.n; i += (int64_t)gridDim.x * 256) {
+        const int64_t src = g.rows ? (int64_t)g.rows[i] : i;
+        const float* x = g.X + src * g.F;
+        float xv[kMaxFeatures];
+#pragma unroll
+        for (int f = 0; f < kMaxFeatures; ++f) xv[f] = f < g.F ? x[f] : 0.f;
+        float margin = g.base;
+        for (int t = 0; t < g.T; ++t) {
+            int idx = 1;
+#pragma unroll
+            for (int d = 0; d < 6; ++d) {
+                const float2 nd = nodes[t * 64 + idx - 1];
+                const int f = __float_as_int(nd.y);
+                float xf = xv[0];
+#pragma unroll
+                for (int q = 1; q < kMaxFeatures; ++q) xf = f == q ? xv[q] : xf;
+                const bool left = g.kind == UGVC_MODEL_RF ? xf <= nd.x : xf < nd.x;
+                idx = 2 * idx + (left ? 0 : 1);
+            }
+            margin += leaves[t * 64 + idx - 64];
+        }
+        g.out[i] = margin;
+    }
+}
+
+}  // namespace ugvc
+
+using namespace ugvc;
+
+namespace ugvc {
+int gemm_model(ugvc_ctx* ctx, int group, std::vector<float2>& nodes, std::vector<float>& leaves, int& T, int& kind, float& base);
+}
+
+extern "C" int ugvc_forest_gemm(ugvc_ctx* ctx, int group, const int32_t* rows, int64_t n_rows, int use_mfma, int iters,
+                                float* margin_out, float* ms_per_launch) {
+    if (!ctx || !margin_out) return fail("NULL argument");
+    if (group < 0 || group >= UGVC_N_GROUPS) return fail("group out of range");
+    if (iters < 1) iters = 1;
+    UGVC_HIP(hipSetDevice(ctx->device));
+    const int F = UGVC_N_BASE_FEATURES + ctx->n_tracks;
+    if (!ctx->x_mat.p || ctx->x_mat.cap < (size_t)ctx->n * F * 4) return fail("no resident feature matrix (ugvc_feature_matrix first)");
+    const int64_t n = rows ? n_rows : ctx->n;
+    if (n <= 0) return 0;
+    std::vector<float2> nodes;
+    std::vector<float> leaves;
+    int T = 0, kind = 0;
+    float base = 0.f;
+    if (gemm_model(ctx, group, nodes, leaves, T, kind, base)) return -1;
+    DeviceBuf dn, dl, dr, dout;
+    int rc = 0;
+    if (upload(ctx, dn, nodes.data(), nodes.size() * sizeof(float2)) || upload(ctx, dl, leaves.data(), leaves.size() * 4) ||
+        ensure(dout, (size_t)n * 4))
+        rc = -1;
+    if (!rc && rows) {
+        for (int64_t i = 0; i < n_rows; ++i)
+            if (rows[i] < 0 || rows[i] >= ctx->n) { rc = fail("row index out of range"); break; }
+        if (!rc && upload(ctx, dr, rows, (size_t)n_rows * 4)) rc = -1;
+    }
+    if (!rc) {
+        GemmArgs g{ctx->x_mat.as<float>(), F, rows ? dr.as<int32_t>() : nullptr, n, dn.as<float2>(), dl.as<float>(),
+                   T, kind, base, dout.as<float>()};
+        const size_t lds_tables = (size_t)T * 64 * 12;
+        const size_t lds = use_mfma ? lds_tables + (size_t)(kGemmThreads / 64) * 16 * kGemmXStride * 4 : lds_tables;
+        if (lds > 156 * 1024) rc = fail("ensemble too large for the LDS-resident GEMM formulation (T * 768 bytes)");
+        if (!rc) {
+            const void* fn = use_mfma ? reinterpret_cast<const void*>(forest_gemm_kernel) : reinterpret_cast<const void*>(forest_rows_kernel);
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess)
+                rc = fail("cannot raise the dynamic LDS limit");
+        }
+        if (!rc) {
+            const unsigned grid = (unsigned)ctx->n_cus;
+            if (hipEventRecord(ctx->ev0, ctx->stream) != hipSuccess) rc = fail("event record failed");
+            for (int it = 0; it < iters && !rc; ++it) {
+                if (use_mfma) hipLaunchKernelGGL(forest_gemm_kernel, dim3(grid), dim3(kGemmThreads), lds, ctx->stream, g);
+                else hipLaunchKernelGGL(forest_rows_kernel, dim3(grid * 4), dim3(256), lds, ctx->stream, g);
+            }
+            if (!rc && (hipEventRecord(ctx->ev1, ctx->stream) != hipSuccess || hipEventSynchronize(ctx->ev1) != hipSuccess ||
+                        hipGetLastError() != hipSuccess))
+                rc = fail("forest GEMM launch failed");
+            if (!rc && ms_per_launch) {
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+                *ms_per_launch = ms / iters;
+            }
+        }
+        if (!rc && hipMemcpyAsync(margin_out, dout.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+            rc = fail("D2H copy failed");
+    }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc) rc = fail("stream sync failed");
+    for (DeviceBuf* b : {&dn, &dl, &dr, &dout})
+        if (b->p) (void)hipFree(b->p);
+    return rc;
+}

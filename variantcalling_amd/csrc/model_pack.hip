@@ -2,6 +2,7 @@
 // tables (LUT / sorted thresholds), code bit-packing layout, cycle-skip LUT.  See ugvc_v2.hpp.
 #include <algorithm>
 #include <cmath>
+#include <limits>
 #include <map>
 
 #include "ugvc_v2.hpp"
@@ -401,6 +402,40 @@ int v2_fill_args(ugvc_ctx* ctx, V2Args& v, int64_t n) {
     v.na3[0] = ctx->has_runs ? (int)ctx->runs_n : 0;
     for (int t = 0; t < ctx->n_tracks; ++t) v.na3[1 + t] = (int)ctx->trk_n[t];
     v.na3[kJoin3 - 1] = (int)ctx->n_bl;
+    return 0;
+}
+
+// Dense depth-6 tables of one group's additive ensemble for the leaf-matrix GEMM / row traversal
+// kernels (kernels_gemm.hip): nodes[t][heap index - 1] = {threshold, feature}, slot 63 padding;
+// leaves[t][0..63].  A leaf above level 6 owns every slot below it; the padded decisions on the way
+// (threshold +inf, feature 0) are immaterial because both sides carry the same payload.
+static void gemm_fill(const V2Group& g, int t, int src, int level, int idx, std::vector<float2>& nodes, std::vector<float>& leaves) {
+    if (g.feature[src] < 0) {
+        const int p = idx - (1 << level);
+        for (int sl = p << (6 - level); sl < (p + 1) << (6 - level); ++sl)
+            leaves[(size_t)t * 64 + sl] = (float)g.leaf_value[2 * (size_t)g.left[src]];
+        return;
+    }
+    float2 nd;
+    nd.x = g.threshold[src];
+    nd.y = __builtin_bit_cast(float, (int)g.feature[src]);
+    nodes[(size_t)t * 64 + idx - 1] = nd;
+    gemm_fill(g, t, g.left[src], level + 1, 2 * idx, nodes, leaves);
+    gemm_fill(g, t, g.right[src], level + 1, 2 * idx + 1, nodes, leaves);
+}
+
+int gemm_model(ugvc_ctx* ctx, int group, std::vector<float2>& nodes, std::vector<float>& leaves, int& T, int& kind, float& base) {
+    const V2Group& g = state(ctx)->g[group];
+    if (!g.set) return fail("no model uploaded for group " + std::to_string(group));
+    if (g.kind != UGVC_MODEL_GBT) return fail("the leaf-matrix GEMM formulation is implemented for additive (XGBoost-style) ensembles");
+    if (g.D > 6) return fail("the leaf-matrix GEMM formulation needs trees of depth <= 6 (63 x 64 path matrix)");
+    T = g.T; kind = g.kind; base = g.base;
+    float2 pad;
+    pad.x = std::numeric_limits<float>::infinity();
+    pad.y = __builtin_bit_cast(float, 0);
+    nodes.assign((size_t)T * 64, pad);
+    leaves.assign((size_t)T * 64, 0.f);
+    for (int t = 0; t < T; ++t) gemm_fill(g, t, g.roots[t], 0, 1, nodes, leaves);
     return 0;
 }
 

@@ -68,6 +68,7 @@ ABI = {
     "ugvc_device_sync": (C.c_int, [_ctx]),
     "ugvc_feature_matrix": (C.c_int, [_ctx, _f32p, _u8p]),
     "ugvc_n_features": (C.c_int, [_ctx]),
+    "ugvc_forest_gemm": (C.c_int, [_ctx, C.c_int, _i32p, C.c_int64, C.c_int, C.c_int, _f32p, _f32p]),
     "ugvc_host_css_lut": (C.c_int, [C.c_char_p, _u8p]),
     "ugvc_set_kernel_variant": (C.c_int, [_ctx, C.c_int]),
     "ugvc_pileup_tally": (C.c_int, [_ctx, _i64p, _u16p, C.c_int64, C.POINTER(CPileupOut)]),
@@ -266,6 +267,17 @@ class Engine:
         g = np.zeros(self.n, np.uint8)
         self._check(self.lib.ugvc_feature_matrix(self._h, _p(X, _f32p), _p(g, _u8p)))
         return X, g
+
+    def forest_gemm(self, group: int, rows: np.ndarray | None = None, use_mfma: bool = True, iters: int = 1):
+        """(f32 margins, ms per launch) of group `group`'s additive ensemble on rows of the resident feature
+        matrix: leaf-matrix GEMM on MFMA (use_mfma) or row traversal."""
+        n = self.n if rows is None else int(rows.size)
+        out = np.zeros(n, np.float32)
+        ms = C.c_float()
+        r = None if rows is None else _col(rows, np.int32)
+        self._check(self.lib.ugvc_forest_gemm(self._h, group, None if r is None else _p(r, _i32p), n, int(use_mfma),
+                                              iters, _p(out, _f32p), C.byref(ms)))
+        return out, ms.value
 
     # ---- pileup
     def pileup_tally(self, offsets: np.ndarray, obs: np.ndarray) -> dict:
