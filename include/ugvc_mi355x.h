@@ -189,11 +189,15 @@ int ugvc_bridging_snvs(ugvc_ctx* ctx, const ugvc_variants* v, const uint8_t* is_
  * One process per GPU.  Rank 0 calls ugvc_comm_unique_id and shares the 128 bytes out of
  * band; every rank calls ugvc_comm_init.  ugvc_allgather_results gathers the resident
  * result columns of every rank (shards padded to shard_cap rows) into host or device
- * order-preserving buffers: rank r's rows land at [r*shard_cap, r*shard_cap + counts[r]). */
+ * order-preserving buffers: rank r's rows land at [r*shard_cap, r*shard_cap + counts[r]).
+ * The collective is issued on a second HIP stream behind an event, so the gather of one scoring pass
+ * overlaps the kernels of the next (ugvc_timed_steps, streaming use); ugvc_gathered_download and
+ * ugvc_gather_fence order it before anything that reads or rewrites the gather buffers. */
 int ugvc_comm_unique_id(uint8_t id[128]);
 int ugvc_comm_init(ugvc_ctx* ctx, const uint8_t id[128], int rank, int world);
 int ugvc_comm_destroy(ugvc_ctx* ctx);
-int ugvc_allgather_resident(ugvc_ctx* ctx, int64_t shard_cap);
+int ugvc_allgather_resident(ugvc_ctx* ctx, int64_t shard_cap);   /* async: collective on its own stream */
+int ugvc_gather_fence(ugvc_ctx* ctx);                             /* context stream waits for the last gather */
 int ugvc_gathered_download(ugvc_ctx* ctx, int64_t shard_cap, int world, const ugvc_results* out);
 
 #ifdef __cplusplus

@@ -335,3 +335,25 @@ def test_c5_leaf_matrix_gemm(engine, small_callset, frozen_models):
     engine.feature_matrix(cs.variants)
     with pytest.raises(RuntimeError, match="additive|depth"):
         engine.forest_gemm(0, None)
+
+
+def test_rccl_gather_path_single_rank(small_callset, frozen_models):
+    """The N > 1 data path (RCCL all-gather of the three result columns on its own stream, overlapped
+    with the next scoring pass) exercised with a one-rank communicator: librccl is dlopen'ed, the
+    communicator initialised, the grouped in-place all-gathers issued and fenced on real hardware."""
+    from variantcalling_amd.engine import Engine, configure
+    O = _oracle()
+    cs = small_callset
+    with Engine(0) as e2:
+        configure(e2, cs.ref, cs.runs, cs.tracks, cs.blacklist, frozen_models[RF])
+        e2.upload_variants(cs.variants)
+        e2.comm_init(e2.comm_unique_id(), 0, 1)
+        cap = cs.variants.n + 37                      # padded shard, as ceil(N / world) is in general
+        tot, ker = e2.timed_steps(4, cap, True)       # 4 x {scoring pass, overlapped gather}
+        assert tot > 0 and ker > 0
+        e2.filter_resident()
+        e2.allgather_resident(cap)
+        got = e2.gathered_download(cap, 1, [cs.variants.n])
+        exp = O.filter_variants(cs.variants, cs.ref, cs.runs, cs.tracks, cs.blacklist, frozen_models[RF])
+        _assert_same(got, exp, "gathered")
+        _assert_same(e2.download_results(), exp, "resident")

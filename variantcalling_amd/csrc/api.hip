@@ -470,6 +470,7 @@ int ugvc_device_sync(ugvc_ctx* ctx) {
 }
 
 int ugvc_allgather_resident(ugvc_ctx* ctx, int64_t shard_cap);
+int ugvc_gather_fence(ugvc_ctx* ctx);
 
 int ugvc_timed_steps(ugvc_ctx* ctx, int iters, int64_t shard_cap, int gather, float* ms_total, float* ms_kernel) {
     if (!ctx || !ms_total || !ms_kernel || iters < 1) return fail("bad arguments");
@@ -486,6 +487,7 @@ int ugvc_timed_steps(ugvc_ctx* ctx, int iters, int64_t shard_cap, int gather, fl
         UGVC_HIP(hipEventRecord(ev[2 * it + 1], ctx->stream));
         if (!rc && gather) rc = ugvc_allgather_resident(ctx, shard_cap);
     }
+    if (!rc && gather) rc = ugvc_gather_fence(ctx);      // the timed region ends when the last gather has landed
     UGVC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     UGVC_HIP(hipEventSynchronize(ctx->ev1));
     if (!rc) {

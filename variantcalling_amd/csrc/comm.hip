@@ -86,13 +86,22 @@ int ugvc_comm_init(ugvc_ctx* ctx, const uint8_t id[128], int rank, int world) {
     ctx->comm = comm;
     ctx->rank = rank;
     ctx->world = world;
+    // the collective runs on its own stream so the gather of pass i overlaps the kernels of pass i+1
+    UGVC_HIP(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+    UGVC_HIP(hipEventCreateWithFlags(&ctx->ev_res_ready, hipEventDisableTiming));
+    UGVC_HIP(hipEventCreateWithFlags(&ctx->ev_gather_done, hipEventDisableTiming));
+    ctx->gather_pending = 0;
     return 0;
 }
 
 int ugvc_comm_destroy(ugvc_ctx* ctx) {
     if (!ctx || !ctx->comm) return 0;
     (void)hipSetDevice(ctx->device);
+    if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
     if (g_rccl.CommDestroy) g_rccl.CommDestroy(static_cast<ncclComm_t>(ctx->comm));
+    if (ctx->comm_stream) { (void)hipStreamDestroy(ctx->comm_stream); ctx->comm_stream = nullptr; }
+    if (ctx->ev_res_ready) { (void)hipEventDestroy(ctx->ev_res_ready); ctx->ev_res_ready = nullptr; }
+    if (ctx->ev_gather_done) { (void)hipEventDestroy(ctx->ev_gather_done); ctx->ev_gather_done = nullptr; }
     ctx->comm = nullptr;
     ctx->world = 1;
     ctx->rank = 0;
@@ -108,21 +117,41 @@ int ugvc_allgather_resident(ugvc_ctx* ctx, int64_t shard_cap) {
     float* gs = ctx->g_score.as<float>();
     uint8_t* gf = ctx->g_filter.as<uint8_t>();
     uint8_t* gl = ctx->g_flags.as<uint8_t>();
+    // the gather buffers are read by the previous pass's collective until ev_gather_done
+    if (ctx->comm && ctx->gather_pending) UGVC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_gather_done, 0));
     if (n) {
         UGVC_HIP(hipMemcpyAsync(gs + r * cap, ctx->r_score.p, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
         UGVC_HIP(hipMemcpyAsync(gf + r * cap, ctx->r_filter.p, n, hipMemcpyDeviceToDevice, ctx->stream));
         UGVC_HIP(hipMemcpyAsync(gl + r * cap, ctx->r_flags.p, n, hipMemcpyDeviceToDevice, ctx->stream));
     }
-    if (ctx->world == 1) return 0;
-    if (!ctx->comm) return fail("communicator not initialised (ugvc_comm_init)");
+    if (!ctx->comm) {
+        if (ctx->world == 1) return 0;
+        return fail("communicator not initialised (ugvc_comm_init)");
+    }
     ncclComm_t comm = static_cast<ncclComm_t>(ctx->comm);
+    UGVC_HIP(hipEventRecord(ctx->ev_res_ready, ctx->stream));
+    UGVC_HIP(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_res_ready, 0));
     UGVC_NCCL(g_rccl.GroupStart());
-    UGVC_NCCL(g_rccl.AllGather(gs + r * cap, gs, cap, ncclFloat32, comm, ctx->stream));
-    UGVC_NCCL(g_rccl.AllGather(gf + r * cap, gf, cap, ncclUint8, comm, ctx->stream));
-    UGVC_NCCL(g_rccl.AllGather(gl + r * cap, gl, cap, ncclUint8, comm, ctx->stream));
+    UGVC_NCCL(g_rccl.AllGather(gs + r * cap, gs, cap, ncclFloat32, comm, ctx->comm_stream));
+    UGVC_NCCL(g_rccl.AllGather(gf + r * cap, gf, cap, ncclUint8, comm, ctx->comm_stream));
+    UGVC_NCCL(g_rccl.AllGather(gl + r * cap, gl, cap, ncclUint8, comm, ctx->comm_stream));
     UGVC_NCCL(g_rccl.GroupEnd());
+    UGVC_HIP(hipEventRecord(ctx->ev_gather_done, ctx->comm_stream));
+    ctx->gather_pending = 1;
     return 0;
 }
+
+// Make the context stream wait for the last collective (end of a timed region, before a download).
+int ugvc_gather_fence(ugvc_ctx* ctx) {
+    if (!ctx) return fail("ctx is NULL");
+    if (ctx->comm && ctx->gather_pending) {
+        UGVC_HIP(hipSetDevice(ctx->device));
+        UGVC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_gather_done, 0));
+    }
+    return 0;
+}
+
+int ugvc_gather_fence(ugvc_ctx* ctx);
 
 int ugvc_gathered_download(ugvc_ctx* ctx, int64_t shard_cap, int world, const ugvc_results* out) {
     if (!ctx || !out) return fail("NULL argument");
@@ -130,6 +159,7 @@ int ugvc_gathered_download(ugvc_ctx* ctx, int64_t shard_cap, int world, const ug
     UGVC_HIP(hipSetDevice(ctx->device));
     const size_t tot = (size_t)shard_cap * (size_t)world;
     if (ctx->g_score.cap < tot * 4) return fail("nothing gathered yet (ugvc_allgather_resident)");
+    if (ugvc_gather_fence(ctx)) return -1;
     if (out->tree_score) UGVC_HIP(hipMemcpyAsync(out->tree_score, ctx->g_score.p, tot * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (out->filter) UGVC_HIP(hipMemcpyAsync(out->filter, ctx->g_filter.p, tot, hipMemcpyDeviceToHost, ctx->stream));
     if (out->flags) UGVC_HIP(hipMemcpyAsync(out->flags, ctx->g_flags.p, tot, hipMemcpyDeviceToHost, ctx->stream));

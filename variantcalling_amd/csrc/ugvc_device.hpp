@@ -125,6 +125,9 @@ struct ugvc_ctx {
     // gather
     ugvc::DeviceBuf g_score, g_filter, g_flags;
     void* comm = nullptr;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_res_ready = nullptr, ev_gather_done = nullptr;
+    int gather_pending = 0;
     int rank = 0, world = 1;
     int kernel_variant = 0;
     void* v2 = nullptr;             // ugvc::V2State (model_pack.hip)

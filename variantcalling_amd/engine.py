@@ -81,6 +81,7 @@ ABI = {
     "ugvc_comm_init": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int]),
     "ugvc_comm_destroy": (C.c_int, [_ctx]),
     "ugvc_allgather_resident": (C.c_int, [_ctx, C.c_int64]),
+    "ugvc_gather_fence": (C.c_int, [_ctx]),
     "ugvc_gathered_download": (C.c_int, [_ctx, C.c_int64, C.c_int, C.POINTER(CResults)]),
 }
 
