@@ -197,7 +197,12 @@ int ugvc_comm_unique_id(uint8_t id[128]);
 int ugvc_comm_init(ugvc_ctx* ctx, const uint8_t id[128], int rank, int world);
 int ugvc_comm_destroy(ugvc_ctx* ctx);
 int ugvc_allgather_resident(ugvc_ctx* ctx, int64_t shard_cap);   /* async: collective on its own stream */
-int ugvc_gather_fence(ugvc_ctx* ctx);                             /* context stream waits for the last gather */
+int ugvc_gather_fence(ugvc_ctx* ctx);                             /* context stream waits for the outstanding gathers */
+/* zero-copy form used by ugvc_timed_steps: ugvc_gather_target picks the next of two gather buffers (waiting for
+ * its previous collective) and returns this rank's slot so the scoring pass writes there; ugvc_gather_launch
+ * issues the collective behind the work queued on the context stream. */
+int ugvc_gather_target(ugvc_ctx* ctx, int64_t shard_cap, float** score, uint8_t** filter, uint8_t** flags);
+int ugvc_gather_launch(ugvc_ctx* ctx, int64_t shard_cap);
 int ugvc_gathered_download(ugvc_ctx* ctx, int64_t shard_cap, int world, const ugvc_results* out);
 
 #ifdef __cplusplus

@@ -153,7 +153,8 @@ int ugvc_ctx_destroy(ugvc_ctx* ctx) {
                         &ctx->v_contig, &ctx->v_pos, &ctx->v_rl, &ctx->v_al, &ctx->v_ro, &ctx->v_ao,
                         &ctx->v_alleles, &ctx->v_qual, &ctx->v_sor, &ctx->v_dp, &ctx->v_adr, &ctx->v_ada,
                         &ctx->v_gq, &ctx->r_score, &ctx->r_filter, &ctx->r_flags, &ctx->x_mat, &ctx->x_group,
-                        &ctx->pl_off, &ctx->pl_obsb, &ctx->pl_out, &ctx->g_score, &ctx->g_filter, &ctx->g_flags};
+                        &ctx->pl_off, &ctx->pl_obsb, &ctx->pl_out, &ctx->g_score[0], &ctx->g_filter[0], &ctx->g_flags[0],
+                        &ctx->g_score[1], &ctx->g_filter[1], &ctx->g_flags[1]};
     for (auto* b : all) release(*b);
     for (int t = 0; t < UGVC_MAX_TRACKS; ++t) {
         release(ctx->trk_s[t]);
@@ -471,6 +472,8 @@ int ugvc_device_sync(ugvc_ctx* ctx) {
 
 int ugvc_allgather_resident(ugvc_ctx* ctx, int64_t shard_cap);
 int ugvc_gather_fence(ugvc_ctx* ctx);
+int ugvc_gather_target(ugvc_ctx* ctx, int64_t shard_cap, float** score, uint8_t** filter, uint8_t** flags);
+int ugvc_gather_launch(ugvc_ctx* ctx, int64_t shard_cap);
 
 int ugvc_timed_steps(ugvc_ctx* ctx, int iters, int64_t shard_cap, int gather, float* ms_total, float* ms_kernel) {
     if (!ctx || !ms_total || !ms_kernel || iters < 1) return fail("bad arguments");
@@ -482,10 +485,13 @@ int ugvc_timed_steps(ugvc_ctx* ctx, int iters, int64_t shard_cap, int gather, fl
     int rc = 0;
     UGVC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     for (int it = 0; it < iters && !rc; ++it) {
+        // with a collective the pass writes straight into this step's gather buffer (no copies)
+        if (gather) rc = ugvc_gather_target(ctx, shard_cap, &a.score, &a.filter, &a.flags);
+        if (rc) break;
         UGVC_HIP(hipEventRecord(ev[2 * it], ctx->stream));
         rc = launch_score(ctx, a);
         UGVC_HIP(hipEventRecord(ev[2 * it + 1], ctx->stream));
-        if (!rc && gather) rc = ugvc_allgather_resident(ctx, shard_cap);
+        if (!rc && gather) rc = ugvc_gather_launch(ctx, shard_cap);
     }
     if (!rc && gather) rc = ugvc_gather_fence(ctx);      // the timed region ends when the last gather has landed
     UGVC_HIP(hipEventRecord(ctx->ev1, ctx->stream));

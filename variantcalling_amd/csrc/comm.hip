@@ -89,8 +89,10 @@ int ugvc_comm_init(ugvc_ctx* ctx, const uint8_t id[128], int rank, int world) {
     // the collective runs on its own stream so the gather of pass i overlaps the kernels of pass i+1
     UGVC_HIP(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
     UGVC_HIP(hipEventCreateWithFlags(&ctx->ev_res_ready, hipEventDisableTiming));
-    UGVC_HIP(hipEventCreateWithFlags(&ctx->ev_gather_done, hipEventDisableTiming));
-    ctx->gather_pending = 0;
+    for (int k = 0; k < 2; ++k) {
+        UGVC_HIP(hipEventCreateWithFlags(&ctx->ev_gather_done[k], hipEventDisableTiming));
+        ctx->gather_pending[k] = 0;
+    }
     return 0;
 }
 
@@ -101,33 +103,48 @@ int ugvc_comm_destroy(ugvc_ctx* ctx) {
     if (g_rccl.CommDestroy) g_rccl.CommDestroy(static_cast<ncclComm_t>(ctx->comm));
     if (ctx->comm_stream) { (void)hipStreamDestroy(ctx->comm_stream); ctx->comm_stream = nullptr; }
     if (ctx->ev_res_ready) { (void)hipEventDestroy(ctx->ev_res_ready); ctx->ev_res_ready = nullptr; }
-    if (ctx->ev_gather_done) { (void)hipEventDestroy(ctx->ev_gather_done); ctx->ev_gather_done = nullptr; }
+    for (int k = 0; k < 2; ++k)
+        if (ctx->ev_gather_done[k]) { (void)hipEventDestroy(ctx->ev_gather_done[k]); ctx->ev_gather_done[k] = nullptr; }
     ctx->comm = nullptr;
     ctx->world = 1;
     ctx->rank = 0;
     return 0;
 }
 
-int ugvc_allgather_resident(ugvc_ctx* ctx, int64_t shard_cap) {
+// Pick the next gather buffer, make the context stream wait until its previous collective has
+// drained, and hand back this rank's slot in it: the scoring pass can write its results there.
+int ugvc_gather_target(ugvc_ctx* ctx, int64_t shard_cap, float** score, uint8_t** filter, uint8_t** flags) {
     if (!ctx) return fail("ctx is NULL");
     if (shard_cap < ctx->n) return fail("shard_cap smaller than this rank's variant count");
     UGVC_HIP(hipSetDevice(ctx->device));
-    const size_t cap = (size_t)shard_cap, W = (size_t)ctx->world, r = (size_t)ctx->rank, n = (size_t)ctx->n;
-    if (ensure(ctx->g_score, cap * W * 4) || ensure(ctx->g_filter, cap * W) || ensure(ctx->g_flags, cap * W)) return -1;
-    float* gs = ctx->g_score.as<float>();
-    uint8_t* gf = ctx->g_filter.as<uint8_t>();
-    uint8_t* gl = ctx->g_flags.as<uint8_t>();
-    // the gather buffers are read by the previous pass's collective until ev_gather_done
-    if (ctx->comm && ctx->gather_pending) UGVC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_gather_done, 0));
-    if (n) {
-        UGVC_HIP(hipMemcpyAsync(gs + r * cap, ctx->r_score.p, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        UGVC_HIP(hipMemcpyAsync(gf + r * cap, ctx->r_filter.p, n, hipMemcpyDeviceToDevice, ctx->stream));
-        UGVC_HIP(hipMemcpyAsync(gl + r * cap, ctx->r_flags.p, n, hipMemcpyDeviceToDevice, ctx->stream));
+    const int b = ctx->g_cur ^ 1;
+    const size_t cap = (size_t)shard_cap, W = (size_t)ctx->world, r = (size_t)ctx->rank;
+    if (ctx->g_score[b].cap < cap * W * 4 || ctx->g_filter[b].cap < cap * W || ctx->g_flags[b].cap < cap * W) {
+        if (ctx->comm_stream) UGVC_HIP(hipStreamSynchronize(ctx->comm_stream));   // re-allocation: nothing may be in flight
+        if (ensure(ctx->g_score[b], cap * W * 4) || ensure(ctx->g_filter[b], cap * W) || ensure(ctx->g_flags[b], cap * W)) return -1;
     }
+    if (ctx->comm && ctx->gather_pending[b]) UGVC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_gather_done[b], 0));
+    ctx->g_cur = b;
+    if (score) *score = ctx->g_score[b].as<float>() + r * cap;
+    if (filter) *filter = ctx->g_filter[b].as<uint8_t>() + r * cap;
+    if (flags) *flags = ctx->g_flags[b].as<uint8_t>() + r * cap;
+    return 0;
+}
+
+// Issue the grouped in-place all-gathers of the current gather buffer on the communication stream,
+// behind everything queued so far on the context stream.
+int ugvc_gather_launch(ugvc_ctx* ctx, int64_t shard_cap) {
+    if (!ctx) return fail("ctx is NULL");
     if (!ctx->comm) {
         if (ctx->world == 1) return 0;
         return fail("communicator not initialised (ugvc_comm_init)");
     }
+    UGVC_HIP(hipSetDevice(ctx->device));
+    const int b = ctx->g_cur;
+    const size_t cap = (size_t)shard_cap, r = (size_t)ctx->rank;
+    float* gs = ctx->g_score[b].as<float>();
+    uint8_t* gf = ctx->g_filter[b].as<uint8_t>();
+    uint8_t* gl = ctx->g_flags[b].as<uint8_t>();
     ncclComm_t comm = static_cast<ncclComm_t>(ctx->comm);
     UGVC_HIP(hipEventRecord(ctx->ev_res_ready, ctx->stream));
     UGVC_HIP(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_res_ready, 0));
@@ -136,17 +153,30 @@ int ugvc_allgather_resident(ugvc_ctx* ctx, int64_t shard_cap) {
     UGVC_NCCL(g_rccl.AllGather(gf + r * cap, gf, cap, ncclUint8, comm, ctx->comm_stream));
     UGVC_NCCL(g_rccl.AllGather(gl + r * cap, gl, cap, ncclUint8, comm, ctx->comm_stream));
     UGVC_NCCL(g_rccl.GroupEnd());
-    UGVC_HIP(hipEventRecord(ctx->ev_gather_done, ctx->comm_stream));
-    ctx->gather_pending = 1;
+    UGVC_HIP(hipEventRecord(ctx->ev_gather_done[b], ctx->comm_stream));
+    ctx->gather_pending[b] = 1;
     return 0;
 }
 
-// Make the context stream wait for the last collective (end of a timed region, before a download).
+int ugvc_allgather_resident(ugvc_ctx* ctx, int64_t shard_cap) {
+    float* gs; uint8_t* gf; uint8_t* gl;
+    if (ugvc_gather_target(ctx, shard_cap, &gs, &gf, &gl)) return -1;
+    const size_t n = (size_t)ctx->n;
+    if (n) {
+        UGVC_HIP(hipMemcpyAsync(gs, ctx->r_score.p, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        UGVC_HIP(hipMemcpyAsync(gf, ctx->r_filter.p, n, hipMemcpyDeviceToDevice, ctx->stream));
+        UGVC_HIP(hipMemcpyAsync(gl, ctx->r_flags.p, n, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return ugvc_gather_launch(ctx, shard_cap);
+}
+
+// Make the context stream wait for the outstanding collectives (end of a timed region, before a download).
 int ugvc_gather_fence(ugvc_ctx* ctx) {
     if (!ctx) return fail("ctx is NULL");
-    if (ctx->comm && ctx->gather_pending) {
+    if (ctx->comm) {
         UGVC_HIP(hipSetDevice(ctx->device));
-        UGVC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_gather_done, 0));
+        for (int b = 0; b < 2; ++b)
+            if (ctx->gather_pending[b]) UGVC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_gather_done[b], 0));
     }
     return 0;
 }
@@ -158,11 +188,12 @@ int ugvc_gathered_download(ugvc_ctx* ctx, int64_t shard_cap, int world, const ug
     if (world != ctx->world) return fail("world does not match the communicator");
     UGVC_HIP(hipSetDevice(ctx->device));
     const size_t tot = (size_t)shard_cap * (size_t)world;
-    if (ctx->g_score.cap < tot * 4) return fail("nothing gathered yet (ugvc_allgather_resident)");
+    const int b = ctx->g_cur;
+    if (ctx->g_score[b].cap < tot * 4) return fail("nothing gathered yet (ugvc_allgather_resident)");
     if (ugvc_gather_fence(ctx)) return -1;
-    if (out->tree_score) UGVC_HIP(hipMemcpyAsync(out->tree_score, ctx->g_score.p, tot * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (out->filter) UGVC_HIP(hipMemcpyAsync(out->filter, ctx->g_filter.p, tot, hipMemcpyDeviceToHost, ctx->stream));
-    if (out->flags) UGVC_HIP(hipMemcpyAsync(out->flags, ctx->g_flags.p, tot, hipMemcpyDeviceToHost, ctx->stream));
+    if (out->tree_score) UGVC_HIP(hipMemcpyAsync(out->tree_score, ctx->g_score[b].p, tot * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out->filter) UGVC_HIP(hipMemcpyAsync(out->filter, ctx->g_filter[b].p, tot, hipMemcpyDeviceToHost, ctx->stream));
+    if (out->flags) UGVC_HIP(hipMemcpyAsync(out->flags, ctx->g_flags[b].p, tot, hipMemcpyDeviceToHost, ctx->stream));
     UGVC_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
 }

@@ -87,6 +87,8 @@ __device__ __forceinline__ bool table_present(const FilterArgs& f, int t) {
 __global__ void bracket3_kernel(const V2Args v) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int nb = v.n_blocks;
+    // the record-list counters of this pass start at zero (saves a memset launch per pass)
+    if (gid < UGVC_N_GROUPS * kShards) v.counters[gid * kCounterStride] = 0;
     const int b = (int)(gid >> 3), a = (int)(gid & 7);
     if (b > nb || a >= kJoin3) return;
     const FilterArgs& f = v.f;
@@ -900,8 +902,7 @@ int launch_filter_v3(ugvc_ctx* ctx, const FilterArgs& a) {
     V2Args v;
     v.f = a;
     if (v2_fill_args(ctx, v, a.n)) return -1;
-    UGVC_HIP(hipMemsetAsync(v.counters, 0, (size_t)UGVC_N_GROUPS * kShards * kCounterStride * 4, ctx->stream));
-    const int64_t nbr = (int64_t)(v.n_blocks + 1) * 8;
+    const int64_t nbr = std::max<int64_t>((int64_t)(v.n_blocks + 1) * 8, UGVC_N_GROUPS * kShards);
     hipLaunchKernelGGL(bracket3_kernel, dim3((unsigned)((nbr + 255) / 256)), dim3(256), 0, ctx->stream, v);
     const int k1_grid = std::min(v.n_blocks, ctx->n_cus * 4);
     hipLaunchKernelGGL(featurize3_kernel, dim3((unsigned)k1_grid), dim3(kBlock), 0, ctx->stream, v);

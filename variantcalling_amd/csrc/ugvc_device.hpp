@@ -123,11 +123,12 @@ struct ugvc_ctx {
     int64_t pl_n = 0, pl_obs = 0;
     ugvc::DeviceBuf pl_off, pl_obsb, pl_out;
     // gather
-    ugvc::DeviceBuf g_score, g_filter, g_flags;
+    ugvc::DeviceBuf g_score[2], g_filter[2], g_flags[2];   // double-buffered: pass i+1 writes one while the collective of pass i reads the other
+    int g_cur = 0;                                         // buffer the last gather used
     void* comm = nullptr;
     hipStream_t comm_stream = nullptr;
-    hipEvent_t ev_res_ready = nullptr, ev_gather_done = nullptr;
-    int gather_pending = 0;
+    hipEvent_t ev_res_ready = nullptr, ev_gather_done[2] = {nullptr, nullptr};
+    int gather_pending[2] = {0, 0};
     int rank = 0, world = 1;
     int kernel_variant = 0;
     void* v2 = nullptr;             // ugvc::V2State (model_pack.hip)

@@ -82,6 +82,8 @@ ABI = {
     "ugvc_comm_destroy": (C.c_int, [_ctx]),
     "ugvc_allgather_resident": (C.c_int, [_ctx, C.c_int64]),
     "ugvc_gather_fence": (C.c_int, [_ctx]),
+    "ugvc_gather_target": (C.c_int, [_ctx, C.c_int64, C.POINTER(_f32p), C.POINTER(_u8p), C.POINTER(_u8p)]),
+    "ugvc_gather_launch": (C.c_int, [_ctx, C.c_int64]),
     "ugvc_gathered_download": (C.c_int, [_ctx, C.c_int64, C.c_int, C.POINTER(CResults)]),
 }
 
