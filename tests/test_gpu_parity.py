@@ -337,6 +337,52 @@ def test_c5_leaf_matrix_gemm(engine, small_callset, frozen_models):
         engine.forest_gemm(0, None)
 
 
+def _stump_forest(specs, n_features=20):
+    """specs: [(feature, threshold, (p0, p1) left, (p0, p1) right)] -> one MODEL_RF FlatForest of stumps."""
+    from variantcalling_amd import schema as S
+    feat, thr, left, right, roots, leaves = [], [], [], [], [], []
+    for k, (f, t, lv, rv) in enumerate(specs):
+        roots.append(3 * k)
+        feat += [f, -1, -1]; thr += [t, 0.0, 0.0]
+        left += [3 * k + 1, 2 * k, 2 * k + 1]; right += [3 * k + 2, 0, 0]
+        leaves += [lv, rv]
+    return S.FlatForest(S.MODEL_RF, np.array(feat, np.int32), np.array(thr, np.float32), np.array(left, np.int32),
+                        np.array(right, np.int32), np.array(roots, np.int32), np.array(leaves, np.float64),
+                        n_features=n_features, max_depth=1)
+
+
+@pytest.mark.parametrize("path", [0, 1024, 512, 256], ids=["v3-single-sum", "v3-pair-sums", "v2", "v1"])
+def test_rf_vote_ties_and_unnormalised_payloads(engine, small_callset, path):
+    """The single-sum forest kernel decides PASS on the class-1 sum alone and must fall back to both
+    sums where scikit-learn's argmax is decided by them: exact ties (pure leaves, even T), near ties
+    (0.3 + 0.7 payloads) - and must not be selected at all for payloads that do not sum to 1."""
+    cs = small_callset
+    O = _oracle()
+    pure = [(2, 24.5, (1.0, 0.0), (0.0, 1.0)), (2, 29.5, (1.0, 0.0), (0.0, 1.0)),
+            (2, 34.5, (0.0, 1.0), (1.0, 0.0)), (6, 50.5, (0.0, 1.0), (1.0, 0.0))]
+    near = [(2, 27.5, (0.3, 0.7), (0.7, 0.3)), (0, 40.0, (0.7, 0.3), (0.3, 0.7)),
+            (4, 9.5, (0.1, 0.9), (0.9, 0.1)), (3, 12.5, (0.9, 0.1), (0.1, 0.9)),
+            (1, 1.0, (1.0 / 3.0, 2.0 / 3.0), (2.0 / 3.0, 1.0 / 3.0)), (5, 0.4, (2.0 / 3.0, 1.0 / 3.0), (1.0 / 3.0, 2.0 / 3.0))]
+    # 0.9 + 0.15 + 0.15 + 0.8 and 0.1 + 0.85 + 0.85 + 0.2 differ by an ulp in f64: PASS is decided by it
+    ulp = [(2, 1000.5, (0.1, 0.9), (0.9, 0.1)), (2, 1000.5, (0.85, 0.15), (0.15, 0.85)),
+           (2, 30.5, (0.85, 0.15), (0.5, 0.5)), (2, 1000.5, (0.2, 0.8), (0.8, 0.2))]
+    counts = [(2, 27.5, (3.0, 5.0), (6.0, 2.0)), (0, 40.0, (4.0, 4.0), (1.0, 7.0))]
+    for name, specs in (("pure", pure), ("near", near), ("ulp", ulp), ("counts", counts)):
+        forests = [_stump_forest(specs)] * 3
+        _configure(engine, cs.ref, cs.runs, cs.tracks, cs.blacklist, forests)
+        engine.set_kernel_variant(path)
+        res = engine.filter_variants(cs.variants)
+        exp = O.filter_variants(cs.variants, cs.ref, cs.runs, cs.tracks, cs.blacklist, forests)
+        _assert_same(res, exp, name)
+        if name != "counts":
+            T = len(specs)
+            tied = np.abs(exp.tree_score.astype(np.float64) - 0.5) < 1e-6
+            assert tied.sum() > 100, "the case must exercise the tie band"
+            if name == "ulp":
+                assert (exp.filter[tied] == 0).sum() > 100, "ties broken towards PASS by one ulp"
+        engine.set_kernel_variant(0)
+
+
 def test_rccl_gather_path_single_rank(small_callset, frozen_models):
     """The N > 1 data path (RCCL all-gather of the three result columns on its own stream, overlapped
     with the next scoring pass) exercised with a one-rank communicator: librccl is dlopen'ed, the

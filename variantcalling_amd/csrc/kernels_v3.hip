@@ -45,6 +45,7 @@ template <class T> __device__ __forceinline__ uint32_t lds_addr(T* p) {
 __device__ __forceinline__ int lds_i32(uint32_t a) { return *(UGVC_LDS const int32_t*)(uintptr_t)a; }
 __device__ __forceinline__ uint32_t lds_u32(uint32_t a) { return *(UGVC_LDS const uint32_t*)(uintptr_t)a; }
 __device__ __forceinline__ uint64_t lds_u64(uint32_t a) { return *(UGVC_LDS const uint64_t*)(uintptr_t)a; }
+__device__ __forceinline__ double lds_f64(uint32_t a) { return *(UGVC_LDS const double*)(uintptr_t)a; }
 __device__ __forceinline__ float lds_f32(uint32_t a) { return *(UGVC_LDS const float*)(uintptr_t)a; }
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint2 lds_u32x2(uint32_t a) {
@@ -748,6 +749,51 @@ __device__ __forceinline__ void walk3(uint32_t nodes_b, uint32_t planes_lane_b, 
     for (int k = 0; k < NT; ++k) leaf[k] = (t + k) * NL + (int)idx[k] - NL;
 }
 
+// Single-sum RF walk (PackedGroupView::fast4).  Levels 0..D-2 as in walk3 over a heap of H = 2^(D-1)
+// dwords per tree; the last level is ONE 8-byte read (64 banks) of {node word, payload indices of
+// both children}, issued with its code read, and the child is picked by a compare + SDWA select -
+// no leaf-index gather, no 16-byte payload gather: the class-1 probability is one 8-byte read.
+__device__ __forceinline__ uint32_t pick_half(uint32_t code, uint32_t node, uint32_t both) {
+    uint32_t out;
+    asm("v_cmp_gt_u16_sdwa vcc, %1, %2 src0_sel:WORD_0 src1_sel:WORD_0\n\t"
+        "v_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1"
+        : "=v"(out) : "v"(code), "v"(node), "v"(both) : "vcc");
+    return out;
+}
+
+template <int NT>
+__device__ __forceinline__ void walk4(uint32_t hi_b, uint32_t last_b, uint32_t planes_lane_b, int t, int D, int H,
+                                      uint32_t (&pidx)[NT]) {
+    uint32_t idx[NT], tb[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        tb[k] = hi_b + 4u * (uint32_t)((t + k) * H);
+        idx[k] = 1;
+    }
+    for (int d = 0; d < D - 1; ++d) {
+        uint32_t w[NT], code[NT];
+#pragma unroll
+        for (int k = 0; k < NT; ++k) w[k] = lds_u32(tb[k] + 4u * idx[k]);
+#pragma unroll
+        for (int k = 0; k < NT; ++k) code[k] = lds_u16(planes_lane_b + (w[k] >> 16));
+#pragma unroll
+        for (int k = 0; k < NT; ++k)
+            idx[k] = twice_plus_carry(idx[k], __builtin_amdgcn_ballot_w64(code[k] > (w[k] & 0xFFFFu)));
+    }
+    uint2 wl[NT];
+    uint32_t code[NT];
+    // entry of heap index i sits at i - H; the per-tree base stays one SGPR (readfirstlane keeps the
+    // compiler from folding it into the per-lane index: one v_lshl_add per read)
+#pragma unroll
+    for (int k = 0; k < NT; ++k)
+        wl[k] = lds_u32x2((uint32_t)rfl((int)(last_b + 8u * (uint32_t)((t + k) * H - H))) + 8u * idx[k]);
+#pragma unroll
+    for (int k = 0; k < NT; ++k) code[k] = lds_u16(planes_lane_b + (wl[k].x >> 16));
+#pragma unroll
+    for (int k = 0; k < NT; ++k) pidx[k] = pick_half(code[k], wl[k].x, wl[k].y);
+}
+
+template <bool FAST>
 __global__ __launch_bounds__(kK2Threads) void forest3_kernel(const V2Args v) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned shard_off[kShards + 1];
@@ -806,22 +852,41 @@ __global__ __launch_bounds__(kK2Threads) void forest3_kernel(const V2Args v) {
     const int D = pg.D, NL = 1 << D;
     const size_t n_nodes = (size_t)pg.T * NL;
     uint32_t* nodes = reinterpret_cast<uint32_t*>(smem);
-    size_t off = (n_nodes * 4 + 15) & ~(size_t)15;
-    double2* pairs = reinterpret_cast<double2*>(smem + off);
-    float* leaf_f32 = reinterpret_cast<float*>(smem + off);
-    off += pg.kind == UGVC_MODEL_RF ? (size_t)pg.n_pairs * 16 : ((n_nodes * 4 + 15) & ~(size_t)15);
-    uint16_t* leaf_idx = reinterpret_cast<uint16_t*>(smem + off);
-    if (pg.kind == UGVC_MODEL_RF) off += (n_nodes * 2 + 15) & ~(size_t)15;
-    uint16_t* planes_all = reinterpret_cast<uint16_t*>(smem + off);
-    for (size_t k = tid; k < n_nodes; k += blockDim.x) nodes[k] = pg.nodes[k];
-    if (pg.kind == UGVC_MODEL_RF) {
-        for (size_t k = tid; k < (size_t)pg.n_pairs; k += blockDim.x) pairs[k] = pg.pairs[k];
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(pg.leaf_idx);      // T * 2^D halfwords: an even count
-        uint32_t* dst = reinterpret_cast<uint32_t*>(leaf_idx);
-        for (size_t k = tid; k < n_nodes / 2; k += blockDim.x) dst[k] = src[k];
+    size_t off = 0;
+    double2* pairs = nullptr;
+    float* leaf_f32 = nullptr;
+    uint16_t* leaf_idx = nullptr;
+    uint2* last4 = nullptr;
+    double* p1 = nullptr;
+    const int H = NL >> 1;
+    if (FAST) {
+        const size_t n_hi = (size_t)pg.T * H;
+        off = (n_hi * 4 + 15) & ~(size_t)15;
+        last4 = reinterpret_cast<uint2*>(smem + off);
+        off += n_hi * 8;
+        p1 = reinterpret_cast<double*>(smem + off);
+        off += ((size_t)pg.n_pairs * 8 + 15) & ~(size_t)15;
+        for (size_t k = tid; k < n_hi; k += blockDim.x) nodes[k] = pg.hi4[k];
+        for (size_t k = tid; k < n_hi; k += blockDim.x) last4[k] = pg.last4[k];
+        for (size_t k = tid; k < (size_t)pg.n_pairs; k += blockDim.x) p1[k] = pg.p1[k];
     } else {
-        for (size_t k = tid; k < n_nodes; k += blockDim.x) leaf_f32[k] = pg.leaf_f32[k];
+        off = (n_nodes * 4 + 15) & ~(size_t)15;
+        pairs = reinterpret_cast<double2*>(smem + off);
+        leaf_f32 = reinterpret_cast<float*>(smem + off);
+        off += pg.kind == UGVC_MODEL_RF ? (size_t)pg.n_pairs * 16 : ((n_nodes * 4 + 15) & ~(size_t)15);
+        leaf_idx = reinterpret_cast<uint16_t*>(smem + off);
+        if (pg.kind == UGVC_MODEL_RF) off += (n_nodes * 2 + 15) & ~(size_t)15;
+        for (size_t k = tid; k < n_nodes; k += blockDim.x) nodes[k] = pg.nodes[k];
+        if (pg.kind == UGVC_MODEL_RF) {
+            for (size_t k = tid; k < (size_t)pg.n_pairs; k += blockDim.x) pairs[k] = pg.pairs[k];
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(pg.leaf_idx);      // T * 2^D halfwords: an even count
+            uint32_t* dst = reinterpret_cast<uint32_t*>(leaf_idx);
+            for (size_t k = tid; k < n_nodes / 2; k += blockDim.x) dst[k] = src[k];
+        } else {
+            for (size_t k = tid; k < n_nodes; k += blockDim.x) leaf_f32[k] = pg.leaf_f32[k];
+        }
     }
+    uint16_t* planes_all = reinterpret_cast<uint16_t*>(smem + off);
     __syncthreads();
 
     const int P = pg.n_planes;
@@ -854,6 +919,43 @@ __global__ __launch_bounds__(kK2Threads) void forest3_kernel(const V2Args v) {
         }
         double a0 = 0.0, a1 = 0.0;
         float margin = pg.base;
+        float score;
+        uint8_t filt;
+        if (FAST) {
+            const uint32_t hi_b = nodes_b, last_b = lds_addr(last4), p1_b = lds_addr(p1);
+            int t = 0;
+            for (; t + 8 <= T; t += 8) {
+                uint32_t pi[8];
+                walk4<8>(hi_b, last_b, planes_lane_b, t, D, H, pi);
+                double pv[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) pv[k] = lds_f64(p1_b + 8u * pi[k]);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a1 += pv[k];
+            }
+            for (; t < T; ++t) {
+                uint32_t pi[1];
+                walk4<1>(hi_b, last_b, planes_lane_b, t, D, H, pi);
+                a1 += lds_f64(p1_b + 8u * pi[0]);
+            }
+            const double half = 0.5 * (double)T, band = 1e-6 * (double)T;
+            const double pr1 = a1 / (double)T;
+            score = (float)pr1;
+            filt = a1 > half ? UGVC_FILTER_PASS : UGVC_FILTER_LOW_SCORE;
+            // inside the band around T/2 the class-0 sum decides as scikit-learn's argmax does: redo the
+            // walk with both payload sums, in tree order (wave-uniform, rare)
+            if (__builtin_amdgcn_ballot_w64(fabs(a1 - half) <= band) != 0) {
+                double b0 = 0.0, b1 = 0.0;
+                for (int tt = 0; tt < T; ++tt) {
+                    uint32_t pi[1];
+                    walk4<1>(hi_b, last_b, planes_lane_b, tt, D, H, pi);
+                    const double2 pv = pg.pairs[pi[0]];
+                    b0 += pv.x; b1 += pv.y;
+                }
+                const double q0 = b0 / (double)T, q1 = b1 / (double)T;
+                if (fabs(a1 - half) <= band) filt = q1 > q0 ? UGVC_FILTER_PASS : UGVC_FILTER_LOW_SCORE;
+            }
+        } else {
         int t = 0;
         for (; t + 8 <= T; t += 8) {
             int leaf[8];
@@ -872,8 +974,6 @@ __global__ __launch_bounds__(kK2Threads) void forest3_kernel(const V2Args v) {
             if (pg.kind == UGVC_MODEL_RF) { const double2 pv = pairs[leaf_idx[leaf[0]]]; a0 += pv.x; a1 += pv.y; }
             else margin += leaf_f32[leaf[0]];
         }
-        float score;
-        uint8_t filt;
         if (pg.kind == UGVC_MODEL_RF) {
             const double pr0 = a0 / (double)T, pr1 = a1 / (double)T;
             score = (float)pr1;
@@ -882,6 +982,7 @@ __global__ __launch_bounds__(kK2Threads) void forest3_kernel(const V2Args v) {
             score = 1.0f / (1.0f + expf(-margin));
             filt = margin > 0.0f ? UGVC_FILTER_PASS : UGVC_FILTER_LOW_SCORE;
         }
+        }
         if (live) {
             v.f.score[q.w] = score;
             v.f.filter[q.w] = filt;
@@ -889,8 +990,13 @@ __global__ __launch_bounds__(kK2Threads) void forest3_kernel(const V2Args v) {
     }
 }
 
-static size_t k3_lds_bytes(const PackedGroupView& pg, int n_waves) {
+static size_t k3_lds_bytes(const PackedGroupView& pg, int n_waves, bool fast) {
     const size_t NL = (size_t)1 << pg.D, n_nodes = (size_t)pg.T * NL;
+    if (fast) {
+        const size_t n_hi = n_nodes / 2;
+        return ((n_hi * 4 + 15) & ~(size_t)15) + n_hi * 8 + (((size_t)pg.n_pairs * 8 + 15) & ~(size_t)15) +
+               (size_t)n_waves * pg.n_planes * 128;
+    }
     size_t b = (n_nodes * 4 + 15) & ~(size_t)15;
     if (pg.kind == UGVC_MODEL_RF) b += (size_t)pg.n_pairs * 16 + ((n_nodes * 2 + 15) & ~(size_t)15);
     else b += (n_nodes * 4 + 15) & ~(size_t)15;
@@ -904,25 +1010,37 @@ int launch_filter_v3(ugvc_ctx* ctx, const FilterArgs& a) {
     if (v2_fill_args(ctx, v, a.n)) return -1;
     const int64_t nbr = std::max<int64_t>((int64_t)(v.n_blocks + 1) * 8, UGVC_N_GROUPS * kShards);
     hipLaunchKernelGGL(bracket3_kernel, dim3((unsigned)((nbr + 255) / 256)), dim3(256), 0, ctx->stream, v);
-    const int k1_grid = std::min(v.n_blocks, ctx->n_cus * 4);
+    // profiling knobs (tools/tune3.py): bits 12-13 of the kernel variant cap K1's workgroups per CU,
+    // bits 14-15 pick K2's wave count; 0 = the defaults
+    const int k1_bpc = ((a.ablate >> 12) & 3) ? ((a.ablate >> 12) & 3) : 4;
+    const int k2_pick = (a.ablate >> 14) & 3;
+    const int k1_grid = std::min(v.n_blocks, ctx->n_cus * k1_bpc);
     hipLaunchKernelGGL(featurize3_kernel, dim3((unsigned)k1_grid), dim3(kBlock), 0, ctx->stream, v);
     int n_waves = 0;
     size_t lds = 0;
+    // single-sum RF kernel when every uploaded group allows it (kernel variant bit 10 forces the pair kernel)
+    bool fast = !(a.ablate & 1024);
+    for (int g = 0; g < UGVC_N_GROUPS; ++g)
+        if (v.pg[g].ok && !v.pg[g].fast4) fast = false;
     for (int w : {16, 12, 8, 4}) {
+        if (k2_pick && w > (k2_pick == 1 ? 12 : (k2_pick == 2 ? 8 : 4))) continue;
         size_t need = 0;
         for (int g = 0; g < UGVC_N_GROUPS; ++g)
-            if (v.pg[g].ok) need = std::max(need, k3_lds_bytes(v.pg[g], w));
+            if (v.pg[g].ok) need = std::max(need, k3_lds_bytes(v.pg[g], w, fast));
         if (need + 2048 <= 160 * 1024) { n_waves = w; lds = need; break; }
     }
     if (n_waves == 0) return fail("internal: packed forest does not fit LDS");
     if (lds && !(a.ablate & 1)) {
         static bool attr_set = false;
         if (!attr_set) {
-            UGVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(forest3_kernel),
+            UGVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(forest3_kernel<false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+            UGVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(forest3_kernel<true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
             attr_set = true;
         }
-        hipLaunchKernelGGL(forest3_kernel, dim3((unsigned)ctx->n_cus), dim3(n_waves * 64), lds, ctx->stream, v);
+        if (fast) hipLaunchKernelGGL(forest3_kernel<true>, dim3((unsigned)ctx->n_cus), dim3(n_waves * 64), lds, ctx->stream, v);
+        else hipLaunchKernelGGL(forest3_kernel<false>, dim3((unsigned)ctx->n_cus), dim3(n_waves * 64), lds, ctx->stream, v);
     }
     UGVC_HIP(hipGetLastError());
     return 0;

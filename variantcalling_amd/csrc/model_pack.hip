@@ -18,6 +18,10 @@ struct V2Group {
     std::vector<uint16_t> leaf_idx;
     std::vector<double> pairs;
     std::vector<float> leaf_f32;
+    std::vector<uint32_t> hi4;          // single-sum layout (ugvc_v2.hpp)
+    std::vector<uint32_t> last4;        // 2 dwords per entry
+    std::vector<double> p1;
+    bool fast4 = false;
     std::vector<std::vector<float>> uthr;   // sorted unique thresholds per feature
     // pointer-layout copy kept to rebuild the dense tables when the layout changes
     std::vector<int32_t> feature, left, right, roots;
@@ -28,7 +32,7 @@ struct V2Group {
     int n_planes = 0;
     bool layout_done = false;               // dword / bit_off already chosen by the joint (group-uniform) layout
     std::vector<uint32_t> plane_desc;
-    DeviceBuf d_nodes, d_leaf_idx, d_pairs, d_leaf_f32, d_plane_desc;
+    DeviceBuf d_nodes, d_leaf_idx, d_pairs, d_leaf_f32, d_plane_desc, d_hi4, d_last4, d_p1;
 };
 
 struct V2State {
@@ -56,7 +60,7 @@ void v2_destroy(ugvc_ctx* ctx) {
     for (auto* b : bufs) if (b->p) (void)hipFree(b->p);
     for (auto& r : s->rec) if (r.p) (void)hipFree(r.p);
     for (auto& g : s->g)
-        for (DeviceBuf* b : {&g.d_nodes, &g.d_leaf_idx, &g.d_pairs, &g.d_leaf_f32, &g.d_plane_desc}) if (b->p) (void)hipFree(b->p);
+        for (DeviceBuf* b : {&g.d_nodes, &g.d_leaf_idx, &g.d_pairs, &g.d_leaf_f32, &g.d_plane_desc, &g.d_hi4, &g.d_last4, &g.d_p1}) if (b->p) (void)hipFree(b->p);
     delete s;
     ctx->v2 = nullptr;
 }
@@ -162,6 +166,27 @@ static bool pack_group(V2Group& g) {
         }
         g.n_pairs = (int)uniq.size();
         lds += n_slot * 2 + (size_t)g.n_pairs * 16;
+        // single-sum layout
+        const size_t H = (size_t)1 << (D - 1);
+        double dev = 0.0;
+        g.p1.resize((size_t)g.n_pairs);
+        for (int k = 0; k < g.n_pairs; ++k) {
+            g.p1[k] = g.pairs[2 * (size_t)k + 1];
+            const double e = std::fabs(g.pairs[2 * (size_t)k] + g.pairs[2 * (size_t)k + 1] - 1.0);
+            dev = !(e <= dev) ? e : dev;                 // NaN payloads disable the layout
+            if (!(e == e)) dev = 1.0;
+        }
+        g.fast4 = dev <= 1e-9 && T <= 4096;
+        g.hi4.assign((size_t)T * H, 0xFFFFu);
+        g.last4.assign((size_t)T * H * 2, 0u);
+        for (int t = 0; t < T; ++t) {
+            for (size_t i = 1; i < H; ++i) g.hi4[(size_t)t * H + i] = g.nodes[((size_t)t << D) + i];
+            for (size_t e = 0; e < H; ++e) {
+                g.last4[2 * ((size_t)t * H + e)] = g.nodes[((size_t)t << D) + H + e];
+                g.last4[2 * ((size_t)t * H + e) + 1] = (uint32_t)g.leaf_idx[((size_t)t << D) + 2 * e] |
+                                                      ((uint32_t)g.leaf_idx[((size_t)t << D) + 2 * e + 1] << 16);
+            }
+        }
     } else {
         g.leaf_f32.resize(n_slot);
         for (size_t i = 0; i < n_slot; ++i) g.leaf_f32[i] = (float)g.leaf_value[2 * (size_t)slot_leaf[i]];
@@ -300,6 +325,9 @@ int finalize_pack(ugvc_ctx* ctx) {
             if (g.kind == UGVC_MODEL_RF) {
                 if (upload(ctx, g.d_leaf_idx, g.leaf_idx.data(), g.leaf_idx.size() * 2)) return -1;
                 if (upload(ctx, g.d_pairs, g.pairs.data(), g.pairs.size() * 8)) return -1;
+                if (upload(ctx, g.d_hi4, g.hi4.data(), g.hi4.size() * 4)) return -1;
+                if (upload(ctx, g.d_last4, g.last4.data(), g.last4.size() * 4)) return -1;
+                if (upload(ctx, g.d_p1, g.p1.data(), g.p1.size() * 8)) return -1;
             } else if (upload(ctx, g.d_leaf_f32, g.leaf_f32.data(), g.leaf_f32.size() * 4)) return -1;
         }
         UGVC_HIP(hipStreamSynchronize(ctx->stream));
@@ -378,6 +406,10 @@ int v2_fill_args(ugvc_ctx* ctx, V2Args& v, int64_t n) {
         p.leaf_idx = g.d_leaf_idx.as<uint16_t>();
         p.pairs = g.d_pairs.as<double2>();
         p.leaf_f32 = g.d_leaf_f32.as<float>();
+        p.fast4 = g.kind == UGVC_MODEL_RF && g.fast4;
+        p.hi4 = g.d_hi4.as<uint32_t>();
+        p.last4 = g.d_last4.as<uint2>();
+        p.p1 = g.d_p1.as<double>();
         if (ensure(s->rec[gi], (size_t)kShards * shard_cap * 16)) return -1;
         v.records[gi] = s->rec[gi].as<uint4>();
     }

@@ -47,6 +47,14 @@ struct PackedGroupView {
     const uint16_t* leaf_idx;     // RF: T * 2^D
     const double2* pairs;         // RF: n_pairs
     const float* leaf_f32;        // GBT: T * 2^D
+    // RF single-sum layout (forest3_kernel<true>): levels 0..D-2 as a u32 heap of 2^(D-1) dwords per
+    // tree, level D-1 as {node word, left payload index | right payload index << 16} pairs, p1[] =
+    // class-1 probability of every distinct payload.  Usable when every payload has p0 + p1 == 1 to
+    // 1e-9 (then pr1 > pr0 is decided by the class-1 sum alone outside a narrow band around T/2).
+    int fast4;
+    const uint32_t* hi4;          // T * 2^(D-1)
+    const uint2* last4;           // T * 2^(D-1)
+    const double* p1;             // n_pairs
 };
 
 struct V2Args {
