@@ -1,0 +1,88 @@
+/* ugvc_vcf.h - C ABI of the native VCF <-> SoA codec (host side of the hot path).
+ *
+ * Replaces the two per-record pysam loops that bracket featurize -> score -> FILTER in the reference:
+ *   read : ugbio_core.vcfbed.vcftools.get_vcf_df  (body absent; call sites
+ *          /root/reference/ugvc/pipelines/run_no_gt_report.py:307-312, shape quoted in
+ *          /root/reference/ugvc/reports/report_wo_gt.ipynb:1207-1210; field dictionary
+ *          /root/reference/test/resources/unit/vcfbed/test_vcftools/header.txt:3369-3398)
+ *   write: header add + per-record filter.add / info[...] = (in-tree instance of the pattern:
+ *          /root/reference/ugvc/pipelines/vcfbed/calibrate_bridging_snvs.py:101-130; tags
+ *          /root/reference/docs/howto-callset-filter.md:65, ugvc/pipelines/evaluate_concordance.py:47)
+ *
+ * The library (libugvc_vcf.so) has no GPU dependency: BGZF blocks are inflated / deflated and records are
+ * tokenised / spliced on host threads; its output columns are exactly the `ugvc_variants` table of
+ * ugvc_mi355x.h.  Semantics are those of variantcalling_amd/io/vcf.py (the pure-Python host reference the
+ * parity tests compare against, byte for byte): multi-allelic records are featurised on their first ALT,
+ * missing numeric fields read as 0, rows are stably sorted by (contig, pos).
+ *
+ * Conventions: 0 on success, <0 on error with ugvc_vcf_last_error() (thread-local); the handle owns every
+ * array a view points to until ugvc_vcf_free.
+ */
+#ifndef UGVC_VCF_H
+#define UGVC_VCF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ugvc_vcf ugvc_vcf;
+
+typedef struct ugvc_vcf_view {
+    int64_t n;                 /* records == table rows                                               */
+    int64_t pool_bytes;        /* length of `alleles`                                                  */
+    /* ugvc_variants columns, rows sorted by (contig, pos) */
+    const uint8_t* contig;
+    const int32_t* pos;
+    const uint16_t* ref_len;
+    const uint16_t* alt_len;
+    const uint32_t* ref_off;
+    const uint32_t* alt_off;
+    const uint8_t* alleles;    /* base codes N=0 A=1 C=2 G=3 T=4, REF then first ALT of every row      */
+    const float* qual;         /* QUAL, or 10 * max(INFO/TLOD) in mutect mode                          */
+    const float* sor;          /* INFO/SOR                                                             */
+    const int32_t* dp;         /* FORMAT/DP, AD[0], AD[1] of the chosen sample                         */
+    const int32_t* ad_ref;
+    const int32_t* ad_alt;
+    const uint8_t* gq;
+    const uint8_t* gt;         /* 0 hom-ref / no call, 1 het (any allele 1), 2 hom-alt "1/1"           */
+    const float* tlod;         /* max(INFO/TLOD)                                                       */
+    const uint8_t* has_id;     /* ID column != "."                                                     */
+    const int64_t* order;      /* table row k is record order[k] of the file                           */
+    /* text */
+    const char* header;        /* header lines (every line starting with '#'), joined by '\n'          */
+    int64_t header_bytes;
+    const char* text;          /* inflated file; FILTER column of table row k = text[filter_off[k] ..] */
+    const int64_t* filter_off;
+    const int32_t* filter_len;
+} ugvc_vcf_view;
+
+/* Read + inflate (.gz: BGZF blocks in parallel, plain gzip serially) + tokenise `path`.
+ * contig_names: the reference's contig order (index = `contig` column).  sample: 0-based sample column.
+ * n_threads <= 0: one per hardware thread (capped at 64). */
+int ugvc_vcf_read(const char* path, const char* const* contig_names, int n_contigs, int is_mutect, int sample,
+                  int n_threads, ugvc_vcf** out);
+int ugvc_vcf_get_view(const ugvc_vcf* h, ugvc_vcf_view* view);
+
+/* Write the input records in their original order with FILTER := PASS | [HPOL_RUN;][COHORT_FP;][LOW_SCORE],
+ * INFO += TREE_SCORE=<shortest round-trip f32>[;HPOL_RUN] (older TREE_SCORE / HPOL_RUN entries dropped) and
+ * the five header lines if absent.  Result columns are in TABLE order (length n); cohort_extra (nullable)
+ * marks additional COHORT_FP rows.  `out_path` ending in ".gz" is written as BGZF (65280-byte blocks,
+ * zlib level 6, EOF marker). */
+int ugvc_vcf_write_filtered(const ugvc_vcf* h, const char* out_path, const float* tree_score, const uint8_t* filter,
+                            const uint8_t* flags, const uint8_t* cohort_extra, int64_t n, int n_threads);
+
+void ugvc_vcf_free(ugvc_vcf* h);
+const char* ugvc_vcf_last_error(void);
+int ugvc_vcf_abi_version(void);
+
+/* Shortest decimal string that round-trips the f32 (fixed notation, at least one fractional digit):
+ * the TREE_SCORE formatter, exposed for the parity test against numpy.format_float_positional. */
+int ugvc_vcf_format_f32(float x, char* buf, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

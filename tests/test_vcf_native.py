@@ -1,0 +1,197 @@
+"""Native VCF <-> SoA codec (include/ugvc_vcf.h) against the pure-Python host reference `io.vcf`
+(SURVEY.md 8(f) rank 1): identical table columns, identical output bytes (compressed stream included,
+both sides drive zlib level 6 over the same 65280-byte blocks), identical errors.  CPU only."""
+import gzip
+import os
+import re
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+from variantcalling_amd import schema as S, synth
+from variantcalling_amd.io import vcf as pv
+from variantcalling_amd.io import vcf_native as nv
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COLS = ("contig", "pos", "ref_len", "alt_len", "ref_off", "alt_off", "alleles", "qual", "sor", "dp", "ad_ref",
+        "ad_alt", "gq", "gt")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    if not os.path.exists(nv.LIB_PATH):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "variantcalling_amd", "csrc_host")], check=True)
+
+
+def _same_file(a, b, mutect=False):
+    for c in COLS:
+        x, y = getattr(a.table, c), getattr(b.table, c)
+        assert x.dtype == y.dtype and np.array_equal(x, y, equal_nan=x.dtype.kind == "f"), c
+    assert np.array_equal(a.order, b.order) and np.array_equal(a.ids, b.ids)
+    assert a.header == b.header and list(a.orig_filter) == list(b.orig_filter)
+    if mutect:
+        assert np.array_equal(a.tlod, b.tlod)
+    else:
+        assert a.tlod is None and b.tlod is None
+
+
+def test_header_symbols_are_exported():
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "ugvc_vcf.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(ugvc_vcf_[a-z0-9_]+)\s*\(", text)))
+    assert len(names) == 7
+    lib = nv.load_library()
+    for n in names:
+        assert hasattr(lib, n), n
+    out = subprocess.run(["nm", "-D", "--defined-only", nv.LIB_PATH], capture_output=True, text=True).stdout
+    assert set(names) <= set(re.findall(r" T (ugvc_vcf_\w+)", out))
+    assert lib.ugvc_vcf_abi_version() == 1
+    # host-only library: no HIP runtime dependency
+    deps = subprocess.run(["ldd", nv.LIB_PATH], capture_output=True, text=True).stdout
+    assert "amdhip" not in deps and "libz" in deps
+
+
+@pytest.mark.parametrize("threads", [1, 3, 0])
+def test_synthetic_callset_read_and_write_back(tmp_path, threads):
+    cs = synth.make_callset(30_000, genome_len=20_000_000, n_contigs=3, seed=5)
+    vt = cs.variants
+    ids = np.arange(vt.n) % 3 == 0
+    rng = np.random.default_rng(2)
+    res = S.FilterResult(rng.random(vt.n).astype(np.float32), rng.integers(0, 2, vt.n).astype(np.uint8),
+                         rng.integers(0, 8, vt.n).astype(np.uint8))
+    res.tree_score[:6] = [0.0, 1.0, 0.5, 1e-7, 0.333333343, 0.1]
+    cg = rng.random(vt.n) < 0.01
+    for name in ("in.vcf", "in.vcf.gz"):
+        p = str(tmp_path / name)
+        pv.write_vcf_from_table(p, vt, cs.ref.names, ids=ids)
+        a = pv.read_vcf(p, cs.ref.names)
+        b = nv.read_vcf(p, cs.ref.names, n_threads=threads)
+        _same_file(a, b)
+        for c in S.VariantTable.COLS:
+            assert np.array_equal(getattr(b.table, c), getattr(vt, c)), c
+        for out_name in ("o.vcf", "o.vcf.gz"):
+            oa, ob = str(tmp_path / ("py_" + out_name)), str(tmp_path / ("nv_" + out_name))
+            pv.write_filtered_vcf(oa, a, res, cg)
+            nv.write_filtered_vcf(ob, b, res, cg, n_threads=threads)
+            A, B = open(oa, "rb").read(), open(ob, "rb").read()
+            if out_name.endswith(".gz"):
+                assert gzip.decompress(A) == gzip.decompress(B)
+                assert B.endswith(pv._BGZF_EOF) and B[12:14] == b"BC"
+            assert A == B, "output streams differ"
+        b.close()
+
+
+EDGE = ("##fileformat=VCFv4.2\n##FILTER=<ID=LOW_SCORE,Description=\"old\">\n"
+        "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\ts1\ts2\n"
+        "chr2\t50\t.\tA\tG,T\t.\t.\tDP=3;SOR=1.5;TLOD=4.5,7.25\tGT:AD:DP:GQ\t1|1:0,7,1:8:99\t0/0:1,0,0:1:3\n"
+        "chr1\t10\trs5\tAT\tA\t33.5\tLowQual\t.\tGT:DP\t./.:.\t0/1:2\n"
+        "\n"
+        "chr1\t10\t.\tn\t<DEL>\t7\tPASS\tSOR=.\n"
+        "chr1\t7\t.\tACGTN\tacgtn\t1e2\tq10;s50\tTREE_SCORE=0.1;HPOL_RUN;AC=2;;X\tGQ:GT:AD\t300:1/0:5\t-4:0|1|1:2,9\r\n"
+        "##late header line\n"
+        "chr2\t5\t.\tC\tT\tnan\t.\tSOR=0x10;TLOD=-3,-9\tGT:AD:DP:GQ\t1/1/1:3.9,4.2:11.7:-5\n"
+        "chr1\t 12 \t.\tG\tA\t 4.5 \t.\tSOR= 2 \tDP:DP\t3:5\n")
+
+
+@pytest.mark.parametrize("container", ["plain", "gzip", "bgzf"])
+@pytest.mark.parametrize("sample", [0, 1])
+def test_edge_records_match_the_python_reference(tmp_path, container, sample):
+    p = str(tmp_path / ("e.vcf" if container == "plain" else "e.vcf.gz"))
+    data = EDGE.encode()
+    if container == "plain":
+        open(p, "wb").write(data)
+    elif container == "gzip":                       # ordinary multi-member gzip, not BGZF: serial inflate path
+        open(p, "wb").write(gzip.compress(data[:150]) + gzip.compress(data[150:]))
+    else:
+        w = pv._BgzfWriter(p)
+        w.write(data)
+        w.close()
+    names = ["chr1", "chr2"]
+    for mutect in (False, True):
+        a = pv.read_vcf(p, names, is_mutect=mutect, sample=sample)
+        b = nv.read_vcf(p, names, is_mutect=mutect, sample=sample)
+        _same_file(a, b, mutect)
+    assert b.table.n == 6 and len(b.header) == 4
+    res = S.FilterResult(np.array([.5, .25, 1, 0, .75, .125], np.float32), np.array([1, 0, 0, 1, 0, 1], np.uint8),
+                         np.array([0, 1, 2, 3, 7, 0], np.uint8))
+    cg = np.array([0, 0, 0, 0, 1, 1], bool)
+    for out_name in ("o.vcf", "o.vcf.gz"):
+        oa, ob = str(tmp_path / ("py_" + out_name)), str(tmp_path / ("nv_" + out_name))
+        pv.write_filtered_vcf(oa, a, res, cg)
+        nv.write_filtered_vcf(ob, b, res, cg)
+        assert open(oa, "rb").read() == open(ob, "rb").read()
+    txt = open(str(tmp_path / "nv_o.vcf")).read().splitlines()
+    assert sum(x.startswith("##FILTER=<ID=LOW_SCORE") for x in txt) == 1          # existing header line kept, not duplicated
+    rec = [x for x in txt if x.startswith("chr1\t7")][0].split("\t")
+    assert rec[7].startswith("AC=2;;X;TREE_SCORE=") and "TREE_SCORE=0.1" not in rec[7]
+
+
+def test_errors_match_the_python_reference(tmp_path):
+    p = str(tmp_path / "bad.vcf")
+    open(p, "w").write("#CHROM\nchr1\t5\t.\tA\tC\t1\t.\t.\nchr9\t5\t.\tA\tC\t1\t.\t.\nchr1\t5\t.\tA\n")
+    for mod in (pv, nv):
+        with pytest.raises(ValueError, match="contig 'chr9' is not in the reference"):
+            mod.read_vcf(p, ["chr1"])
+        with pytest.raises(ValueError, match=r"record 3 has 4 columns"):
+            mod.read_vcf(p, ["chr1", "chr9"])
+    with pytest.raises(ValueError, match="cannot open"):
+        nv.read_vcf(str(tmp_path / "missing.vcf"), ["chr1"])
+    g = str(tmp_path / "trunc.vcf.gz")
+    w = pv._BgzfWriter(g)
+    w.write(b"#CHROM\n" + b"chr1\t5\t.\tA\tC\t1\t.\t.\n" * 5000)
+    w.close()
+    raw = bytearray(open(g, "rb").read())
+    raw[40] ^= 0xFF                                   # corrupt the first block's deflate payload
+    open(g, "wb").write(bytes(raw))
+    with pytest.raises(ValueError, match="corrupt"):
+        nv.read_vcf(g, ["chr1"])
+    open(str(tmp_path / "empty.vcf"), "w").write("##fileformat=VCFv4.2\n#CHROM\tPOS\n")
+    v = nv.read_vcf(str(tmp_path / "empty.vcf"), ["chr1"])
+    a = pv.read_vcf(str(tmp_path / "empty.vcf"), ["chr1"])
+    assert v.table.n == 0 and a.table.n == 0 and v.header == a.header
+    none = S.FilterResult(np.zeros(0, np.float32), np.zeros(0, np.uint8), np.zeros(0, np.uint8))
+    pv.write_filtered_vcf(str(tmp_path / "e_py.vcf.gz"), a, none)
+    nv.write_filtered_vcf(str(tmp_path / "e_nv.vcf.gz"), v, none)
+    assert open(str(tmp_path / "e_py.vcf.gz"), "rb").read() == open(str(tmp_path / "e_nv.vcf.gz"), "rb").read()
+    with pytest.raises(RuntimeError, match="do not match"):
+        nv.write_filtered_vcf(str(tmp_path / "x.vcf"), v, S.FilterResult(np.zeros(2, np.float32), np.zeros(2, np.uint8),
+                                                                      np.zeros(2, np.uint8)))
+
+
+def test_tree_score_text_is_numpys_shortest_round_trip():
+    rng = np.random.default_rng(11)
+    xs = np.concatenate([rng.random(60_000).astype(np.float32),
+                         (rng.random(20_000) * 1e-4).astype(np.float32),
+                         np.array([0, 1, 0.5, 0.1, 1 / 3, 2 / 3, 1e-7, 1e-10, 3.4e38, 16777216, 0.975, 0.025, 1.17549435e-38],
+                                  np.float32),
+                         (rng.integers(0, 41, 20_000) / np.float64(40)).astype(np.float32)])
+    for x in xs:
+        want = np.format_float_positional(x, unique=True, trim="0")
+        got = nv.format_f32(float(x))
+        assert got == want, (float(x), got, want)
+        assert np.float32(got) == x
+
+
+def test_block_boundaries_follow_the_python_writer(tmp_path):
+    """A stream that is an exact multiple of the BGZF block size ends without an empty data block."""
+    line = b"chr1\t%d\t.\tA\tC\t1\t.\tK=" + b"x" * 30 + b"\n"
+    p = str(tmp_path / "m.vcf")
+    with open(p, "wb") as fh:
+        fh.write(b"#CHROM\n")
+        for k in range(20_000):
+            fh.write(line % (k + 1))
+    a, b = pv.read_vcf(p, ["chr1"]), nv.read_vcf(p, ["chr1"])
+    n = a.table.n
+    res = S.FilterResult(np.full(n, 0.5, np.float32), np.zeros(n, np.uint8), np.zeros(n, np.uint8))
+    pv.write_filtered_vcf(str(tmp_path / "a.vcf.gz"), a, res)
+    nv.write_filtered_vcf(str(tmp_path / "b.vcf.gz"), b, res)
+    A = open(str(tmp_path / "a.vcf.gz"), "rb").read()
+    assert A == open(str(tmp_path / "b.vcf.gz"), "rb").read()
+    # every data block but the last inflates to exactly 65280 bytes
+    off, sizes = 0, []
+    while off < len(A):
+        bsize = int.from_bytes(A[off + 16: off + 18], "little") + 1
+        sizes.append(len(zlib.decompress(A[off + 18: off + bsize - 8], -15)))
+        off += bsize
+    assert sizes[-1] == 0 and all(s == 65280 for s in sizes[:-2]) and 0 < sizes[-2] <= 65280

@@ -1,4 +1,4 @@
-"""Launch-shape sweep of the v3 scoring pass (profiling aid).  Kernel-variant bits: 1 no forest kernel,
+"""Launch-shape sweep of the v3 scoring pass (profiling aid).  Kernel-variant bits: 1 no forest kernel, 32 K1 without column prefetch, 2048 16 trees in flight,
 1024 pair-sum forest kernel, bits 12-13 K1 workgroups per CU (0 = 4), bits 14-15 K2 waves (0 = 16, 1 = 12,
 2 = 8, 3 = 4).  Usage: python tools/tune3.py [n_variants ...]"""
 import os
@@ -32,6 +32,10 @@ for n in sizes:
     print(f"single-sum forest: pass {base:8.1f} us   K0+K1 {k1:8.1f} us   K2 {base - k1:8.1f} us", flush=True)
     pair = t(1024)
     print(f"pair-sum forest:   pass {pair:8.1f} us   K2 {pair - k1:8.1f} us", flush=True)
+    nt8 = t(2048)
+    print(f"16 trees in flight: pass {nt8:8.1f} us   K2 {nt8 - k1:8.1f} us", flush=True)
+    nopf = t(1 | 32)
+    print(f"K1 without column prefetch: K0+K1 {nopf:8.1f} us", flush=True)
     for bpc in (1, 2, 3):
         print(f"K1 {bpc} workgroups/CU: K0+K1 {t(1 | (bpc << 12)):8.1f} us", flush=True)
     for pick, w in ((1, 12), (2, 8), (3, 4)):

@@ -141,6 +141,10 @@ __device__ __forceinline__ int cycle_skip_walk(int L, const uint8_t flow[4], Seq
     return poss ? 1 : 0;
 }
 
+// PF: the six columns that address the second batch of loads (contig, pos, allele lengths and offsets)
+// are fetched one tile ahead, so a tile starts with its window / allele / CSR gathers instead of
+// waiting an HBM round trip for their addresses.
+template <bool PF>
 __global__ __launch_bounds__(kBlock, 4) void featurize3_kernel(const V2Args v) {
     __shared__ uint32_t win[kBlock * kWinStride];                  // 13 KB
     __shared__ int32_t pool[kPool3];                               // 8 KB
@@ -165,6 +169,16 @@ __global__ __launch_bounds__(kBlock, 4) void featurize3_kernel(const V2Args v) {
     for (int k = tid; k <= a.n_contigs; k += kBlock) coff_lds[k] = a.contig_off[k];
     css_lds[tid] = v.css_lut[tid];
     __syncthreads();
+
+    int nc = 0, npos = 0, nrl = 0, nal = 0;
+    uint32_t nro = 0, nao = 0;
+    auto early = [&](int tile_) {
+        const int64_t j_raw = (int64_t)tile_ * kBlock + tid;
+        const int64_t j = j_raw < a.n ? j_raw : a.n - 1;
+        nc = a.contig[j]; npos = a.pos[j]; nrl = a.ref_len[j]; nal = a.alt_len[j];
+        nro = a.ref_off[j]; nao = a.alt_off[j];
+    };
+    if (PF && (int)blockIdx.x < v.n_blocks) early(blockIdx.x);
 
     for (int tile = blockIdx.x; tile < v.n_blocks; tile += gridDim.x) {
         const int64_t i_raw = (int64_t)tile * kBlock + tid;
@@ -203,10 +217,16 @@ __global__ __launch_bounds__(kBlock, 4) void featurize3_kernel(const V2Args v) {
             plan.staged = ok;
             plan.maxbits = maxlen > 0 ? 32 - __builtin_clz((unsigned)maxlen) : 0;
         }
-        const int c = a.contig[i];
-        const int pos = a.pos[i];
-        const int rl = a.ref_len[i], al = a.alt_len[i];
-        const uint32_t ro = a.ref_off[i], ao = a.alt_off[i];
+        int c, pos, rl, al;
+        uint32_t ro, ao;
+        if (PF) {
+            c = nc; pos = npos; rl = nrl; al = nal; ro = nro; ao = nao;
+            const int nt = tile + (int)gridDim.x;
+            early(nt < v.n_blocks ? nt : tile);
+        } else {
+            c = a.contig[i]; pos = a.pos[i]; rl = a.ref_len[i]; al = a.alt_len[i];
+            ro = a.ref_off[i]; ao = a.alt_off[i];
+        }
         const float qual = a.qual[i], sor = a.sor[i];
         const int dp = a.dp[i], adr = a.ad_ref[i], ada = a.ad_alt[i];
         const int gq = a.gq[i];
@@ -793,7 +813,7 @@ __device__ __forceinline__ void walk4(uint32_t hi_b, uint32_t last_b, uint32_t p
     for (int k = 0; k < NT; ++k) pidx[k] = pick_half(code[k], wl[k].x, wl[k].y);
 }
 
-template <bool FAST>
+template <bool FAST, int NTM>
 __global__ __launch_bounds__(kK2Threads) void forest3_kernel(const V2Args v) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned shard_off[kShards + 1];
@@ -924,6 +944,17 @@ __global__ __launch_bounds__(kK2Threads) void forest3_kernel(const V2Args v) {
         if (FAST) {
             const uint32_t hi_b = nodes_b, last_b = lds_addr(last4), p1_b = lds_addr(p1);
             int t = 0;
+            if (NTM > 8) {
+                for (; t + NTM <= T; t += NTM) {
+                    uint32_t pi[NTM];
+                    walk4<NTM>(hi_b, last_b, planes_lane_b, t, D, H, pi);
+                    double pv[NTM];
+#pragma unroll
+                    for (int k = 0; k < NTM; ++k) pv[k] = lds_f64(p1_b + 8u * pi[k]);
+#pragma unroll
+                    for (int k = 0; k < NTM; ++k) a1 += pv[k];
+                }
+            }
             for (; t + 8 <= T; t += 8) {
                 uint32_t pi[8];
                 walk4<8>(hi_b, last_b, planes_lane_b, t, D, H, pi);
@@ -938,15 +969,26 @@ __global__ __launch_bounds__(kK2Threads) void forest3_kernel(const V2Args v) {
                 walk4<1>(hi_b, last_b, planes_lane_b, t, D, H, pi);
                 a1 += lds_f64(p1_b + 8u * pi[0]);
             }
-            const double half = 0.5 * (double)T, band = 1e-6 * (double)T;
+            const double half = 0.5 * (double)T, band = pg.band;
             const double pr1 = a1 / (double)T;
             score = (float)pr1;
             filt = a1 > half ? UGVC_FILTER_PASS : UGVC_FILTER_LOW_SCORE;
-            // inside the band around T/2 the class-0 sum decides as scikit-learn's argmax does: redo the
-            // walk with both payload sums, in tree order (wave-uniform, rare)
+            // inside the band around T/2 (rounding of the two sums, see model_pack.hip) the class-0 sum
+            // decides as scikit-learn's argmax does: redo the walk with both payload sums, in tree order
+            // (wave-uniform, exact ties only in practice)
             if (__builtin_amdgcn_ballot_w64(fabs(a1 - half) <= band) != 0) {
                 double b0 = 0.0, b1 = 0.0;
-                for (int tt = 0; tt < T; ++tt) {
+                int tt = 0;
+                for (; tt + 8 <= T; tt += 8) {
+                    uint32_t pi[8];
+                    walk4<8>(hi_b, last_b, planes_lane_b, tt, D, H, pi);
+                    double2 pv[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) pv[k] = pg.pairs[pi[k]];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { b0 += pv[k].x; b1 += pv[k].y; }
+                }
+                for (; tt < T; ++tt) {
                     uint32_t pi[1];
                     walk4<1>(hi_b, last_b, planes_lane_b, tt, D, H, pi);
                     const double2 pv = pg.pairs[pi[0]];
@@ -1015,7 +1057,9 @@ int launch_filter_v3(ugvc_ctx* ctx, const FilterArgs& a) {
     const int k1_bpc = ((a.ablate >> 12) & 3) ? ((a.ablate >> 12) & 3) : 4;
     const int k2_pick = (a.ablate >> 14) & 3;
     const int k1_grid = std::min(v.n_blocks, ctx->n_cus * k1_bpc);
-    hipLaunchKernelGGL(featurize3_kernel, dim3((unsigned)k1_grid), dim3(kBlock), 0, ctx->stream, v);
+    // kernel variant bit 5 (32): K1 without the one-tile-ahead column prefetch
+    if (a.ablate & 32) hipLaunchKernelGGL(featurize3_kernel<false>, dim3((unsigned)k1_grid), dim3(kBlock), 0, ctx->stream, v);
+    else hipLaunchKernelGGL(featurize3_kernel<true>, dim3((unsigned)k1_grid), dim3(kBlock), 0, ctx->stream, v);
     int n_waves = 0;
     size_t lds = 0;
     // single-sum RF kernel when every uploaded group allows it (kernel variant bit 10 forces the pair kernel)
@@ -1031,16 +1075,17 @@ int launch_filter_v3(ugvc_ctx* ctx, const FilterArgs& a) {
     }
     if (n_waves == 0) return fail("internal: packed forest does not fit LDS");
     if (lds && !(a.ablate & 1)) {
+        using K2 = void (*)(const V2Args);
+        // trees in flight per lane: 8 (16 measured slower: 345 vs 324 us per 5M pass - the LDS pipeline, not
+        // the dependent latency, bounds the walk); kernel variant bit 11 selects 16
+        const K2 fn = !fast ? forest3_kernel<false, 8> : ((a.ablate & 2048) ? forest3_kernel<true, 16> : forest3_kernel<true, 8>);
         static bool attr_set = false;
         if (!attr_set) {
-            UGVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(forest3_kernel<false>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
-            UGVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(forest3_kernel<true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+            for (K2 f : {(K2)forest3_kernel<false, 8>, (K2)forest3_kernel<true, 8>, (K2)forest3_kernel<true, 16>})
+                UGVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
             attr_set = true;
         }
-        if (fast) hipLaunchKernelGGL(forest3_kernel<true>, dim3((unsigned)ctx->n_cus), dim3(n_waves * 64), lds, ctx->stream, v);
-        else hipLaunchKernelGGL(forest3_kernel<false>, dim3((unsigned)ctx->n_cus), dim3(n_waves * 64), lds, ctx->stream, v);
+        hipLaunchKernelGGL(fn, dim3((unsigned)ctx->n_cus), dim3(n_waves * 64), lds, ctx->stream, v);
     }
     UGVC_HIP(hipGetLastError());
     return 0;

@@ -22,6 +22,7 @@ struct V2Group {
     std::vector<uint32_t> last4;        // 2 dwords per entry
     std::vector<double> p1;
     bool fast4 = false;
+    double band4 = 0.0;
     std::vector<std::vector<float>> uthr;   // sorted unique thresholds per feature
     // pointer-layout copy kept to rebuild the dense tables when the layout changes
     std::vector<int32_t> feature, left, right, roots;
@@ -177,6 +178,10 @@ static bool pack_group(V2Group& g) {
             if (!(e == e)) dev = 1.0;
         }
         g.fast4 = dev <= 1e-9 && T <= 4096;
+        // a1 and a0 are T-term f64 sums (error <= T^2 * 2^-53 each) of payloads with p0 + p1 = 1 +- dev:
+        // a1 - a0 = 2 (a1 - T/2) +- (T dev + 2 T^2 2^-53), and the quotients by T keep a strict order once the
+        // difference exceeds a few ulps of T.  Outside this band a1 > T/2 decides; inside, both sums are formed.
+        g.band4 = 2.0 * T * dev + 1e-15 * (double)T * (double)T + 1e-14;
         g.hi4.assign((size_t)T * H, 0xFFFFu);
         g.last4.assign((size_t)T * H * 2, 0u);
         for (int t = 0; t < T; ++t) {
@@ -407,6 +412,7 @@ int v2_fill_args(ugvc_ctx* ctx, V2Args& v, int64_t n) {
         p.pairs = g.d_pairs.as<double2>();
         p.leaf_f32 = g.d_leaf_f32.as<float>();
         p.fast4 = g.kind == UGVC_MODEL_RF && g.fast4;
+        p.band = g.band4;
         p.hi4 = g.d_hi4.as<uint32_t>();
         p.last4 = g.d_last4.as<uint2>();
         p.p1 = g.d_p1.as<double>();

@@ -1,0 +1,771 @@
+// Native VCF <-> SoA codec (include/ugvc_vcf.h).  Host threads only: BGZF blocks are independent deflate
+// streams, so inflate / deflate parallelise per block; records are independent lines, so tokenising and
+// the FILTER / INFO splice parallelise per line range.  Semantics mirror variantcalling_amd/io/vcf.py (the
+// pure-Python host reference; tests/test_vcf_native.py compares both byte for byte).
+#include "../../include/ugvc_vcf.h"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <charconv>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <numeric>
+#include <string>
+#include <string_view>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+int fail(std::string m) {
+    g_err = std::move(m);
+    return -1;
+}
+
+int pick_threads(int n_threads) {
+    if (n_threads > 0) return std::min(n_threads, 256);
+    const unsigned hw = std::thread::hardware_concurrency();
+    return (int)std::min<unsigned>(hw ? hw : 1, 64);
+}
+
+// f(part, lo, hi) over [0, n) cut into `parts` contiguous ranges
+template <class F>
+void parallel_ranges(int64_t n, int parts, F f) {
+    if (parts <= 1 || n < 2) {
+        f(0, (int64_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    th.reserve(parts);
+    for (int p = 0; p < parts; ++p) {
+        const int64_t lo = n * p / parts, hi = n * (p + 1) / parts;
+        th.emplace_back([=, &f] { f(p, lo, hi); });
+    }
+    for (auto& t : th) t.join();
+}
+
+// dynamic work queue: f(item) for item in [0, n)
+template <class F>
+void parallel_items(int64_t n, int threads, F f) {
+    if (threads <= 1 || n < 2) {
+        for (int64_t i = 0; i < n; ++i) f(i);
+        return;
+    }
+    std::atomic<int64_t> next{0};
+    std::vector<std::thread> th;
+    const int T = (int)std::min<int64_t>(threads, n);
+    for (int p = 0; p < T; ++p)
+        th.emplace_back([&] {
+            for (;;) {
+                const int64_t i = next.fetch_add(1);
+                if (i >= n) break;
+                f(i);
+            }
+        });
+    for (auto& t : th) t.join();
+}
+
+inline uint32_t le16(const unsigned char* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+inline uint32_t le32(const unsigned char* p) { return le16(p) | (le16(p + 2) << 16); }
+
+struct Block {
+    size_t c_off, c_len;      // raw deflate payload
+    size_t out_off;
+    uint32_t out_len, crc;
+};
+
+// BGZF = gzip members with FEXTRA subfield 'B','C' (SLEN 2) = total member size - 1
+bool parse_bgzf(const std::vector<unsigned char>& raw, std::vector<Block>& blocks) {
+    size_t p = 0, out = 0;
+    const size_t n = raw.size();
+    while (p < n) {
+        if (n - p < 18) return false;
+        const unsigned char* h = raw.data() + p;
+        if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return false;
+        if (h[3] & ~4) return false;                       // FNAME / FCOMMENT / FHCRC: not BGZF-shaped
+        const size_t xlen = le16(h + 10);
+        if (n - p < 12 + xlen + 8) return false;
+        size_t q = 12, bsize = 0;
+        bool found = false;
+        while (q + 4 <= 12 + xlen) {
+            const size_t slen = le16(h + q + 2);
+            if (h[q] == 'B' && h[q + 1] == 'C' && slen == 2 && q + 6 <= 12 + xlen) {
+                bsize = le16(h + q + 4);
+                found = true;
+            }
+            q += 4 + slen;
+        }
+        if (!found) return false;
+        const size_t total = bsize + 1;
+        if (total < 12 + xlen + 8 || n - p < total) return false;
+        Block b;
+        b.c_off = p + 12 + xlen;
+        b.c_len = total - (12 + xlen) - 8;
+        b.crc = le32(h + total - 8);
+        b.out_len = le32(h + total - 4);
+        b.out_off = out;
+        out += b.out_len;
+        blocks.push_back(b);
+        p += total;
+    }
+    return true;
+}
+
+int inflate_serial(const std::vector<unsigned char>& raw, std::vector<char>& text, const std::string& path) {
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, 16 + MAX_WBITS) != Z_OK) return fail("zlib inflateInit2 failed");
+    text.resize(std::max<size_t>(raw.size() * 4, 1 << 16));
+    zs.next_in = const_cast<unsigned char*>(raw.data());
+    zs.avail_in = (uInt)std::min<size_t>(raw.size(), 1u << 30);
+    size_t in_done = 0, out_done = 0;
+    for (;;) {
+        if (out_done == text.size()) text.resize(text.size() * 2);
+        const size_t room = std::min<size_t>(text.size() - out_done, 1u << 30);
+        zs.next_out = reinterpret_cast<unsigned char*>(text.data() + out_done);
+        zs.avail_out = (uInt)room;
+        const size_t in_before = zs.avail_in;
+        const int rc = inflate(&zs, Z_NO_FLUSH);
+        in_done += in_before - zs.avail_in;
+        out_done += room - zs.avail_out;
+        if (zs.avail_in == 0 && in_done < raw.size()) {
+            zs.next_in = const_cast<unsigned char*>(raw.data() + in_done);
+            zs.avail_in = (uInt)std::min<size_t>(raw.size() - in_done, 1u << 30);
+        }
+        if (rc == Z_STREAM_END) {
+            if (in_done >= raw.size()) break;
+            if (inflateReset(&zs) != Z_OK) { inflateEnd(&zs); return fail(path + ": zlib inflateReset failed"); }
+            continue;                                       // next gzip member
+        }
+        if (rc != Z_OK && rc != Z_BUF_ERROR) { inflateEnd(&zs); return fail(path + ": corrupt gzip stream"); }
+        if (rc == Z_BUF_ERROR && zs.avail_in == 0 && in_done >= raw.size()) { inflateEnd(&zs); return fail(path + ": truncated gzip stream"); }
+    }
+    inflateEnd(&zs);
+    text.resize(out_done);
+    return 0;
+}
+
+int inflate_bgzf(const std::vector<unsigned char>& raw, const std::vector<Block>& blocks, std::vector<char>& text,
+                 int threads, const std::string& path) {
+    const size_t total = blocks.empty() ? 0 : blocks.back().out_off + blocks.back().out_len;
+    text.resize(total);
+    std::atomic<int> bad{0};
+    parallel_items((int64_t)blocks.size(), threads, [&](int64_t i) {
+        const Block& b = blocks[(size_t)i];
+        if (b.out_len == 0) return;
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; return; }
+        zs.next_in = const_cast<unsigned char*>(raw.data() + b.c_off);
+        zs.avail_in = (uInt)b.c_len;
+        zs.next_out = reinterpret_cast<unsigned char*>(text.data() + b.out_off);
+        zs.avail_out = b.out_len;
+        const int rc = inflate(&zs, Z_FINISH);
+        inflateEnd(&zs);
+        if (rc != Z_STREAM_END || zs.avail_out != 0) { bad = 1; return; }
+        if ((uint32_t)crc32(0L, reinterpret_cast<const unsigned char*>(text.data() + b.out_off), b.out_len) != b.crc) bad = 1;
+    });
+    if (bad) return fail(path + ": corrupt BGZF block");
+    return 0;
+}
+
+struct Span {
+    int64_t off;
+    int32_t len;
+};
+
+inline bool is_space(char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f'; }
+
+// Python float(bytes): optional surrounding whitespace, full consumption; hex floats are not accepted
+bool parse_float(const char* s, int len, double& out) {
+    while (len > 0 && is_space(*s)) { ++s; --len; }
+    while (len > 0 && is_space(s[len - 1])) --len;
+    if (len <= 0 || len > 63) return false;
+    char buf[64];
+    for (int i = 0; i < len; ++i) {
+        const char c = s[i];
+        if (c == 'x' || c == 'X' || c == 'p' || c == 'P' || c == '(') return false;
+        buf[i] = c;
+    }
+    buf[len] = 0;
+    char* end = nullptr;
+    const double v = strtod(buf, &end);
+    if (end != buf + len) return false;
+    out = v;
+    return true;
+}
+inline double fnum(const char* s, int len) {
+    double v;
+    return parse_float(s, len, v) ? v : 0.0;
+}
+inline int32_t to_i32(double v) {                           // int(float): truncation toward zero
+    if (!(v == v)) return 0;
+    if (v >= 2147483647.0) return 2147483647;
+    if (v <= -2147483648.0) return (int32_t)-2147483647 - 1;
+    return (int32_t)v;
+}
+
+bool parse_int(const char* s, int len, int64_t& out) {       // Python int(bytes), base 10
+    while (len > 0 && is_space(*s)) { ++s; --len; }
+    while (len > 0 && is_space(s[len - 1])) --len;
+    if (len <= 0) return false;
+    bool neg = false;
+    if (*s == '+' || *s == '-') { neg = *s == '-'; ++s; --len; }
+    if (len <= 0 || len > 18) return false;
+    int64_t v = 0;
+    for (int i = 0; i < len; ++i) {
+        if (s[i] < '0' || s[i] > '9') return false;
+        v = v * 10 + (s[i] - '0');
+    }
+    out = neg ? -v : v;
+    return true;
+}
+
+const char* const kNewHeader[5] = {
+    "##FILTER=<ID=LOW_SCORE,Description=\"Low decision tree score\">",
+    "##FILTER=<ID=HPOL_RUN,Description=\"Homopolymer run\">",
+    "##FILTER=<ID=COHORT_FP,Description=\"Common false positive in the cohort (blacklist)\">",
+    "##INFO=<ID=TREE_SCORE,Number=1,Type=Float,Description=\"Filtering score\">",
+    "##INFO=<ID=HPOL_RUN,Number=0,Type=Flag,Description=\"In or close to homopolymer run\">",
+};
+
+int format_f32(float x, char* buf, int cap) {
+    if (cap < 8) return -1;
+    if (x == 0.0f) { const char* z = std::signbit(x) ? "-0.0" : "0.0"; const int n = (int)strlen(z); memcpy(buf, z, (size_t)n + 1); return n; }
+    if (!(x == x)) { memcpy(buf, "nan", 4); return 3; }
+    if (std::isinf(x)) {
+        const char* s = x < 0 ? "-inf" : "inf";
+        const int n = (int)strlen(s);
+        memcpy(buf, s, (size_t)n + 1);
+        return n;
+    }
+    // shortest round-trip digits (scientific), laid out positionally with zero fill - what
+    // numpy.format_float_positional(x, unique=True, trim="0") prints
+    char sci[48];
+    auto r = std::to_chars(sci, sci + sizeof sci, x, std::chars_format::scientific);
+    if (r.ec != std::errc()) return -1;
+    const char* p = sci;
+    const bool neg = *p == '-';
+    if (neg) ++p;
+    char digits[24];
+    int nd = 0;
+    for (; p < r.ptr && *p != 'e'; ++p)
+        if (*p != '.') digits[nd++] = *p;
+    int ex = 0;
+    if (p < r.ptr && *p == 'e') {
+        ++p;
+        const bool eneg = *p == '-';
+        if (*p == '-' || *p == '+') ++p;
+        for (; p < r.ptr; ++p) ex = ex * 10 + (*p - '0');
+        if (eneg) ex = -ex;
+    }
+    while (nd > 1 && digits[nd - 1] == '0') --nd;
+    const int need = (neg ? 1 : 0) + (ex >= 0 ? std::max(nd, ex + 1) + 2 : -ex + nd + 2) + 1;
+    if (need > cap) return -1;
+    int n = 0;
+    if (neg) buf[n++] = '-';
+    if (ex >= 0) {
+        for (int i = 0; i <= ex; ++i) buf[n++] = i < nd ? digits[i] : '0';
+        buf[n++] = '.';
+        if (nd > ex + 1) for (int i = ex + 1; i < nd; ++i) buf[n++] = digits[i];
+        else buf[n++] = '0';
+    } else {
+        buf[n++] = '0';
+        buf[n++] = '.';
+        for (int i = 0; i < -ex - 1; ++i) buf[n++] = '0';
+        for (int i = 0; i < nd; ++i) buf[n++] = digits[i];
+    }
+    buf[n] = 0;
+    return n;
+}
+
+}  // namespace
+
+struct ugvc_vcf {
+    std::string path;
+    std::vector<char> text;
+    std::vector<Span> hdr_lines;            // file order
+    std::vector<Span> rec_lines;            // file order, without trailing \r / \n
+    std::string header_joined;
+    int64_t n = 0;
+    // table order
+    std::vector<uint8_t> contig, gq, gt, has_id, alleles;
+    std::vector<int32_t> pos, dp, ad_ref, ad_alt, filter_len;
+    std::vector<uint16_t> ref_len, alt_len;
+    std::vector<uint32_t> ref_off, alt_off;
+    std::vector<float> qual, sor, tlod;
+    std::vector<int64_t> order, filter_off;
+};
+
+namespace {
+
+struct Parsed {                              // file order
+    std::vector<uint8_t> contig, gq, gt, has_id;
+    std::vector<int32_t> pos, dp, adr, ada;
+    std::vector<float> qual, sor, tlod;
+    std::vector<Span> ref, alt, filt;
+    void resize(size_t n) {
+        contig.resize(n); gq.resize(n); gt.resize(n); has_id.resize(n);
+        pos.resize(n); dp.resize(n); adr.resize(n); ada.resize(n);
+        qual.resize(n); sor.resize(n); tlod.resize(n);
+        ref.resize(n); alt.resize(n); filt.resize(n);
+    }
+};
+
+// one record line -> file-order columns; returns false with a message on malformed input
+bool parse_record(const char* base, Span line, int64_t k, const std::unordered_map<std::string_view, int>& contig_idx,
+                  int sample, Parsed& P, const std::string& path, std::string& err) {
+    const char* s = base + line.off;
+    const char* e = s + line.len;
+    const int want = 10 + sample;
+    Span f[16];
+    int nf = 0;
+    Span fs{0, 0};                           // the sample column (field 9 + sample)
+    {
+        const char* p = s;
+        for (;;) {
+            const char* t = static_cast<const char*>(memchr(p, '\t', (size_t)(e - p)));
+            const char* fe = t ? t : e;
+            if (nf < 9) f[nf] = Span{(int64_t)(p - base), (int32_t)(fe - p)};
+            if (nf == want - 1) fs = Span{(int64_t)(p - base), (int32_t)(fe - p)};
+            ++nf;
+            if (!t) break;
+            p = t + 1;
+        }
+    }
+    if (nf < 8) {
+        err = path + ": record " + std::to_string(k + 1) + " has " + std::to_string(nf) + " columns";
+        return false;
+    }
+    auto it = contig_idx.find(std::string_view(base + f[0].off, (size_t)f[0].len));
+    if (it == contig_idx.end()) {
+        err = path + ": contig '" + std::string(base + f[0].off, (size_t)f[0].len) + "' is not in the reference";
+        return false;
+    }
+    P.contig[k] = (uint8_t)it->second;
+    int64_t pv;
+    if (!parse_int(base + f[1].off, f[1].len, pv) || pv < INT32_MIN || pv > INT32_MAX) {
+        err = path + ": record " + std::to_string(k + 1) + ": POS '" + std::string(base + f[1].off, (size_t)f[1].len) + "' is not an integer";
+        return false;
+    }
+    P.pos[k] = (int32_t)pv;
+    P.has_id[k] = !(f[2].len == 1 && base[f[2].off] == '.');
+    P.ref[k] = f[3];
+    {
+        const char* a = base + f[4].off;
+        const char* c = static_cast<const char*>(memchr(a, ',', (size_t)f[4].len));
+        P.alt[k] = Span{f[4].off, c ? (int32_t)(c - a) : f[4].len};
+    }
+    if (P.ref[k].len > 65535 || P.alt[k].len > 65535) {
+        err = path + ": record " + std::to_string(k + 1) + ": allele longer than 65535 bases";
+        return false;
+    }
+    P.qual[k] = (float)fnum(base + f[5].off, f[5].len);
+    P.filt[k] = f[6];
+    float sor = 0.f, tlod = 0.f;
+    {
+        const char* p = base + f[7].off;
+        const char* ie = p + f[7].len;
+        while (p <= ie) {
+            const char* t = static_cast<const char*>(memchr(p, ';', (size_t)(ie - p)));
+            const char* fe = t ? t : ie;
+            const int len = (int)(fe - p);
+            if (len >= 4 && memcmp(p, "SOR=", 4) == 0) sor = (float)fnum(p + 4, len - 4);
+            else if (len >= 5 && memcmp(p, "TLOD=", 5) == 0) {
+                double best = 0.0;
+                bool first = true;
+                const char* q = p + 5;
+                while (q <= fe) {
+                    const char* c = static_cast<const char*>(memchr(q, ',', (size_t)(fe - q)));
+                    const char* ce = c ? c : fe;
+                    const double v = fnum(q, (int)(ce - q));
+                    if (first || v > best) best = v;       // Python max(): keeps the first of equals, NaN never wins later
+                    first = false;
+                    if (!c) break;
+                    q = c + 1;
+                }
+                tlod = (float)best;
+            }
+            if (!t) break;
+            p = t + 1;
+        }
+    }
+    P.sor[k] = sor;
+    P.tlod[k] = tlod;
+    int32_t dp = 0, adr = 0, ada = 0;
+    int gq = 0, gt = 0;
+    if (nf > 9 + sample && nf > 9) {
+        const char* kp = base + f[8].off;
+        const char* ke = kp + f[8].len;
+        const char* vp = base + fs.off;
+        const char* ve = vp + fs.len;
+        bool kdone = false, vdone = false;
+        while (!kdone && !vdone) {                          // zip(keys, vals)
+            const char* kt = static_cast<const char*>(memchr(kp, ':', (size_t)(ke - kp)));
+            const char* kfe = kt ? kt : ke;
+            const char* vt = static_cast<const char*>(memchr(vp, ':', (size_t)(ve - vp)));
+            const char* vfe = vt ? vt : ve;
+            const int kl = (int)(kfe - kp), vl = (int)(vfe - vp);
+            if (kl == 2 && kp[0] == 'D' && kp[1] == 'P') dp = to_i32(fnum(vp, vl));
+            else if (kl == 2 && kp[0] == 'A' && kp[1] == 'D') {
+                const char* c = static_cast<const char*>(memchr(vp, ',', (size_t)vl));
+                if (!c) { adr = to_i32(fnum(vp, vl)); ada = 0; }
+                else {
+                    adr = to_i32(fnum(vp, (int)(c - vp)));
+                    const char* c2 = static_cast<const char*>(memchr(c + 1, ',', (size_t)(vfe - c - 1)));
+                    ada = to_i32(fnum(c + 1, (int)((c2 ? c2 : vfe) - c - 1)));
+                }
+            } else if (kl == 2 && kp[0] == 'G' && kp[1] == 'Q') {
+                const int32_t g = to_i32(fnum(vp, vl));
+                gq = g < 0 ? 0 : (g > 255 ? 255 : g);
+            } else if (kl == 2 && kp[0] == 'G' && kp[1] == 'T') {
+                // val.replace("|", "/").split("/"): 2 iff exactly ["1", "1"], else 1 iff any allele == "1"
+                int n_all = 0, n_one = 0;
+                const char* q = vp;
+                for (;;) {
+                    const char* c = q;
+                    while (c < vfe && *c != '/' && *c != '|') ++c;
+                    ++n_all;
+                    if (c - q == 1 && *q == '1') ++n_one;
+                    if (c >= vfe) break;
+                    q = c + 1;
+                }
+                gt = (n_all == 2 && n_one == 2) ? 2 : (n_one > 0 ? 1 : 0);
+            }
+            if (!kt) kdone = true; else kp = kt + 1;
+            if (!vt) vdone = true; else vp = vt + 1;
+        }
+    }
+    P.dp[k] = dp; P.adr[k] = adr; P.ada[k] = ada;
+    P.gq[k] = (uint8_t)gq; P.gt[k] = (uint8_t)gt;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ugvc_vcf_last_error(void) { return g_err.c_str(); }
+int ugvc_vcf_abi_version(void) { return 1; }
+int ugvc_vcf_format_f32(float x, char* buf, int cap) { return buf ? format_f32(x, buf, cap) : -1; }
+
+void ugvc_vcf_free(ugvc_vcf* h) { delete h; }
+
+int ugvc_vcf_read(const char* path, const char* const* contig_names, int n_contigs, int is_mutect, int sample,
+                  int n_threads, ugvc_vcf** out) {
+    if (!path || !out || (n_contigs > 0 && !contig_names)) return fail("NULL argument");
+    if (n_contigs < 0 || n_contigs > 256) return fail("the contig column is u8: at most 256 contigs");
+    if (sample < 0 || sample > 1000000) return fail("bad sample index");
+    *out = nullptr;
+    const int threads = pick_threads(n_threads);
+    std::vector<unsigned char> raw;
+    {
+        FILE* fh = fopen(path, "rb");
+        if (!fh) return fail(std::string(path) + ": cannot open");
+        fseek(fh, 0, SEEK_END);
+        const long sz = ftell(fh);
+        fseek(fh, 0, SEEK_SET);
+        raw.resize(sz > 0 ? (size_t)sz : 0);
+        const size_t got = raw.empty() ? 0 : fread(raw.data(), 1, raw.size(), fh);
+        fclose(fh);
+        if (got != raw.size()) return fail(std::string(path) + ": short read");
+    }
+    std::unique_ptr<ugvc_vcf> h(new ugvc_vcf());
+    h->path = path;
+    if (raw.size() >= 2 && raw[0] == 0x1f && raw[1] == 0x8b) {
+        std::vector<Block> blocks;
+        if (parse_bgzf(raw, blocks)) {
+            if (inflate_bgzf(raw, blocks, h->text, threads, h->path)) return -1;
+        } else if (inflate_serial(raw, h->text, h->path)) return -1;
+        std::vector<unsigned char>().swap(raw);
+    } else {
+        h->text.assign(reinterpret_cast<const char*>(raw.data()), reinterpret_cast<const char*>(raw.data()) + raw.size());
+        std::vector<unsigned char>().swap(raw);
+    }
+    const char* base = h->text.data();
+    const int64_t tn = (int64_t)h->text.size();
+
+    // ---- lines: part p owns the lines that START inside its byte range
+    const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(threads, tn / (1 << 16)));
+    std::vector<std::vector<Span>> hdr_p((size_t)parts), rec_p((size_t)parts);
+    parallel_ranges(tn, parts, [&](int p, int64_t lo, int64_t hi) {
+        int64_t s = lo;
+        if (lo > 0) {
+            const void* nl = memchr(base + lo - 1, '\n', (size_t)(tn - lo + 1));
+            if (!nl) return;
+            s = (const char*)nl - base + 1;
+        }
+        while (s < hi && s < tn) {
+            const void* nl = memchr(base + s, '\n', (size_t)(tn - s));
+            const int64_t e = nl ? (const char*)nl - base : tn;
+            int64_t le = e;
+            while (le > s && (base[le - 1] == '\r' || base[le - 1] == '\n')) --le;
+            if (base[s] == '#' && e > s) hdr_p[(size_t)p].push_back(Span{s, (int32_t)(le - s)});
+            else {
+                bool blank = true;
+                for (int64_t q = s; q < le && blank; ++q) blank = is_space(base[q]);
+                if (!blank) {
+                    if (le - s > INT32_MAX) return;
+                    rec_p[(size_t)p].push_back(Span{s, (int32_t)(le - s)});
+                }
+            }
+            s = e + 1;
+        }
+    });
+    for (int p = 0; p < parts; ++p) {
+        h->hdr_lines.insert(h->hdr_lines.end(), hdr_p[(size_t)p].begin(), hdr_p[(size_t)p].end());
+        h->rec_lines.insert(h->rec_lines.end(), rec_p[(size_t)p].begin(), rec_p[(size_t)p].end());
+    }
+    for (size_t i = 0; i < h->hdr_lines.size(); ++i) {
+        if (i) h->header_joined.push_back('\n');
+        h->header_joined.append(base + h->hdr_lines[i].off, (size_t)h->hdr_lines[i].len);
+    }
+    const int64_t n = (int64_t)h->rec_lines.size();
+    h->n = n;
+
+    // ---- tokenise (file order)
+    std::unordered_map<std::string_view, int> contig_idx;
+    std::vector<std::string> names((size_t)n_contigs);
+    for (int c = 0; c < n_contigs; ++c) names[(size_t)c] = contig_names[c] ? contig_names[c] : "";
+    for (int c = 0; c < n_contigs; ++c) contig_idx[std::string_view(names[(size_t)c])] = c;   // duplicates: the last wins
+    Parsed P;
+    P.resize((size_t)n);
+    const int pparts = (int)std::max<int64_t>(1, std::min<int64_t>(threads, n / 2048));
+    std::vector<std::string> errs((size_t)pparts);
+    std::vector<int64_t> err_at((size_t)pparts, INT64_MAX);
+    parallel_ranges(n, pparts, [&](int p, int64_t lo, int64_t hi) {
+        for (int64_t k = lo; k < hi; ++k)
+            if (!parse_record(base, h->rec_lines[(size_t)k], k, contig_idx, sample, P, h->path, errs[(size_t)p])) {
+                err_at[(size_t)p] = k;
+                return;
+            }
+    });
+    for (int p = 0; p < pparts; ++p)
+        if (err_at[(size_t)p] != INT64_MAX) return fail(errs[(size_t)p]);     // parts are in file order: first error first
+    if (is_mutect)
+        for (int64_t k = 0; k < n; ++k) P.qual[(size_t)k] = 10.0f * P.tlod[(size_t)k];
+
+    // ---- stable order by (contig, pos)
+    h->order.resize((size_t)n);
+    std::iota(h->order.begin(), h->order.end(), (int64_t)0);
+    std::vector<uint64_t> key((size_t)n);
+    for (int64_t k = 0; k < n; ++k)
+        key[(size_t)k] = ((uint64_t)P.contig[(size_t)k] << 32) | (uint32_t)((uint32_t)P.pos[(size_t)k] ^ 0x80000000u);
+    if (!std::is_sorted(key.begin(), key.end()))
+        std::stable_sort(h->order.begin(), h->order.end(), [&](int64_t a, int64_t b) { return key[(size_t)a] < key[(size_t)b]; });
+    std::vector<uint64_t>().swap(key);
+
+    // ---- table columns
+    h->contig.resize((size_t)n); h->gq.resize((size_t)n); h->gt.resize((size_t)n); h->has_id.resize((size_t)n);
+    h->pos.resize((size_t)n); h->dp.resize((size_t)n); h->ad_ref.resize((size_t)n); h->ad_alt.resize((size_t)n);
+    h->ref_len.resize((size_t)n); h->alt_len.resize((size_t)n); h->ref_off.resize((size_t)n); h->alt_off.resize((size_t)n);
+    h->qual.resize((size_t)n); h->sor.resize((size_t)n); h->tlod.resize((size_t)n);
+    h->filter_off.resize((size_t)n); h->filter_len.resize((size_t)n);
+    uint64_t tot = 0;
+    for (int64_t k = 0; k < n; ++k) {
+        const size_t j = (size_t)h->order[(size_t)k];
+        if (tot + (uint64_t)P.ref[j].len > 0xFFFFFFFFull) return fail(h->path + ": allele pool exceeds 4 GiB");
+        h->ref_off[(size_t)k] = (uint32_t)tot;
+        h->alt_off[(size_t)k] = (uint32_t)(tot + (uint64_t)P.ref[j].len);
+        tot += (uint64_t)P.ref[j].len + (uint64_t)P.alt[j].len;
+    }
+    if (tot > 0xFFFFFFFFull) return fail(h->path + ": allele pool exceeds 4 GiB");
+    h->alleles.resize((size_t)tot);
+    uint8_t code[256];
+    memset(code, 0, sizeof code);
+    code['A'] = code['a'] = 1; code['C'] = code['c'] = 2; code['G'] = code['g'] = 3; code['T'] = code['t'] = 4;
+    parallel_ranges(n, pparts, [&](int, int64_t lo, int64_t hi) {
+        for (int64_t k = lo; k < hi; ++k) {
+            const size_t j = (size_t)h->order[(size_t)k], kk = (size_t)k;
+            h->contig[kk] = P.contig[j]; h->pos[kk] = P.pos[j]; h->gq[kk] = P.gq[j]; h->gt[kk] = P.gt[j];
+            h->has_id[kk] = P.has_id[j]; h->dp[kk] = P.dp[j]; h->ad_ref[kk] = P.adr[j]; h->ad_alt[kk] = P.ada[j];
+            h->qual[kk] = P.qual[j]; h->sor[kk] = P.sor[j]; h->tlod[kk] = P.tlod[j];
+            h->ref_len[kk] = (uint16_t)P.ref[j].len; h->alt_len[kk] = (uint16_t)P.alt[j].len;
+            h->filter_off[kk] = P.filt[j].off; h->filter_len[kk] = P.filt[j].len;
+            uint8_t* d = h->alleles.data() + h->ref_off[kk];
+            const unsigned char* r = reinterpret_cast<const unsigned char*>(base + P.ref[j].off);
+            for (int32_t q = 0; q < P.ref[j].len; ++q) d[q] = code[r[q]];
+            d = h->alleles.data() + h->alt_off[kk];
+            const unsigned char* a = reinterpret_cast<const unsigned char*>(base + P.alt[j].off);
+            for (int32_t q = 0; q < P.alt[j].len; ++q) d[q] = code[a[q]];
+        }
+    });
+    *out = h.release();
+    return 0;
+}
+
+int ugvc_vcf_get_view(const ugvc_vcf* h, ugvc_vcf_view* v) {
+    if (!h || !v) return fail("NULL argument");
+    v->n = h->n;
+    v->pool_bytes = (int64_t)h->alleles.size();
+    v->contig = h->contig.data(); v->pos = h->pos.data();
+    v->ref_len = h->ref_len.data(); v->alt_len = h->alt_len.data();
+    v->ref_off = h->ref_off.data(); v->alt_off = h->alt_off.data();
+    v->alleles = h->alleles.data();
+    v->qual = h->qual.data(); v->sor = h->sor.data();
+    v->dp = h->dp.data(); v->ad_ref = h->ad_ref.data(); v->ad_alt = h->ad_alt.data();
+    v->gq = h->gq.data(); v->gt = h->gt.data(); v->tlod = h->tlod.data(); v->has_id = h->has_id.data();
+    v->order = h->order.data();
+    v->header = h->header_joined.data(); v->header_bytes = (int64_t)h->header_joined.size();
+    v->text = h->text.data(); v->filter_off = h->filter_off.data(); v->filter_len = h->filter_len.data();
+    return 0;
+}
+
+int ugvc_vcf_write_filtered(const ugvc_vcf* h, const char* out_path, const float* tree_score, const uint8_t* filter,
+                            const uint8_t* flags, const uint8_t* cohort_extra, int64_t n, int n_threads) {
+    if (!h || !out_path || !tree_score || !filter || !flags) return fail("NULL argument");
+    if (n != h->n) return fail("result columns do not match the record count of the input");
+    const int threads = pick_threads(n_threads);
+    const char* base = h->text.data();
+    const size_t plen = strlen(out_path);
+    const bool gz = plen >= 3 && strcmp(out_path + plen - 3, ".gz") == 0;
+    FILE* fh = fopen(out_path, "wb");
+    if (!fh) return fail(std::string(out_path) + ": cannot open for writing");
+
+    // ---- header
+    std::string stream;
+    {
+        std::vector<std::string_view> hdr, chrom;
+        for (const Span& s : h->hdr_lines) {
+            const std::string_view l(base + s.off, (size_t)s.len);
+            (l.substr(0, 6) == "#CHROM" ? chrom : hdr).push_back(l);
+        }
+        auto have = [&](std::string_view key) {
+            for (const Span& s : h->hdr_lines)
+                if (std::string_view(base + s.off, (size_t)s.len).substr(0, key.size()) == key) return true;
+            return false;
+        };
+        for (auto& l : hdr) { stream.append(l); stream.push_back('\n'); }
+        for (const char* nh : kNewHeader) {
+            const std::string_view full(nh);
+            const std::string_view key = full.substr(0, full.find(','));
+            if (!have(key)) { stream.append(full); stream.push_back('\n'); }
+        }
+        for (auto& l : chrom) { stream.append(l); stream.push_back('\n'); }
+    }
+    std::vector<int64_t> row_of((size_t)n);
+    for (int64_t k = 0; k < n; ++k) row_of[(size_t)h->order[(size_t)k]] = k;
+
+    bool io_ok = true;
+    static const unsigned char kEof[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0,
+                                           0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    constexpr size_t kBlk = 65280;
+    auto flush_blocks = [&](bool final) {                    // emit every full block of `stream` (all of it when final)
+        if (!gz) {
+            if (!stream.empty() && fwrite(stream.data(), 1, stream.size(), fh) != stream.size()) io_ok = false;
+            stream.clear();
+            return;
+        }
+        const size_t nb = final ? (stream.size() + kBlk - 1) / kBlk : stream.size() / kBlk;
+        std::vector<std::string> comp(nb);
+        std::atomic<int> bad{0};
+        parallel_items((int64_t)nb, threads, [&](int64_t b) {
+            const size_t lo = (size_t)b * kBlk, len = std::min(kBlk, stream.size() - lo);
+            z_stream zs;
+            memset(&zs, 0, sizeof zs);
+            if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { bad = 1; return; }
+            std::string& o = comp[(size_t)b];
+            o.resize(18 + deflateBound(&zs, (uLong)len) + 8);
+            zs.next_in = reinterpret_cast<unsigned char*>(const_cast<char*>(stream.data() + lo));
+            zs.avail_in = (uInt)len;
+            zs.next_out = reinterpret_cast<unsigned char*>(&o[18]);
+            zs.avail_out = (uInt)(o.size() - 26);
+            const int rc = deflate(&zs, Z_FINISH);
+            const size_t clen = zs.total_out;
+            deflateEnd(&zs);
+            if (rc != Z_STREAM_END || clen + 25 > 65535) { bad = 1; return; }
+            static const unsigned char hd[16] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 'B', 'C', 0x02, 0};
+            memcpy(&o[0], hd, 16);
+            const uint32_t bsize = (uint32_t)(clen + 25);
+            o[16] = (char)(bsize & 0xff); o[17] = (char)(bsize >> 8);
+            const uint32_t crc = (uint32_t)crc32(0L, reinterpret_cast<const unsigned char*>(stream.data() + lo), (uInt)len);
+            unsigned char* t = reinterpret_cast<unsigned char*>(&o[18 + clen]);
+            for (int i = 0; i < 4; ++i) { t[i] = (unsigned char)(crc >> (8 * i)); t[4 + i] = (unsigned char)((uint32_t)len >> (8 * i)); }
+            o.resize(18 + clen + 8);
+        });
+        if (bad) { io_ok = false; return; }
+        for (auto& o : comp)
+            if (fwrite(o.data(), 1, o.size(), fh) != o.size()) io_ok = false;
+        stream.erase(0, std::min(stream.size(), nb * kBlk));
+    };
+
+    // ---- records, in batches of file-order ranges
+    const int64_t batch = 1 << 18;
+    for (int64_t b0 = 0; b0 < n && io_ok; b0 += batch) {
+        const int64_t b1 = std::min(n, b0 + batch);
+        const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(threads, (b1 - b0) / 1024));
+        std::vector<std::string> part((size_t)parts);
+        parallel_ranges(b1 - b0, parts, [&](int p, int64_t lo, int64_t hi) {
+            std::string& o = part[(size_t)p];
+            o.reserve((size_t)(hi - lo) * 160);
+            char num[64];
+            for (int64_t j = b0 + lo; j < b0 + hi; ++j) {
+                const Span ln = h->rec_lines[(size_t)j];
+                const size_t k = (size_t)row_of[(size_t)j];
+                const char* s = base + ln.off;
+                const char* e = s + ln.len;
+                const char* tab[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+                int nt = 0;
+                for (const char* q = s; nt < 8;) {
+                    const char* t = static_cast<const char*>(memchr(q, '\t', (size_t)(e - q)));
+                    if (!t) break;
+                    tab[nt++] = t;
+                    q = t + 1;
+                }
+                // fields 6 and 7 lie between tab[5]..tab[6] and tab[6]..(tab[7] | e); read validated >= 8 fields
+                if (nt < 7) continue;
+                const char* f6 = tab[5] + 1;
+                const char* f7 = tab[6] + 1;
+                const char* f7e = nt >= 8 ? tab[7] : e;
+                o.append(s, (size_t)(f6 - s));
+                const unsigned fl = flags[k];
+                bool any = false;
+                if (fl & 1u) { o.append("HPOL_RUN"); any = true; }
+                if ((fl & 2u) || (cohort_extra && cohort_extra[k])) { if (any) o.push_back(';'); o.append("COHORT_FP"); any = true; }
+                if (filter[k] == 1) { if (any) o.push_back(';'); o.append("LOW_SCORE"); any = true; }
+                if (!any) o.append("PASS");
+                o.push_back('\t');
+                bool wrote = false;
+                if (!((f7e - f7 == 1 && *f7 == '.') || f7e == f7)) {
+                    const char* q = f7;
+                    for (;;) {
+                        const char* t = static_cast<const char*>(memchr(q, ';', (size_t)(f7e - q)));
+                        const char* fe = t ? t : f7e;
+                        const size_t len = (size_t)(fe - q);
+                        const bool drop = (len >= 11 && memcmp(q, "TREE_SCORE=", 11) == 0) || (len == 8 && memcmp(q, "HPOL_RUN", 8) == 0);
+                        if (!drop) {
+                            if (wrote) o.push_back(';');
+                            o.append(q, len);
+                            wrote = true;
+                        }
+                        if (!t) break;
+                        q = t + 1;
+                    }
+                }
+                if (wrote) o.push_back(';');
+                o.append("TREE_SCORE=");
+                const int nn = format_f32(tree_score[k], num, (int)sizeof num);
+                o.append(num, (size_t)(nn > 0 ? nn : 0));
+                if (fl & 1u) o.append(";HPOL_RUN");
+                o.append(f7e, (size_t)(e - f7e));
+                o.push_back('\n');
+            }
+        });
+        for (auto& p : part) stream.append(p);
+        flush_blocks(false);
+    }
+    if (io_ok) flush_blocks(true);
+    if (io_ok && gz && fwrite(kEof, 1, 28, fh) != 28) io_ok = false;
+    if (fclose(fh) != 0) io_ok = false;
+    if (!io_ok) return fail(std::string(out_path) + ": write failed");
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,142 @@
+"""ctypes binding of the native VCF <-> SoA codec (include/ugvc_vcf.h, csrc_host/vcf_codec.cpp).
+
+`read_vcf` / `write_filtered_vcf` have the signatures and results of `io.vcf` (the pure-Python host
+reference of the same two loops, which tests/test_vcf_native.py compares against byte for byte); the
+pipelines call these.  The library must have been built (`__graft_entry__.build()` /
+`make -C variantcalling_amd/csrc_host`): a missing library raises, there is no silent fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .. import schema as S
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libugvc_vcf.so")
+_lib = None
+
+
+class _View(C.Structure):
+    _fields_ = [("n", C.c_int64), ("pool_bytes", C.c_int64),
+                ("contig", C.c_void_p), ("pos", C.c_void_p), ("ref_len", C.c_void_p), ("alt_len", C.c_void_p),
+                ("ref_off", C.c_void_p), ("alt_off", C.c_void_p), ("alleles", C.c_void_p),
+                ("qual", C.c_void_p), ("sor", C.c_void_p), ("dp", C.c_void_p), ("ad_ref", C.c_void_p),
+                ("ad_alt", C.c_void_p), ("gq", C.c_void_p), ("gt", C.c_void_p), ("tlod", C.c_void_p),
+                ("has_id", C.c_void_p), ("order", C.c_void_p),
+                ("header", C.c_void_p), ("header_bytes", C.c_int64),
+                ("text", C.c_void_p), ("filter_off", C.c_void_p), ("filter_len", C.c_void_p)]
+
+
+def load_library():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` "
+                               "(make -C variantcalling_amd/csrc_host)")
+        lib = C.CDLL(LIB_PATH)
+        lib.ugvc_vcf_last_error.restype = C.c_char_p
+        lib.ugvc_vcf_read.restype = C.c_int
+        lib.ugvc_vcf_read.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.POINTER(C.c_void_p)]
+        lib.ugvc_vcf_get_view.restype = C.c_int
+        lib.ugvc_vcf_get_view.argtypes = [C.c_void_p, C.POINTER(_View)]
+        lib.ugvc_vcf_write_filtered.restype = C.c_int
+        lib.ugvc_vcf_write_filtered.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_int64, C.c_int]
+        lib.ugvc_vcf_free.restype = None
+        lib.ugvc_vcf_free.argtypes = [C.c_void_p]
+        lib.ugvc_vcf_format_f32.restype = C.c_int
+        lib.ugvc_vcf_format_f32.argtypes = [C.c_float, C.c_char_p, C.c_int]
+        lib.ugvc_vcf_abi_version.restype = C.c_int
+        _lib = lib
+    return _lib
+
+
+def _err(lib) -> str:
+    return (lib.ugvc_vcf_last_error() or b"").decode(errors="replace")
+
+
+def _arr(ptr, n, dtype):
+    """Copy of a library-owned column (the handle may be freed before the table is)."""
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype)
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n).copy()
+
+
+class NativeVcfFile:
+    """Same attributes as io.vcf.VcfFile; `records` / `orig_filter` are materialised on first use."""
+
+    def __init__(self, handle, lib, is_mutect):
+        self._h, self._lib = handle, lib
+        v = _View()
+        if lib.ugvc_vcf_get_view(handle, C.byref(v)):
+            raise RuntimeError(_err(lib))
+        n = int(v.n)
+        self.n = n
+        self.header = C.string_at(v.header, v.header_bytes).decode().split("\n") if v.header_bytes else []
+        self.order = _arr(v.order, n, np.int64)
+        self.ids = _arr(v.has_id, n, np.uint8).astype(bool)
+        tl = _arr(v.tlod, n, np.float32)
+        self.tlod = tl if is_mutect else None
+        self.table = S.VariantTable(
+            contig=_arr(v.contig, n, np.uint8), pos=_arr(v.pos, n, np.int32),
+            ref_len=_arr(v.ref_len, n, np.uint16), alt_len=_arr(v.alt_len, n, np.uint16),
+            ref_off=_arr(v.ref_off, n, np.uint32), alt_off=_arr(v.alt_off, n, np.uint32),
+            alleles=_arr(v.alleles, int(v.pool_bytes), np.uint8), qual=_arr(v.qual, n, np.float32),
+            sor=_arr(v.sor, n, np.float32), dp=_arr(v.dp, n, np.int32), ad_ref=_arr(v.ad_ref, n, np.int32),
+            ad_alt=_arr(v.ad_alt, n, np.int32), gq=_arr(v.gq, n, np.uint8), gt=_arr(v.gt, n, np.uint8))
+        self.table.validate()
+        self._orig_filter = None
+
+    @property
+    def orig_filter(self) -> list:
+        if self._orig_filter is None:
+            v = _View()
+            self._lib.ugvc_vcf_get_view(self._h, C.byref(v))
+            off = _arr(v.filter_off, self.n, np.int64)
+            ln = _arr(v.filter_len, self.n, np.int32)
+            self._orig_filter = [C.string_at(v.text + int(o), int(l)).decode() for o, l in zip(off, ln)]
+        return self._orig_filter
+
+    def close(self):
+        if self._h:
+            self._lib.ugvc_vcf_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def read_vcf(path: str, contig_names: list, is_mutect: bool = False, sample: int = 0, n_threads: int = 0) -> NativeVcfFile:
+    lib = load_library()
+    names = (C.c_char_p * len(contig_names))(*[n.encode() for n in contig_names])
+    h = C.c_void_p()
+    if lib.ugvc_vcf_read(os.fsencode(path), names, len(contig_names), int(is_mutect), int(sample), int(n_threads),
+                         C.byref(h)):
+        raise ValueError(_err(lib))
+    return NativeVcfFile(h, lib, is_mutect)
+
+
+def write_filtered_vcf(path: str, vcf: NativeVcfFile, res: S.FilterResult, blacklist_cg: np.ndarray | None = None,
+                       n_threads: int = 0) -> None:
+    lib = load_library()
+    ts = np.ascontiguousarray(res.tree_score, np.float32)
+    fl = np.ascontiguousarray(res.filter, np.uint8)
+    fg = np.ascontiguousarray(res.flags, np.uint8)
+    cg = None if blacklist_cg is None else np.ascontiguousarray(np.asarray(blacklist_cg).astype(bool), np.uint8)
+    if lib.ugvc_vcf_write_filtered(vcf._h, os.fsencode(path), ts.ctypes.data, fl.ctypes.data, fg.ctypes.data,
+                                   None if cg is None else cg.ctypes.data, int(ts.size), int(n_threads)):
+        raise RuntimeError(_err(lib))
+
+
+def format_f32(x: float) -> str:
+    buf = C.create_string_buffer(64)
+    n = load_library().ugvc_vcf_format_f32(float(x), buf, 64)
+    if n < 0:
+        raise RuntimeError("format_f32 failed")
+    return buf.value.decode()

@@ -12,7 +12,7 @@ import logging
 import sys
 
 from .. import model_io
-from ..io import vcf as vcfio
+from ..io import vcf_native as vcfio      # native codec (libugvc_vcf.so); io.vcf is its pure-Python reference
 from . import common
 
 logger = logging.getLogger("ugvc")

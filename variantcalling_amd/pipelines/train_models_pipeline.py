@@ -21,7 +21,7 @@ import sys
 import numpy as np
 
 from .. import evaluate, model_io, schema as S
-from ..io import vcf as vcfio
+from ..io import vcf_native as vcfio      # native codec (libugvc_vcf.so); io.vcf is its pure-Python reference
 from . import common
 
 logger = logging.getLogger("ugvc")
