@@ -159,6 +159,10 @@ int ugvc_forest_gemm(ugvc_ctx* ctx, int group, const int32_t* rows, int64_t n_ro
  * against the full flow-key computation. */
 int ugvc_host_css_lut(const char* flow4, uint8_t out[256]);
 int ugvc_set_kernel_variant(ugvc_ctx* ctx, int variant);
+/* Profiling aid: core-clock cycles wave 0 of every featurize workgroup spent between the kernel's phase
+ * boundaries (kernel variant bit 6 turns the clocks on), summed over workgroups and launches since the
+ * last reset; out[6] = tiles counted. */
+int ugvc_debug_phase_clocks(ugvc_ctx* ctx, uint64_t out[8], int reset);
 
 /* ---- pileup allele/strand/base-quality tally (builder-defined) ---------
  * offsets: n_loci+1 CSR offsets into obs; obs u16 = allele(2b: 0 ref,1 alt,2 other) |

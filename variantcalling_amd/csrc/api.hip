@@ -57,7 +57,7 @@ int build_args(ugvc_ctx* ctx, FilterArgs& a, bool want_x) {
     a.ad_ref = ctx->v_adr.as<int32_t>();
     a.ad_alt = ctx->v_ada.as<int32_t>();
     a.gq = ctx->v_gq.as<uint8_t>();
-    a.ref = ctx->ref.as<uint8_t>();
+    a.ref = ctx->ref.as<uint8_t>() + kRefFrontPad;
     a.contig_off = ctx->contig_off.as<int64_t>();
     a.runs = TrackView{ctx->runs_s.as<int32_t>(), ctx->runs_e.as<int32_t>(), ctx->runs_p.as<int32_t>()};
     a.has_runs = ctx->has_runs;
@@ -107,7 +107,12 @@ int build_args(ugvc_ctx* ctx, FilterArgs& a, bool want_x) {
 // kernel_variant bit 9 (512) forces v2 over v3.
 int launch_score(ugvc_ctx* ctx, const FilterArgs& a) {
     if (!(ctx->kernel_variant & 256) && v2_available(ctx)) {
-        if (!(ctx->kernel_variant & 512) && v3_available(ctx)) return launch_filter_v3(ctx, a);
+        if (!(ctx->kernel_variant & 512) && v3_available(ctx)) {
+            // v4 featurize kernel (single-contig tiles, sentinel-padded joins, packed window arithmetic) under the
+            // v3 preconditions; kernel variant bit 7 (128) keeps v3's
+            if (!(ctx->kernel_variant & 128) && v4_available(ctx)) return launch_filter_v4(ctx, a);
+            return launch_filter_v3(ctx, a);
+        }
         return launch_filter_v2(ctx, a);
     }
     return launch_filter(ctx, a, true, false);
@@ -149,7 +154,7 @@ int ugvc_ctx_destroy(ugvc_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     ugvc_comm_destroy(ctx);
     v2_destroy(ctx);
-    DeviceBuf* all[] = {&ctx->ref, &ctx->contig_off, &ctx->runs_s, &ctx->runs_e, &ctx->runs_p, &ctx->bl,
+    DeviceBuf* all[] = {&ctx->ref, &ctx->contig_off, &ctx->runs_s, &ctx->runs_e, &ctx->runs_p, &ctx->bl, &ctx->bl_ptr, &ctx->v_tiles,
                         &ctx->v_contig, &ctx->v_pos, &ctx->v_rl, &ctx->v_al, &ctx->v_ro, &ctx->v_ao,
                         &ctx->v_alleles, &ctx->v_qual, &ctx->v_sor, &ctx->v_dp, &ctx->v_adr, &ctx->v_ada,
                         &ctx->v_gq, &ctx->r_score, &ctx->r_filter, &ctx->r_flags, &ctx->x_mat, &ctx->x_group,
@@ -200,9 +205,12 @@ int ugvc_ref_upload(ugvc_ctx* ctx, const uint8_t* codes, int64_t total_len, cons
         if (contig_off[c + 1] < contig_off[c]) return fail("contig_off must be non-decreasing");
     UGVC_HIP(hipSetDevice(ctx->device));
     // 64 zero bytes of padding: the v2 kernel reads 16-byte aligned 64-byte windows
-    if (ensure(ctx->ref, (size_t)total_len + 64)) return -1;
-    UGVC_HIP(hipMemsetAsync(static_cast<uint8_t*>(ctx->ref.p) + total_len, 0, 64, ctx->stream));
-    if (upload(ctx, ctx->ref, codes, (size_t)total_len)) return -1;
+    // (and the v4 kernel addresses windows from 32 bytes before a contig's first base: 64 in front too)
+    if (ensure(ctx->ref, (size_t)total_len + 64 + kRefFrontPad)) return -1;
+    UGVC_HIP(hipMemsetAsync(ctx->ref.p, 0, kRefFrontPad, ctx->stream));
+    UGVC_HIP(hipMemsetAsync(static_cast<uint8_t*>(ctx->ref.p) + kRefFrontPad + total_len, 0, 64, ctx->stream));
+    if (total_len) UGVC_HIP(hipMemcpyAsync(static_cast<uint8_t*>(ctx->ref.p) + kRefFrontPad, codes, (size_t)total_len,
+                                           hipMemcpyHostToDevice, ctx->stream));
     if (upload(ctx, ctx->contig_off, contig_off, sizeof(int64_t) * (n_contigs + 1))) return -1;
     UGVC_HIP(hipStreamSynchronize(ctx->stream));
     ctx->n_contigs = n_contigs;
@@ -290,6 +298,12 @@ int ugvc_blacklist_upload(ugvc_ctx* ctx, const uint64_t* keys, int64_t n) {
         if (keys[i] <= keys[i - 1]) return fail("blacklist keys must be sorted and unique");
     UGVC_HIP(hipSetDevice(ctx->device));
     if (upload(ctx, ctx->bl, keys, (size_t)n * 8)) return -1;
+    // CSR by contig id (the contig column is u8): bl_ptr[c] = first key of contig >= c
+    std::vector<int32_t> bp(258, 0);
+    if (n <= std::numeric_limits<int32_t>::max())
+        for (int c = 0; c <= 257; ++c)
+            bp[c] = (int32_t)(std::lower_bound(keys, keys + n, (uint64_t)c << 32) - keys);
+    if (upload(ctx, ctx->bl_ptr, bp.data(), bp.size() * 4)) return -1;
     UGVC_HIP(hipStreamSynchronize(ctx->stream));
     ctx->n_bl = n;
     return 0;
@@ -391,8 +405,17 @@ int ugvc_variants_upload(ugvc_ctx* ctx, const ugvc_variants* v) {
     if (ctx->n_contigs == 0) return fail("upload the reference before variants");
     UGVC_HIP(hipSetDevice(ctx->device));
     const size_t n = (size_t)v->n;
+    // single-contig tiles of <= kBlock consecutive variants (v4 kernel): cut at every contig change
+    std::vector<int2> tiles;
+    tiles.reserve(n / kBlock + 260);
     // host-side validation the kernel relies on (sortedness, contig range, allele bounds)
     for (size_t i = 0; i < n; ++i) {
+        if (n < (size_t)1 << 31) {
+            if (i == 0 || v->contig[i] != v->contig[i - 1] || (tiles.back().y & 0xFFFF) == kBlock)
+                tiles.push_back(make_int2((int)i, 1 | ((int)v->contig[i] << 16)));
+            else
+                tiles.back().y += 1;
+        }
         if (v->contig[i] >= ctx->n_contigs) return fail("contig index out of range at row " + std::to_string(i));
         if (v->ref_len[i] == 0 || v->alt_len[i] == 0) return fail("empty allele at row " + std::to_string(i));
         if ((int64_t)v->ref_off[i] + v->ref_len[i] > v->alleles_len ||
@@ -409,7 +432,12 @@ int ugvc_variants_upload(ugvc_ctx* ctx, const ugvc_variants* v) {
     if (upload(ctx, ctx->v_al, v->alt_len, n * 2)) return -1;
     if (upload(ctx, ctx->v_ro, v->ref_off, n * 4)) return -1;
     if (upload(ctx, ctx->v_ao, v->alt_off, n * 4)) return -1;
+    // 16 zero bytes behind the allele pool: the v4 kernel fetches an allele's tail as one 8-byte load
+    if (ensure(ctx->v_alleles, (size_t)v->alleles_len + 16)) return -1;
+    UGVC_HIP(hipMemsetAsync(static_cast<uint8_t*>(ctx->v_alleles.p) + v->alleles_len, 0, 16, ctx->stream));
     if (upload(ctx, ctx->v_alleles, v->alleles, (size_t)v->alleles_len)) return -1;
+    if (upload(ctx, ctx->v_tiles, tiles.data(), tiles.size() * sizeof(int2))) return -1;
+    ctx->n_tiles4 = (int)tiles.size();
     if (upload(ctx, ctx->v_qual, v->qual, n * 4)) return -1;
     if (upload(ctx, ctx->v_sor, v->sor, n * 4)) return -1;
     if (upload(ctx, ctx->v_dp, v->dp, n * 4)) return -1;
@@ -511,6 +539,11 @@ int ugvc_timed_steps(ugvc_ctx* ctx, int iters, int64_t shard_cap, int gather, fl
 }
 
 int ugvc_n_features(ugvc_ctx* ctx) { return ctx ? UGVC_N_BASE_FEATURES + ctx->n_tracks : -1; }
+
+int ugvc_debug_phase_clocks(ugvc_ctx* ctx, uint64_t out[8], int reset) {
+    if (!ctx || !out) return fail("NULL argument");
+    return v2_phase_clocks(ctx, out, reset);
+}
 
 int ugvc_set_kernel_variant(ugvc_ctx* ctx, int variant) {
     if (!ctx) return fail("ctx is NULL");

@@ -359,7 +359,7 @@ int ugvc_bridging_snvs(ugvc_ctx* ctx, const ugvc_variants* v, const uint8_t* is_
         a.ref_off = ctx->v_ro.as<uint32_t>(); a.alt_off = ctx->v_ao.as<uint32_t>();
         a.alleles = ctx->v_alleles.as<uint8_t>(); a.qual = ctx->v_qual.as<float>(); a.dp = ctx->v_dp.as<int32_t>();
         a.is_pass = dp_.as<uint8_t>(); a.ad_alt_sum = da.as<int32_t>(); a.bg_ad_alt_sum = db.as<int32_t>();
-        a.bg_dp = dd.as<int32_t>(); a.ref = ctx->ref.as<uint8_t>(); a.contig_off = ctx->contig_off.as<int64_t>();
+        a.bg_dp = dd.as<int32_t>(); a.ref = ctx->ref.as<uint8_t>() + kRefFrontPad; a.contig_off = ctx->contig_off.as<int64_t>();
         a.p = *p; a.out_hmer = oh.as<uint8_t>(); a.out_pass = op.as<uint8_t>();
         hipLaunchKernelGGL(bridging_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a);
         if (hipGetLastError() != hipSuccess) rc = fail("bridging kernel launch failed");

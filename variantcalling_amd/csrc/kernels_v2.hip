@@ -4,7 +4,6 @@
 
 namespace ugvc {
 
-int v2_fill_args(ugvc_ctx* ctx, V2Args& v, int64_t n);
 
 __device__ __forceinline__ int lb_i32(const int32_t* __restrict__ a, int lo, int hi, int key) {
     int base = lo, len = hi - lo;          // absolute index of the first element >= key in a[lo:hi)

@@ -27,7 +27,6 @@
 
 namespace ugvc {
 
-int v2_fill_args(ugvc_ctx* ctx, V2Args& v, int64_t n);
 
 constexpr int kWinDw = 12;            // 48-byte reference window per variant
 constexpr int kWinStride = 13;        // dwords per lane row (odd: conflict-free column access)
@@ -170,6 +169,15 @@ __global__ __launch_bounds__(kBlock, 4) void featurize3_kernel(const V2Args v) {
     css_lds[tid] = v.css_lut[tid];
     __syncthreads();
 
+    // phase clocks (tools/phase3.py, kernel variant bit 6): wave 0 accumulates the core-clock cycles between
+    // the phase boundaries of its tiles; slot 6 counts tiles
+    __shared__ unsigned long long prof_lds[8];
+    const bool prof_on = (a.ablate & 64) != 0 && v.prof != nullptr;
+    unsigned long long prof_t = 0;
+    if (prof_on && tid == 0) {
+        for (int k = 0; k < 8; ++k) prof_lds[k] = 0;
+        prof_t = clock64();
+    }
     int nc = 0, npos = 0, nrl = 0, nal = 0;
     uint32_t nro = 0, nao = 0;
     auto early = [&](int tile_) {
@@ -276,6 +284,7 @@ __global__ __launch_bounds__(kBlock, 4) void featurize3_kernel(const V2Args v) {
             }
         }
         __syncthreads();                                      // plan visible
+        if (prof_on && tid == 0) { const unsigned long long now_ = clock64(); prof_lds[1] += now_ - prof_t; prof_t = now_; }
 
         // ---- stage the slices this tile can touch: wave w copies segments w, w+4, w+8, w+12
         const int abl = a.ablate;       // profiling only (tools/ablate3.py): 2 joins, 4 quantise, 8 window features, 16 append
@@ -460,6 +469,7 @@ __global__ __launch_bounds__(kBlock, 4) void featurize3_kernel(const V2Args v) {
             }
         }
         __syncthreads();                                      // staged slices visible
+        if (prof_on && tid == 0) { const unsigned long long now_ = clock64(); prof_lds[2] += now_ - prof_t; prof_t = now_; }
 
         // ---- joins: rank among the starts of every table + blacklist keys, all descents in lock-step
         uint8_t flags = 0;
@@ -605,6 +615,7 @@ __global__ __launch_bounds__(kBlock, 4) void featurize3_kernel(const V2Args v) {
             a.filter[i] = UGVC_FILTER_PASS;
         }
 
+        if (prof_on && tid == 0) { const unsigned long long now_ = clock64(); prof_lds[3] += now_ - prof_t; prof_t = now_; }
         // ---- quantise: feature -> rank among the group's sorted thresholds
         const float vaf = dp > 0 ? __fdiv_rn((float)ada, (float)dp) : 0.0f;
         const uint2* dsc = desc_lds + group * kMaxFeatures;
@@ -718,6 +729,7 @@ __global__ __launch_bounds__(kBlock, 4) void featurize3_kernel(const V2Args v) {
             }
         }
 
+        if (prof_on && tid == 0) { const unsigned long long now_ = clock64(); prof_lds[4] += now_ - prof_t; prof_t = now_; }
         // ---- append {codes, variant index} to the group's sharded record list
         {
             const unsigned b0 = __shfl(slot_base, 0), b1 = __shfl(slot_base, 1), b2 = __shfl(slot_base, 2);
@@ -727,6 +739,10 @@ __global__ __launch_bounds__(kBlock, 4) void featurize3_kernel(const V2Args v) {
                 v.records[group][(size_t)shard * v.shard_cap + sb + grank] = make_uint4(c0, c1, c2, (uint32_t)i);
         }
         __syncthreads();                                      // plan / pool are rewritten by the next tile
+        if (prof_on && tid == 0) { const unsigned long long now_ = clock64(); prof_lds[5] += now_ - prof_t; prof_t = now_; prof_lds[6] += 1; }
+    }
+    if (prof_on && tid == 0) {
+        for (int k = 0; k < 7; ++k) atomicAdd(&v.prof[k], prof_lds[k]);
     }
 }
 
@@ -1055,11 +1071,16 @@ int launch_filter_v3(ugvc_ctx* ctx, const FilterArgs& a) {
     // profiling knobs (tools/tune3.py): bits 12-13 of the kernel variant cap K1's workgroups per CU,
     // bits 14-15 pick K2's wave count; 0 = the defaults
     const int k1_bpc = ((a.ablate >> 12) & 3) ? ((a.ablate >> 12) & 3) : 4;
-    const int k2_pick = (a.ablate >> 14) & 3;
     const int k1_grid = std::min(v.n_blocks, ctx->n_cus * k1_bpc);
     // kernel variant bit 5 (32): K1 without the one-tile-ahead column prefetch
     if (a.ablate & 32) hipLaunchKernelGGL(featurize3_kernel<false>, dim3((unsigned)k1_grid), dim3(kBlock), 0, ctx->stream, v);
     else hipLaunchKernelGGL(featurize3_kernel<true>, dim3((unsigned)k1_grid), dim3(kBlock), 0, ctx->stream, v);
+    return launch_forest3(ctx, v, a);
+}
+
+// K2 over the record lists K1 (v3 or v4) appended
+int launch_forest3(ugvc_ctx* ctx, const V2Args& v, const FilterArgs& a) {
+    const int k2_pick = (a.ablate >> 14) & 3;
     int n_waves = 0;
     size_t lds = 0;
     // single-sum RF kernel when every uploaded group allows it (kernel variant bit 10 forces the pair kernel)

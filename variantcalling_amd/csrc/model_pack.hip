@@ -38,7 +38,7 @@ struct V2Group {
 
 struct V2State {
     V2Group g[UGVC_N_GROUPS];
-    DeviceBuf desc, desc3, lut, thr, css, brackets, brackets3, counters;
+    DeviceBuf desc, desc3, lut, thr, css, brackets, brackets3, counters, prof;
     int thr_bits4[4] = {0, 0, 0, 0};        // descent depth per float feature (qual, sor, vaf, gc), max over groups
     bool uniform_layout = false;            // every group uses the same dword per feature; booleans in fixed slots
     int dw3[kMaxFeatures];                  // that dword
@@ -57,7 +57,7 @@ static V2State* state(ugvc_ctx* ctx) {
 void v2_destroy(ugvc_ctx* ctx) {
     if (!ctx->v2) return;
     V2State* s = static_cast<V2State*>(ctx->v2);
-    DeviceBuf* bufs[] = {&s->desc, &s->desc3, &s->lut, &s->thr, &s->css, &s->brackets, &s->brackets3, &s->counters};
+    DeviceBuf* bufs[] = {&s->desc, &s->desc3, &s->lut, &s->thr, &s->css, &s->brackets, &s->brackets3, &s->counters, &s->prof};
     for (auto* b : bufs) if (b->p) (void)hipFree(b->p);
     for (auto& r : s->rec) if (r.p) (void)hipFree(r.p);
     for (auto& g : s->g)
@@ -393,10 +393,20 @@ bool v2_available(ugvc_ctx* ctx) {
 
 const char* v2_reason(ugvc_ctx* ctx) { return state(ctx)->why.c_str(); }
 
-int v2_fill_args(ugvc_ctx* ctx, V2Args& v, int64_t n) {
+int v2_phase_clocks(ugvc_ctx* ctx, uint64_t out[8], int reset) {
+    V2State* s = state(ctx);
+    UGVC_HIP(hipSetDevice(ctx->device));
+    if (ensure(s->prof, 64)) return -1;
+    UGVC_HIP(hipStreamSynchronize(ctx->stream));
+    UGVC_HIP(hipMemcpy(out, s->prof.p, 64, hipMemcpyDeviceToHost));
+    if (reset) UGVC_HIP(hipMemset(s->prof.p, 0, 64));
+    return 0;
+}
+
+int v2_fill_args(ugvc_ctx* ctx, V2Args& v, int64_t n, int n_tiles) {
     V2State* s = state(ctx);
     if (!s->css.p && build_css_lut(ctx)) return -1;
-    const int n_blocks = (int)((n + kBlock - 1) / kBlock);
+    const int n_blocks = n_tiles > 0 ? n_tiles : (int)((n + kBlock - 1) / kBlock);
     const size_t shard_cap = (size_t)((n_blocks + kShards - 1) / kShards) * kBlock;
     v.shard_cap = (int)shard_cap;
     for (int gi = 0; gi < UGVC_N_GROUPS; ++gi) {
@@ -424,7 +434,7 @@ int v2_fill_args(ugvc_ctx* ctx, V2Args& v, int64_t n) {
     v.thr = s->thr.as<float>();
     v.thr_lds_len = std::min(s->thr_lds_len, 4096);   // kThrLds floats are staged in LDS; the rest is read from L2
     v.css_lut = s->css.as<uint8_t>();
-    v.n_blocks = (int)((n + kBlock - 1) / kBlock);
+    v.n_blocks = n_blocks;
     if (ensure(s->brackets, (size_t)(v.n_blocks + 1) * kJoinArrays * 4)) return -1;
     if (ensure(s->counters, (size_t)UGVC_N_GROUPS * kShards * kCounterStride * 4)) return -1;
     v.brackets = s->brackets.as<int32_t>();
@@ -440,6 +450,10 @@ int v2_fill_args(ugvc_ctx* ctx, V2Args& v, int64_t n) {
     v.na3[0] = ctx->has_runs ? (int)ctx->runs_n : 0;
     for (int t = 0; t < ctx->n_tracks; ++t) v.na3[1 + t] = (int)ctx->trk_n[t];
     v.na3[kJoin3 - 1] = (int)ctx->n_bl;
+    if (ensure(s->prof, 64)) return -1;
+    v.prof = s->prof.as<unsigned long long>();
+    v.tiles4 = ctx->v_tiles.as<int2>();
+    v.bl_ptr = ctx->bl_ptr.as<int32_t>();
     return 0;
 }
 
@@ -475,6 +489,11 @@ int gemm_model(ugvc_ctx* ctx, int group, std::vector<float2>& nodes, std::vector
     leaves.assign((size_t)T * 64, 0.f);
     for (int t = 0; t < T; ++t) gemm_fill(g, t, g.roots[t], 0, 1, nodes, leaves);
     return 0;
+}
+
+bool v4_available(ugvc_ctx* ctx) {
+    return ctx->n_tiles4 > 0 && ctx->n < ((int64_t)1 << 31) && (ctx->n_bl == 0 || ctx->bl_ptr.p != nullptr) &&
+           ctx->n_bl <= std::numeric_limits<int32_t>::max();
 }
 
 bool v3_available(ugvc_ctx* ctx) {

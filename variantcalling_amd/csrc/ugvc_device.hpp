@@ -14,6 +14,7 @@ constexpr int kBlock = 256;                                   // variants per wo
 constexpr int kMaxFeatures = UGVC_N_BASE_FEATURES + UGVC_MAX_TRACKS;
 constexpr int kMotif = 5;
 constexpr int kGcWindow = 10;
+constexpr int kRefFrontPad = 64;                              // zero bytes in front of the reference buffer (v4 window loads)
 
 // 16-byte tree node.  Leaves self-loop (thr = +inf, left = self) so a fixed-depth walk needs
 // no leaf test; `right` of a leaf is its payload row.
@@ -106,7 +107,7 @@ struct ugvc_ctx {
     int64_t runs_n = 0, trk_n[UGVC_MAX_TRACKS] = {0, 0, 0, 0, 0};
     // v3 needs: runs disjoint and sorted; tracks with non-decreasing starts AND ends per contig
     int runs_fast = 1, trk_fast[UGVC_MAX_TRACKS] = {1, 1, 1, 1, 1};
-    ugvc::DeviceBuf bl;
+    ugvc::DeviceBuf bl, bl_ptr;        // bl_ptr: first key of every contig id 0..256 (v4 kernel)
     int64_t n_bl = 0;
     uint8_t flow[4] = {4, 3, 2, 1};   // TGCA
     struct Model {
@@ -119,6 +120,8 @@ struct ugvc_ctx {
     ugvc::DeviceBuf v_contig, v_pos, v_rl, v_al, v_ro, v_ao, v_alleles, v_qual, v_sor, v_dp,
         v_adr, v_ada, v_gq;
     ugvc::DeviceBuf r_score, r_filter, r_flags, x_mat, x_group;
+    ugvc::DeviceBuf v_tiles;           // v4 kernel: int2 {first variant, count | contig << 16} per single-contig tile
+    int n_tiles4 = 0;
     // pileup
     int64_t pl_n = 0, pl_obs = 0;
     ugvc::DeviceBuf pl_off, pl_obsb, pl_out;

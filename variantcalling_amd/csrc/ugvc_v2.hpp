@@ -78,6 +78,10 @@ struct V2Args {
     uint32_t boolmask3[UGVC_N_GROUPS];   // which of the seven 0/1 features (bit f-15) a group's model tests below 1
     int32_t* brackets3;           // [(n_blocks + 1)][8]
     int na3[8];                   // lengths of the searched arrays
+    unsigned long long* prof;     // 8 phase-clock accumulators (profiling aid), or null
+    // v4
+    const int2* tiles4;           // {first variant, count | contig << 16}
+    const int32_t* bl_ptr;        // blacklist CSR by contig id
 };
 
 int pack_model_group(ugvc_ctx* ctx, int g, const int32_t* feature, const float* threshold,
@@ -89,8 +93,13 @@ int build_css_lut(ugvc_ctx* ctx);
 bool v2_available(ugvc_ctx* ctx);
 int launch_filter_v2(ugvc_ctx* ctx, const FilterArgs& a);
 int launch_filter_v3(ugvc_ctx* ctx, const FilterArgs& a);
+int launch_filter_v4(ugvc_ctx* ctx, const FilterArgs& a);
+int launch_forest3(ugvc_ctx* ctx, const V2Args& v, const FilterArgs& a);
+bool v4_available(ugvc_ctx* ctx);
+int v2_fill_args(ugvc_ctx* ctx, V2Args& v, int64_t n, int n_tiles = 0);
 bool v3_available(ugvc_ctx* ctx);
 void v2_destroy(ugvc_ctx* ctx);
 const char* v2_reason(ugvc_ctx* ctx);
+int v2_phase_clocks(ugvc_ctx* ctx, uint64_t out[8], int reset);
 
 }  // namespace ugvc

@@ -71,6 +71,7 @@ ABI = {
     "ugvc_forest_gemm": (C.c_int, [_ctx, C.c_int, _i32p, C.c_int64, C.c_int, C.c_int, _f32p, _f32p]),
     "ugvc_host_css_lut": (C.c_int, [C.c_char_p, _u8p]),
     "ugvc_set_kernel_variant": (C.c_int, [_ctx, C.c_int]),
+    "ugvc_debug_phase_clocks": (C.c_int, [_ctx, C.POINTER(C.c_uint64), C.c_int]),
     "ugvc_pileup_tally": (C.c_int, [_ctx, _i64p, _u16p, C.c_int64, C.POINTER(CPileupOut)]),
     "ugvc_pileup_upload": (C.c_int, [_ctx, _i64p, _u16p, C.c_int64]),
     "ugvc_timed_pileup": (C.c_int, [_ctx, C.c_int, _f32p]),
@@ -205,6 +206,11 @@ class Engine:
 
     def set_kernel_variant(self, v: int):
         self._check(self.lib.ugvc_set_kernel_variant(self._h, v))
+
+    def phase_clocks(self, reset: bool = True) -> list:
+        out = (C.c_uint64 * 8)()
+        self._check(self.lib.ugvc_debug_phase_clocks(self._h, out, int(reset)))
+        return list(out)
 
     # ---- hot path
     def _cvariants(self, vt: S.VariantTable) -> CVariants:
