@@ -40,7 +40,7 @@ def test_library_is_loaded_in_tree(engine):
         assert "libugvc_mi355x.so" in fh.read()
 
 
-PATHS = pytest.mark.parametrize("path", [0, 128, 512, 256], ids=["v4-sentinel", "v3-lockstep", "v2-lds-forest", "v1-universal"])
+PATHS = pytest.mark.parametrize("path", [0, 128, 512, 256], ids=["v3-lockstep", "v4-sentinel", "v2-lds-forest", "v1-universal"])
 
 
 @pytest.fixture(autouse=True)
@@ -117,7 +117,7 @@ def test_gbt_model(engine, small_callset, frozen_models, path):
     assert np.max(np.abs(res.tree_score - exp.tree_score)) <= 1e-6
 
 
-@pytest.mark.parametrize("path", [0, 128], ids=["v4-sentinel", "v3-lockstep"])
+@pytest.mark.parametrize("path", [0, 128], ids=["v3-lockstep", "v4-sentinel"])
 def test_v3_fallbacks_and_dense_tiles(engine, frozen_models, path):
     """v3 / v4 preconditions: (i) a tile whose side-table slices overflow the LDS pool takes the HBM
     search path; (ii) overlapping intervals with sorted ends stay on v3; (iii) a track whose ends
@@ -353,7 +353,7 @@ def _stump_forest(specs, n_features=20):
                         n_features=n_features, max_depth=1)
 
 
-@pytest.mark.parametrize("path", [0, 1024, 128, 512, 256], ids=["v4-single-sum", "v4-pair-sums", "v3-single-sum", "v2", "v1"])
+@pytest.mark.parametrize("path", [0, 1024, 128, 512, 256], ids=["v3-single-sum", "v3-pair-sums", "v4-single-sum", "v2", "v1"])
 def test_rf_vote_ties_and_unnormalised_payloads(engine, small_callset, path):
     """The single-sum forest kernel decides PASS on the class-1 sum alone and must fall back to both
     sums where scikit-learn's argmax is decided by them: exact ties (pure leaves, even T), near ties
