@@ -385,6 +385,33 @@ def test_rf_vote_ties_and_unnormalised_payloads(engine, small_callset, path):
         engine.set_kernel_variant(0)
 
 
+@PATHS
+def test_code_table_edges(engine, small_callset, path):
+    """Integer features are quantised through code tables that reach one past the model's top threshold (larger
+    values take the last entry) and are cut at 8192 entries (larger values search the thresholds); negative
+    values always search.  Thresholds around both limits, values on both sides."""
+    import copy
+    cs = small_callset
+    O = _oracle()
+    vt = copy.deepcopy(cs.variants)
+    rng = np.random.default_rng(3)
+    n = vt.n
+    vt.dp = vt.dp.copy(); vt.ad_alt = vt.ad_alt.copy(); vt.ad_ref = vt.ad_ref.copy()
+    pick = rng.permutation(n)
+    vt.dp[pick[:400]] = rng.choice([0, 1, 59, 60, 61, 62, 8190, 8191, 8192, 8193, 8999, 9000, 9001, 20000, 2**31 - 1], 400)
+    vt.dp[pick[400:600]] = rng.choice([-1, -3, -(2**31)], 200)
+    vt.ad_alt[pick[600:800]] = rng.choice([-2, 0, 41, 42, 43, 100000], 200)
+    specs = [(2, 60.5, (0.9, 0.1), (0.2, 0.8)), (2, 9000.5, (0.3, 0.7), (0.6, 0.4)), (2, 8190.5, (0.7, 0.3), (0.4, 0.6)),
+             (4, 41.5, (0.8, 0.2), (0.1, 0.9)), (4, -0.5, (0.25, 0.75), (0.5, 0.5)), (3, 12.5, (0.35, 0.65), (0.65, 0.35))]
+    forests = [_stump_forest(specs)] * 3
+    _configure(engine, cs.ref, cs.runs, cs.tracks, cs.blacklist, forests)
+    engine.set_kernel_variant(path)
+    res = engine.filter_variants(vt)
+    exp = O.filter_variants(vt, cs.ref, cs.runs, cs.tracks, cs.blacklist, forests)
+    _assert_same(res, exp, "code tables")
+    assert len(np.unique(exp.tree_score)) > 4
+
+
 def test_rccl_gather_path_single_rank(small_callset, frozen_models):
     """The N > 1 data path (RCCL all-gather of the three result columns on its own stream, overlapped
     with the next scoring pass) exercised with a one-rank communicator: librccl is dlopen'ed, the

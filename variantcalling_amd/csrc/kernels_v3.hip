@@ -696,7 +696,7 @@ __global__ __launch_bounds__(kBlock, 4) void featurize3_kernel(const V2Args v) {
                     const uint32_t x = (uint32_t)iv[j];
                     const uint32_t idx = x < len ? x : len - 1;
                     code[j] = v.lut[(d.x & 0xFFFFFu) + idx];
-                    slow |= (d.x >> 30) == 1 && x >= len;
+                    slow |= x >= len && ((d.x >> 30) == 1 || (int32_t)x < 0);        // past a cut table, or negative
                 }
                 if (slow) {                                       // value beyond the LUT: search the thresholds in HBM
 #pragma unroll
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(kBlock, 4) void featurize3_kernel(const V2Args v) {
                         if (j == 5 || j == 13) continue;
                         if (j >= F) break;
                         const uint2 d = dsc[j];
-                        if ((d.x >> 30) == 1 && (uint32_t)iv[j] >= (d.y & 0xFFFFu)) {
+                        if ((uint32_t)iv[j] >= (d.y & 0xFFFFu) && ((d.x >> 30) == 1 || iv[j] < 0)) {
                             const FeatDesc fd = v.desc[group * kMaxFeatures + j];
                             const uint32_t toff = fd.thr & 0xFFFFF, tlen = fd.thr >> 20;
                             const float x = (float)iv[j];

@@ -309,7 +309,9 @@ int finalize_pack(ugvc_ctx* ctx) {
                         d.lut = (uint32_t)lut.size() | (1u << 30);
                         d.lut_len = (uint32_t)len;
                         for (int v = 0; v < len; ++v) lut.push_back((uint16_t)count_code(g, f, (float)v));
-                        d3 = make_uint2((d.lut & 0xFFFFFu) | (1u << 30), (uint32_t)len | pk3);
+                        // kind 3: the table reaches one past the top threshold, so every larger value takes its last
+                        // entry (no threshold search); kind 1: table cut at 8192 entries, larger values search
+                        d3 = make_uint2((d.lut & 0xFFFFFu) | ((top + 2.0 <= 8192.0 ? 3u : 1u) << 30), (uint32_t)len | pk3);
                     }
                 }
                 if (pass == 0 && gi == UGVC_N_GROUPS - 1) s->thr_lds_len = (int)thr.size();
