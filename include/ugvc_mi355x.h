@@ -164,6 +164,22 @@ int ugvc_set_kernel_variant(ugvc_ctx* ctx, int variant);
  * last reset; out[6] = tiles counted. */
 int ugvc_debug_phase_clocks(ugvc_ctx* ctx, uint64_t out[8], int reset);
 
+/* ---- score evaluation on the GPU ----------------------------------
+ * ugvc_eval_counts: integer counts under the accuracy table of `train_models_pipeline --evaluate_concordance`
+ * (calc_accuracy_metrics: ugvc/pipelines/evaluate_concordance.py:27,100; group names
+ * test/resources/system/test_evaluate_concordance/expected.out.stats.csv:1-10) on the RESIDENT FILTER column of the
+ * last scoring pass.  label[i]: 1 true call, 0 false call, <0 unlabelled; cat_bits[i]: bit c set = row belongs to
+ * category c (<= 16); out[c] = {true, false, true & PASS, false & PASS}.
+ * ugvc_pr_curve: cumulative recall / precision / f1 curve of ReportUtils.__calc_performance
+ * (ugvc/reports/report_utils.py:494-504; formulas ugvc/utils/stats_utils.py:76-138): rows sorted by score
+ * ascending (stable; NaN last), cls[i] = 1 tp / 2 fp / 0 other; per position c_fn = initial_fn + cumsum(tp),
+ * c_tp = initial_tp - cumsum(tp), c_fp = initial_fp - cumsum(fp).  Outputs have n entries; order (nullable) = the
+ * permutation; ms_device (nullable) = device time of sort + scans + finish. */
+int ugvc_eval_counts(ugvc_ctx* ctx, const int8_t* label, const uint16_t* cat_bits, int64_t out[16][4]);
+int ugvc_pr_curve(ugvc_ctx* ctx, const double* score, const uint8_t* cls, int64_t n, int64_t initial_tp, int64_t initial_fp,
+                  int64_t initial_fn, double* sorted_score, double* recall, double* precision, double* f1, int32_t* order,
+                  float* ms_device);
+
 /* ---- pileup allele/strand/base-quality tally (builder-defined) ---------
  * offsets: n_loci+1 CSR offsets into obs; obs u16 = allele(2b: 0 ref,1 alt,2 other) |
  * strand<<2 | bq<<3. */

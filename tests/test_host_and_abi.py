@@ -53,7 +53,10 @@ def test_library_is_gfx950_only(lib):
         assert targets and all("gfx950" in t for t in targets), targets
     else:                                  # bundle section not listable on a .so: look for the ISA name
         blob = open(eng_mod.LIB_PATH, "rb").read()
-        assert b"gfx950" in blob and b"gfx90a" not in blob and b"gfx942" not in blob
+        # offload-bundle entry ids name the ISA of every embedded code object (rocPRIM's host-side target-name
+        # table mentions other ISAs as plain strings; those are not code objects)
+        isas = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-f]+)", blob))
+        assert isas == {b"gfx950"}, isas
 
 
 def test_no_gpu_fails_loudly(lib):

@@ -181,6 +181,13 @@ def test_calc_performance_and_accuracy_table():
     snp = rows[0]
     assert snp["tp"] + snp["fn"] == snp["initial_tp"] and snp["fp"] <= snp["initial_fp"]
     assert rows[7]["initial_tp"] == sum(r["initial_tp"] for r in rows[1:7])
+    # the same rows from integer counts (what Engine.eval_counts returns) and the category bit layout
+    indel, hm, lab = rng.random(n) < 0.2, rng.integers(0, 16, n), rng.random(n) < 0.5
+    bits = evaluate.category_bits(indel, hm)
+    assert bits.dtype == np.uint16 and (bits >> len(evaluate.CATEGORIES) == 0).all()
+    cnt = [[int((m & lab).sum()), int((m & ~lab).sum()), int((m & lab & passed).sum()), int((m & ~lab & passed).sum())]
+           for m in (((bits >> c) & 1).astype(bool) for c in range(len(evaluate.CATEGORIES)))]
+    assert evaluate.accuracy_rows(cnt) == evaluate.accuracy_table(score, passed, lab, indel, hm)
 
 
 def test_pipelines_help_and_fail_loudly_without_gpu(tmp_path, capsys, cs):

@@ -72,6 +72,10 @@ ABI = {
     "ugvc_host_css_lut": (C.c_int, [C.c_char_p, _u8p]),
     "ugvc_set_kernel_variant": (C.c_int, [_ctx, C.c_int]),
     "ugvc_debug_phase_clocks": (C.c_int, [_ctx, C.POINTER(C.c_uint64), C.c_int]),
+    "ugvc_eval_counts": (C.c_int, [_ctx, C.POINTER(C.c_int8), C.POINTER(C.c_uint16), C.POINTER(C.c_int64)]),
+    "ugvc_pr_curve": (C.c_int, [_ctx, C.POINTER(C.c_double), _u8p, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                _i32p, _f32p]),
     "ugvc_pileup_tally": (C.c_int, [_ctx, _i64p, _u16p, C.c_int64, C.POINTER(CPileupOut)]),
     "ugvc_pileup_upload": (C.c_int, [_ctx, _i64p, _u16p, C.c_int64]),
     "ugvc_timed_pileup": (C.c_int, [_ctx, C.c_int, _f32p]),
@@ -206,6 +210,35 @@ class Engine:
 
     def set_kernel_variant(self, v: int):
         self._check(self.lib.ugvc_set_kernel_variant(self._h, v))
+
+    # ---- score evaluation (consumers of the resident FILTER / tree_score columns)
+    def eval_counts(self, label: np.ndarray, cat_bits: np.ndarray) -> np.ndarray:
+        """int64 [16, 4] = per category {true, false, true & PASS, false & PASS} over the resident FILTER column;
+        label: 1 true / 0 false / < 0 unlabelled, cat_bits: u16 category membership bits."""
+        lab = np.ascontiguousarray(label, np.int8)
+        cb = np.ascontiguousarray(cat_bits, np.uint16)
+        if lab.size != self.n or cb.size != self.n:
+            raise ValueError("label / cat_bits must have one entry per resident variant")
+        out = np.zeros((16, 4), np.int64)
+        self._check(self.lib.ugvc_eval_counts(self._h, lab.ctypes.data_as(C.POINTER(C.c_int8)),
+                                              cb.ctypes.data_as(C.POINTER(C.c_uint16)),
+                                              out.ctypes.data_as(C.POINTER(C.c_int64))))
+        return out
+
+    def pr_curve(self, score: np.ndarray, cls: np.ndarray, initial_tp: int, initial_fp: int, initial_fn: int,
+                 want_order: bool = False):
+        """(sorted score, recall, precision, f1[, order], device ms): evaluate.calc_performance's curve on the GPU."""
+        s = np.ascontiguousarray(score, np.float64)
+        c = np.ascontiguousarray(cls, np.uint8)
+        n = s.size
+        out = [np.zeros(n, np.float64) for _ in range(4)]
+        order = np.zeros(n, np.int32) if want_order else None
+        ms = C.c_float()
+        dp = C.POINTER(C.c_double)
+        self._check(self.lib.ugvc_pr_curve(self._h, s.ctypes.data_as(dp), _p(c, _u8p), n, int(initial_tp), int(initial_fp),
+                                           int(initial_fn), *[o.ctypes.data_as(dp) for o in out],
+                                           None if order is None else _p(order, _i32p), C.byref(ms)))
+        return (*out, order, ms.value)
 
     def phase_clocks(self, reset: bool = True) -> list:
         out = (C.c_uint64 * 8)()

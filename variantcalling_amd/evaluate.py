@@ -111,7 +111,9 @@ def calc_performance(score, passed, tp, fp, fn, missing_candidate=None, curve: b
            "miss_candidate": n_miss}
     if not curve or score.size < 10:
         return res, None
-    order = np.argsort(s, kind="quicksort")       # pandas sort_values default
+    # pandas sort_values' default quicksort leaves the order inside a run of equal scores unspecified; BUILDER-DEFINED:
+    # stable (input order), which is also what the GPU curve (Engine.pr_curve: stable radix sort) produces
+    order = np.argsort(s, kind="stable")
     ctp = np.cumsum(tp[order])
     cfp = np.cumsum(fp[order])
     c_fn = i_fn + ctp
@@ -137,17 +139,20 @@ def category_masks(indel, hmer_len):
             "INDELS": indel, "H-INDELS": indel & (h > 0)}
 
 
-def accuracy_table(score, passed, label_tp, indel, hmer_len, ignored_pass=None):
-    """Per-category tp/fp/fn/precision/recall/f1 before ('initial_*') and after filtering for scored CALLS
-    with a true/false label (no un-called truth variants: fn counts only filtered true calls).
-    `ignored_pass`: rows whose only filter is an ignored one (HPOL_RUN,
-    evaluate_concordance.py:44-48) count as passing."""
-    passed = np.asarray(passed, bool) if ignored_pass is None else (np.asarray(passed, bool) | np.asarray(ignored_pass, bool))
-    label_tp = np.asarray(label_tp, bool)
+def category_bits(indel, hmer_len) -> np.ndarray:
+    """u16 per row: bit c set = the row belongs to CATEGORIES[c] (the layout Engine.eval_counts takes)."""
+    bits = np.zeros(np.asarray(indel).shape[0], np.uint16)
+    for c, m in enumerate(category_masks(indel, hmer_len).values()):
+        bits |= (m.astype(np.uint16) << np.uint16(c))
+    return bits
+
+
+def accuracy_rows(counts) -> list:
+    """Accuracy-table rows from integer counts[c] = (true, false, true & passing, false & passing) per category -
+    the counts come from the host (`accuracy_table`) or from the GPU (`Engine.eval_counts`)."""
     rows = []
-    for name, m in category_masks(indel, hmer_len).items():
-        tp0 = int((label_tp & m).sum()); fp0 = int((~label_tp & m).sum())
-        tp1 = int((label_tp & m & passed).sum()); fp1 = int((~label_tp & m & passed).sum())
+    for c, name in enumerate(CATEGORIES):
+        tp0, fp0, tp1, fp1 = (int(x) for x in counts[c][:4])
         fn1 = tp0 - tp1
         p1, r1 = float(get_precision(fp1, tp1)), float(get_recall(fn1, tp1))
         p0, r0 = float(get_precision(fp0, tp0)), float(get_recall(0, tp0))
@@ -156,3 +161,17 @@ def accuracy_table(score, passed, label_tp, indel, hmer_len, ignored_pass=None):
                          initial_precision=round(p0, 5), initial_recall=round(r0, 5),
                          initial_f1=round(float(get_f1(p0, r0)), 5)))
     return rows
+
+
+def accuracy_table(score, passed, label_tp, indel, hmer_len, ignored_pass=None):
+    """Per-category tp/fp/fn/precision/recall/f1 before ('initial_*') and after filtering for scored CALLS
+    with a true/false label (no un-called truth variants: fn counts only filtered true calls).
+    `ignored_pass`: rows whose only filter is an ignored one (HPOL_RUN,
+    evaluate_concordance.py:44-48) count as passing."""
+    passed = np.asarray(passed, bool) if ignored_pass is None else (np.asarray(passed, bool) | np.asarray(ignored_pass, bool))
+    label_tp = np.asarray(label_tp, bool)
+    counts = []
+    for m in category_masks(indel, hmer_len).values():
+        counts.append((int((label_tp & m).sum()), int((~label_tp & m).sum()),
+                       int((label_tp & m & passed).sum()), int((~label_tp & m & passed).sum())))
+    return accuracy_rows(counts)

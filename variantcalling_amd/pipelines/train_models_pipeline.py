@@ -145,8 +145,10 @@ def run(argv: list[str]):
             sel = label >= 0
             if args.evaluate_concordance_contig and args.evaluate_concordance_contig in ref.names:
                 sel &= vt.contig == ref.names.index(args.evaluate_concordance_contig)
-            rows = evaluate.accuracy_table(res.tree_score[sel], res.filter[sel] == S.FILTER_PASS, label[sel] == 1,
-                                           group[sel] != S.GROUP_SNP, X[sel, names.index("hmer_indel_length")])
+            # the accuracy table's counts come from the FILTER column still resident on the GPU (ugvc_eval_counts)
+            lab = np.where(sel, label, -1).astype(np.int8)
+            bits = evaluate.category_bits(group != S.GROUP_SNP, X[:, names.index("hmer_indel_length")])
+            rows = evaluate.accuracy_rows(eng.eval_counts(lab, bits))
             with open(args.output_file_prefix + ".stats.csv", "w", newline="") as fh:
                 w = csv.DictWriter(fh, fieldnames=list(rows[0]), delimiter=";")
                 w.writeheader()
