@@ -17,7 +17,7 @@ per = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob(os.path.join(d, f"pmc_{c}", "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0]
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")       # template instantiations print a return type
             if k.startswith("ugvc::"):
                 per.setdefault(k, {}).setdefault(c, []).append(float(r["Counter_Value"]))
 out = {"source": d, "unit": "bytes per scoring pass (5 M variants, 1 GPU)", "fetch_correction": 2.0, "kernels": {}}
