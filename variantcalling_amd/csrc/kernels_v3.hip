@@ -82,6 +82,33 @@ __device__ __forceinline__ bool table_present(const FilterArgs& f, int t) {
     return t == 0 ? f.has_runs != 0 : (t - 1) < f.n_tracks;
 }
 
+// 16-ary lower bound: 15 independent pivot loads per round instead of one dependent load per halving - K0 is
+// pure latency (one search per tile and table), so rounds, not loads, are what it pays for (22 -> 6 rounds on a
+// 3 M-entry table).
+template <class T>
+__device__ __forceinline__ int lb_wide_g(const T* __restrict__ a, int lo, int hi, T key) {
+    while (hi - lo > 16) {
+        const int step = (hi - lo) >> 4;
+        T x[15];
+#pragma unroll
+        for (int k = 0; k < 15; ++k) x[k] = a[lo + (k + 1) * step];
+        int c = 0;
+#pragma unroll
+        for (int k = 0; k < 15; ++k) c += x[k] < key ? 1 : 0;          // sorted: the pivots below the key are a prefix
+        const int nlo = c == 0 ? lo : lo + c * step + 1;
+        hi = c == 15 ? hi : lo + (c + 1) * step;
+        lo = nlo;
+    }
+    const int n = hi - lo;
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const T x = k < n ? a[lo + k] : key;
+        c += (k < n && x < key) ? 1 : 0;
+    }
+    return lo + c;
+}
+
 // ---- K0: brackets3[b][a] = first index of searched array a (a < 6: starts of table a; a == 6:
 // blacklist keys) that is >= the first variant of tile b; row n_tiles holds the array lengths.
 __global__ void bracket3_kernel(const V2Args v) {
@@ -98,7 +125,7 @@ __global__ void bracket3_kernel(const V2Args v) {
             if (b == nb) out = (int)f.n_bl;
             else {
                 const int64_t i = (int64_t)b * kBlock;
-                out = lb_u64_g(f.bl, 0, (int)f.n_bl, ((uint64_t)f.contig[i] << 32) | (uint32_t)f.pos[i]);
+                out = lb_wide_g<uint64_t>(f.bl, 0, (int)f.n_bl, ((uint64_t)f.contig[i] << 32) | (uint32_t)f.pos[i]);
             }
         }
     } else if (table_present(f, a)) {
@@ -107,7 +134,7 @@ __global__ void bracket3_kernel(const V2Args v) {
         else {
             const int64_t i = (int64_t)b * kBlock;
             const int c = f.contig[i];
-            out = lb_i32_g(tv.starts, tv.ptr[c], tv.ptr[c + 1], f.pos[i]);
+            out = lb_wide_g<int32_t>(tv.starts, tv.ptr[c], tv.ptr[c + 1], f.pos[i]);
         }
     }
     v.brackets3[gid] = out;
@@ -147,7 +174,7 @@ template <bool PF>
 __global__ __launch_bounds__(kBlock, 4) void featurize3_kernel(const V2Args v) {
     __shared__ uint32_t win[kBlock * kWinStride];                  // 13 KB
     __shared__ int32_t pool[kPool3];                               // 8 KB
-    __shared__ float thr_lds[kThr3];                               // 14 KB
+    __shared__ __attribute__((aligned(16))) float thr_lds[kThr3];   // 14 KB
     __shared__ uint2 desc_lds[UGVC_N_GROUPS * kMaxFeatures];
     __shared__ int64_t coff_lds[257];
     __shared__ uint8_t css_lds[256];
@@ -164,7 +191,9 @@ __global__ __launch_bounds__(kBlock, 4) void featurize3_kernel(const V2Args v) {
 
     // ---- once per workgroup: model-side tables into LDS
     for (int k = tid; k < UGVC_N_GROUPS * kMaxFeatures; k += kBlock) desc_lds[k] = v.desc3[k];
-    for (int k = tid; k < v.thr_lds_len; k += kBlock) thr_lds[k] = v.thr[k];
+    // (16-byte pieces: the threshold table is padded to a multiple of four floats on the host)
+    for (int k = tid; k < (v.thr_lds_len + 3) / 4; k += kBlock)
+        reinterpret_cast<float4*>(thr_lds)[k] = reinterpret_cast<const float4*>(v.thr)[k];
     for (int k = tid; k <= a.n_contigs; k += kBlock) coff_lds[k] = a.contig_off[k];
     css_lds[tid] = v.css_lut[tid];
     __syncthreads();
@@ -897,14 +926,29 @@ __global__ __launch_bounds__(kK2Threads) void forest3_kernel(const V2Args v) {
     const int H = NL >> 1;
     if (FAST) {
         const size_t n_hi = (size_t)pg.T * H;
-        off = (n_hi * 4 + 15) & ~(size_t)15;
+        // the three tables are padded to 16 bytes (host and LDS): the fill is a handful of independent 16-byte
+        // loads per thread instead of a dependent load per dword (it is pure latency in front of every launch)
+        const size_t b_hi = (n_hi * 4 + 15) & ~(size_t)15, b_last = (n_hi * 8 + 15) & ~(size_t)15;
+        const size_t b_p1 = ((size_t)pg.n_pairs * 8 + 15) & ~(size_t)15;
+        off = b_hi;
         last4 = reinterpret_cast<uint2*>(smem + off);
-        off += n_hi * 8;
+        off += b_last;
         p1 = reinterpret_cast<double*>(smem + off);
-        off += ((size_t)pg.n_pairs * 8 + 15) & ~(size_t)15;
-        for (size_t k = tid; k < n_hi; k += blockDim.x) nodes[k] = pg.hi4[k];
-        for (size_t k = tid; k < n_hi; k += blockDim.x) last4[k] = pg.last4[k];
-        for (size_t k = tid; k < (size_t)pg.n_pairs; k += blockDim.x) p1[k] = pg.p1[k];
+        off += b_p1;
+        {
+            const uint4* s0 = reinterpret_cast<const uint4*>(pg.hi4);
+            const uint4* s1 = reinterpret_cast<const uint4*>(pg.last4);
+            const uint4* s2 = reinterpret_cast<const uint4*>(pg.p1);
+            uint4* d0 = reinterpret_cast<uint4*>(smem);
+            uint4* d1 = reinterpret_cast<uint4*>(smem + b_hi);
+            uint4* d2 = reinterpret_cast<uint4*>(smem + b_hi + b_last);
+            const size_t n0 = b_hi / 16, n1 = b_last / 16, n2 = b_p1 / 16;
+            for (size_t k = tid; k < n0 + n1 + n2; k += blockDim.x) {
+                if (k < n0) d0[k] = s0[k];
+                else if (k < n0 + n1) d1[k - n0] = s1[k - n0];
+                else d2[k - n0 - n1] = s2[k - n0 - n1];
+            }
+        }
     } else {
         off = (n_nodes * 4 + 15) & ~(size_t)15;
         pairs = reinterpret_cast<double2*>(smem + off);
@@ -1052,7 +1096,7 @@ static size_t k3_lds_bytes(const PackedGroupView& pg, int n_waves, bool fast) {
     const size_t NL = (size_t)1 << pg.D, n_nodes = (size_t)pg.T * NL;
     if (fast) {
         const size_t n_hi = n_nodes / 2;
-        return ((n_hi * 4 + 15) & ~(size_t)15) + n_hi * 8 + (((size_t)pg.n_pairs * 8 + 15) & ~(size_t)15) +
+        return ((n_hi * 4 + 15) & ~(size_t)15) + ((n_hi * 8 + 15) & ~(size_t)15) + (((size_t)pg.n_pairs * 8 + 15) & ~(size_t)15) +
                (size_t)n_waves * pg.n_planes * 128;
     }
     size_t b = (n_nodes * 4 + 15) & ~(size_t)15;

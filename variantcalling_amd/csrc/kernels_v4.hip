@@ -55,6 +55,31 @@ __device__ __forceinline__ int lb_u64_g(const uint64_t* __restrict__ a, int lo, 
     return base;
 }
 
+// 16-ary lower bound (see kernels_v3.hip): 15 independent pivot loads per round
+template <class T>
+__device__ __forceinline__ int lb_wide_g(const T* __restrict__ a, int lo, int hi, T key) {
+    while (hi - lo > 16) {
+        const int step = (hi - lo) >> 4;
+        T x[15];
+#pragma unroll
+        for (int k = 0; k < 15; ++k) x[k] = a[lo + (k + 1) * step];
+        int c = 0;
+#pragma unroll
+        for (int k = 0; k < 15; ++k) c += x[k] < key ? 1 : 0;
+        const int nlo = c == 0 ? lo : lo + c * step + 1;
+        hi = c == 15 ? hi : lo + (c + 1) * step;
+        lo = nlo;
+    }
+    const int n = hi - lo;
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const T x = k < n ? a[lo + k] : key;
+        c += (k < n && x < key) ? 1 : 0;
+    }
+    return lo + c;
+}
+
 __device__ __forceinline__ const TrackView& table_view(const FilterArgs& f, int t) { return t == 0 ? f.runs : f.tracks[t - 1]; }
 __device__ __forceinline__ bool table_present(const FilterArgs& f, int t) { return t == 0 ? f.has_runs != 0 : (t - 1) < f.n_tracks; }
 
@@ -115,7 +140,7 @@ __global__ void bracket4_kernel(const V2Args v) {
             if (b == nb) out = (int)f.n_bl;
             else {
                 const int64_t i = v.tiles4[b].x;
-                out = lb_u64_g(f.bl, 0, (int)f.n_bl, ((uint64_t)f.contig[i] << 32) | (uint32_t)f.pos[i]);
+                out = lb_wide_g<uint64_t>(f.bl, 0, (int)f.n_bl, ((uint64_t)f.contig[i] << 32) | (uint32_t)f.pos[i]);
             }
         }
     } else if (table_present(f, a)) {
@@ -124,7 +149,7 @@ __global__ void bracket4_kernel(const V2Args v) {
         else {
             const int64_t i = v.tiles4[b].x;
             const int c = f.contig[i];
-            out = lb_i32_g(tv.starts, tv.ptr[c], tv.ptr[c + 1], f.pos[i]);
+            out = lb_wide_g<int32_t>(tv.starts, tv.ptr[c], tv.ptr[c + 1], f.pos[i]);
         }
     }
     v.brackets3[gid] = out;
@@ -133,7 +158,7 @@ __global__ void bracket4_kernel(const V2Args v) {
 __global__ __launch_bounds__(kBlock, 4) void featurize4_kernel(const V2Args v) {
     __shared__ uint32_t win[kBlock * kWinStride];                  // 13 KB
     __shared__ int32_t pool[kPool4];                               // 10 KB
-    __shared__ float thr_lds[kThr3];                               // 14 KB
+    __shared__ __attribute__((aligned(16))) float thr_lds[kThr3];   // 14 KB
     // per (group, feature): {table offset | kind << 30, table length, byte offset of the code's dword, bit offset}
     __shared__ uint4 desc_lds[UGVC_N_GROUPS * kMaxFeatures];
     __shared__ float gc_lut[11 * 11];                              // (f32)((f64)count / (f64)length)
@@ -154,7 +179,9 @@ __global__ __launch_bounds__(kBlock, 4) void featurize4_kernel(const V2Args v) {
         const uint2 d = v.desc3[k];
         desc_lds[k] = make_uint4(d.x, d.y & 0xFFFFu, ((d.y >> 16) & 3u) * 4u, (d.y >> 18) & 31u);
     }
-    for (int k = tid; k < v.thr_lds_len; k += kBlock) thr_lds[k] = v.thr[k];
+    // (16-byte pieces: the threshold table is padded to a multiple of four floats on the host)
+    for (int k = tid; k < (v.thr_lds_len + 3) / 4; k += kBlock)
+        reinterpret_cast<float4*>(thr_lds)[k] = reinterpret_cast<const float4*>(v.thr)[k];
     if (tid < 121) {
         const int cnt = tid / 11, len = tid % 11;
         gc_lut[tid] = len > 0 ? (float)((double)cnt / (double)len) : 0.0f;

@@ -324,6 +324,7 @@ int finalize_pack(ugvc_ctx* ctx) {
         if (upload(ctx, s->desc3, desc3.data(), desc3.size() * sizeof(uint2))) return -1;
         for (int k = 0; k < 4; ++k) s->thr_bits4[k] = thr_bits4[k];
         if (upload(ctx, s->lut, lut.data(), lut.size() * 2)) return -1;
+        thr.resize((thr.size() + 3) & ~(size_t)3, 0.f);          // K1 copies the LDS-resident prefix as float4
         if (upload(ctx, s->thr, thr.data(), thr.size() * 4)) return -1;
         for (auto& g : s->g) {
             if (!g.set) continue;
@@ -332,6 +333,10 @@ int finalize_pack(ugvc_ctx* ctx) {
             if (g.kind == UGVC_MODEL_RF) {
                 if (upload(ctx, g.d_leaf_idx, g.leaf_idx.data(), g.leaf_idx.size() * 2)) return -1;
                 if (upload(ctx, g.d_pairs, g.pairs.data(), g.pairs.size() * 8)) return -1;
+                // padded to whole 16-byte pieces: the forest kernel fills its LDS with 16-byte loads
+                g.hi4.resize((g.hi4.size() + 3) & ~(size_t)3, 0xFFFFu);
+                g.last4.resize((g.last4.size() + 3) & ~(size_t)3, 0u);
+                g.p1.resize((g.p1.size() + 1) & ~(size_t)1, 0.0);
                 if (upload(ctx, g.d_hi4, g.hi4.data(), g.hi4.size() * 4)) return -1;
                 if (upload(ctx, g.d_last4, g.last4.data(), g.last4.size() * 4)) return -1;
                 if (upload(ctx, g.d_p1, g.p1.data(), g.p1.size() * 8)) return -1;
