@@ -43,20 +43,37 @@ def run(argv: list[str]):
     args = get_parser().parse_args(argv[1:])
     from ..engine import Engine, configure     # fails loudly if the library or the GPU is missing
 
+    import time
+    t0 = time.perf_counter()
+    stages = {}
+
+    def lap(name):
+        nonlocal t0
+        t1 = time.perf_counter()
+        stages[name] = t1 - t0
+        t0 = t1
+
     logger.info("reading side tables")
     ref, runs, tracks, bl = common.load_side_tables(args.reference_file, args.runs_file, args.annotate_intervals,
                                                     args.blacklist)
     forests = model_io.load_model_file(args.model_file, args.model_name)
     common.check_model_tracks(forests, len(tracks), "filter_variants_pipeline")
+    lap("side tables + model")
     logger.info("reading %s", args.input_file)
     vcf = vcfio.read_vcf(args.input_file, ref.names, is_mutect=args.is_mutect)
+    lap("VCF -> columns (native codec)")
     hp_len, hp_dist = args.hpol_filter_length_dist
     with Engine(args.device) as eng:
         configure(eng, ref, runs, tracks, bl, forests, args.flow_order, hp_len, hp_dist, True)
+        lap("context + uploads (reference, tables, model)")
         res = eng.filter_variants(vcf.table)
+        lap("upload variants + scoring pass + download")
     cg = common.cg_insertion_mask(vcf.table) if args.blacklist_cg_insertions else None
     logger.info("writing %s", args.output_file)
     vcfio.write_filtered_vcf(args.output_file, vcf, res, cg)
+    lap("FILTER/INFO write-back (native codec)")
+    run.last_stage_seconds = stages                        # read by tools/bench_pipeline.py
+    logger.info("stage seconds: %s", ", ".join(f"{k} {v:.3f}" for k, v in stages.items()))
     n_pass = int(((res.filter == 0) & (res.flags & 3 == 0)).sum())
     logger.info("%d variants, %d PASS", vcf.table.n, n_pass)
     return 0
