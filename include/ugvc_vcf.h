@@ -78,6 +78,40 @@ void ugvc_vcf_free(ugvc_vcf* h);
 const char* ugvc_vcf_last_error(void);
 int ugvc_vcf_abi_version(void);
 
+/* ---- side tables of the same tools: FASTA -> base codes, BED / interval_list -> interval arrays ----------------
+ * `--reference_file` is opened with pyfaidx and fetched per row in the reference
+ * (/root/reference/ugvc/pipelines/vcfbed/calibrate_bridging_snvs.py:28-30); here the whole FASTA (plain, gzip or
+ * BGZF) is encoded once: record name = first token after '>', sequence bytes mapped A/a C/c G/g T/t -> 1..4,
+ * everything else 0, line ends dropped.  `--runs_file` / `--annotate_intervals`
+ * (/root/reference/docs/filter_variants_pipeline.md:30-33,45-46): one (contig index, start, end) row per data line
+ * whose contig is in `contig_names`, 0-based half-open; interval_list files (an '@' header line, or the file
+ * extension) are 1-based inclusive and converted.  Sorting / merging stays with the caller.  Semantics are those
+ * of variantcalling_amd/io/fasta.py and bed.py (tests/test_vcf_native.py compares). */
+typedef struct ugvc_fasta ugvc_fasta;
+typedef struct ugvc_fasta_view {
+    int64_t total;               /* bases over all records                                   */
+    int32_t n_contigs;
+    const uint8_t* codes;        /* total bytes                                              */
+    const int64_t* contig_off;   /* n_contigs + 1                                            */
+    const char* names;           /* record names joined by '\n'                              */
+    int64_t names_bytes;
+} ugvc_fasta_view;
+int ugvc_fasta_read(const char* path, int n_threads, ugvc_fasta** out);
+int ugvc_fasta_get_view(const ugvc_fasta* h, ugvc_fasta_view* view);
+void ugvc_fasta_free(ugvc_fasta* h);
+
+typedef struct ugvc_intervals ugvc_intervals;
+typedef struct ugvc_intervals_view {
+    int64_t n;
+    const int64_t* contig;       /* index into contig_names                                  */
+    const int64_t* start;        /* 0-based                                                  */
+    const int64_t* end;          /* exclusive                                                */
+} ugvc_intervals_view;
+int ugvc_intervals_read(const char* path, const char* const* contig_names, int n_contigs, int n_threads,
+                        ugvc_intervals** out);
+int ugvc_intervals_get_view(const ugvc_intervals* h, ugvc_intervals_view* view);
+void ugvc_intervals_free(ugvc_intervals* h);
+
 /* Shortest decimal string that round-trips the f32 (fixed notation, at least one fractional digit):
  * the TREE_SCORE formatter, exposed for the parity test against numpy.format_float_positional. */
 int ugvc_vcf_format_f32(float x, char* buf, int cap);

@@ -39,13 +39,13 @@ def _same_file(a, b, mutect=False):
 
 def test_header_symbols_are_exported():
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "ugvc_vcf.h")).read(), flags=re.S)
-    names = sorted(set(re.findall(r"\b(ugvc_vcf_[a-z0-9_]+)\s*\(", text)))
-    assert len(names) == 7
+    names = sorted(set(re.findall(r"\b(ugvc_(?:vcf|fasta|intervals)_[a-z0-9_]+)\s*\(", text)))
+    assert len(names) == 13
     lib = nv.load_library()
     for n in names:
         assert hasattr(lib, n), n
     out = subprocess.run(["nm", "-D", "--defined-only", nv.LIB_PATH], capture_output=True, text=True).stdout
-    assert set(names) <= set(re.findall(r" T (ugvc_vcf_\w+)", out))
+    assert set(names) <= set(re.findall(r" T (ugvc_\w+)", out))
     assert lib.ugvc_vcf_abi_version() == 1
     # host-only library: no HIP runtime dependency
     deps = subprocess.run(["ldd", nv.LIB_PATH], capture_output=True, text=True).stdout
@@ -195,3 +195,65 @@ def test_block_boundaries_follow_the_python_writer(tmp_path):
         sizes.append(len(zlib.decompress(A[off + 18: off + bsize - 8], -15)))
         off += bsize
     assert sizes[-1] == 0 and all(s == 65280 for s in sizes[:-2]) and 0 < sizes[-2] <= 65280
+
+
+def test_fasta_reader_matches_the_python_reference(tmp_path):
+    from variantcalling_amd.io import fasta
+    text = (">chr1 first record description\nACGTNacgtn\nRYKM\n\n>chr2\r\nAC\r\nGT\r\n>empty\n>chrM\tmito\nTTTT")
+    for name, data in (("a.fa", text.encode()), ("a.fa.gz", gzip.compress(text.encode()))):
+        p = str(tmp_path / name)
+        open(p, "wb").write(data)
+        a, b = fasta.read_fasta(p), nv.read_fasta(p)
+        assert a.names == b.names == ["chr1", "chr2", "empty", "chrM"]
+        assert np.array_equal(a.codes, b.codes) and np.array_equal(a.contig_off, b.contig_off)
+        assert b.contig_off.tolist() == [0, 14, 18, 18, 22] and b.codes[:10].tolist() == [1, 2, 3, 4, 0, 1, 2, 3, 4, 0]
+        sub_a, sub_b = fasta.read_fasta(p, contigs=["chrM", "chr2"]), nv.read_fasta(p, contigs=["chrM", "chr2"])
+        assert sub_a.names == sub_b.names == ["chr2", "chrM"] and np.array_equal(sub_a.codes, sub_b.codes)
+        assert np.array_equal(sub_a.contig_off, sub_b.contig_off)
+    cs = synth.make_callset(2000, genome_len=3_000_000, n_contigs=3, seed=2)
+    for name in ("g.fa", "g.fa.gz"):
+        p = str(tmp_path / name)
+        fasta.write_fasta(p, cs.ref)
+        for th in (1, 0):
+            b = nv.read_fasta(p, n_threads=th)
+            assert b.names == cs.ref.names and np.array_equal(b.codes, cs.ref.codes) and np.array_equal(b.contig_off, cs.ref.contig_off)
+    bad = str(tmp_path / "bad.fa")
+    open(bad, "w").write("ACGT\n")
+    for mod in (fasta, nv):
+        with pytest.raises(ValueError, match="not a FASTA"):
+            mod.read_fasta(bad)
+
+
+def test_interval_reader_matches_the_python_reference(tmp_path):
+    from variantcalling_amd.io import bed
+    names = ["chr1", "chr2"]
+    files = {
+        "t.bed": "track name=x\nbrowser position\n#c\nchr1\t10\t20\textra\nchr2\t5\t9\nchrUn\t1\t2\nchr1\t15\t30\nchr1\t30\t40\n\nchr1\t100\t100\n",
+        "s.bed": "chr1 10 20\nchr2   7\t9\n",
+        "p.interval_list": "@HD\tVN:1.6\n@SQ\tSN:chr1\nchr1\t11\t20\t+\tx\nchr2\t6\t9\t+\ty\r\n",
+        "h.bed": "chr1\t1\t5\n@late header turns one-based on\nchr1\t11\t20\n",
+    }
+    for fn, txt in files.items():
+        for gz in (False, True):
+            p = str(tmp_path / (fn + (".gz" if gz else "")))
+            open(p, "wb").write(gzip.compress(txt.encode()) if gz else txt.encode())
+            for merge in (True, False):
+                a, b = bed.read_intervals(p, names, merge=merge), nv.read_intervals(p, names, merge=merge)
+                assert np.array_equal(a.starts, b.starts) and np.array_equal(a.ends, b.ends), (fn, gz, merge)
+                assert np.array_equal(a.contig_ptr, b.contig_ptr) and a.name == b.name
+    t = nv.read_intervals(str(tmp_path / "t.bed"), names)
+    assert t.starts.tolist() == [10, 5] and t.ends.tolist() == [40, 9] and t.contig_ptr.tolist() == [0, 1, 2]
+    assert nv.read_intervals(str(tmp_path / "p.interval_list"), names).starts.tolist() == [10, 5]
+    cs = synth.make_callset(3000, genome_len=3_000_000, n_contigs=3, seed=4)
+    p = str(tmp_path / "big.bed")
+    bed.write_bed(p, cs.tracks[2], cs.ref.names)
+    for th in (1, 0):
+        y = nv.read_intervals(p, cs.ref.names, n_threads=th)
+        assert np.array_equal(y.starts, cs.tracks[2].starts) and np.array_equal(y.ends, cs.tracks[2].ends)
+    badp = str(tmp_path / "bad.bed")
+    open(badp, "w").write("chr1\t10\n")
+    with pytest.raises(ValueError, match="fewer than 3"):
+        nv.read_intervals(badp, names)
+    open(badp, "w").write("chr1\tx\t20\n")
+    with pytest.raises(ValueError, match="not integers"):
+        nv.read_intervals(badp, names)

@@ -176,6 +176,29 @@ int inflate_bgzf(const std::vector<unsigned char>& raw, const std::vector<Block>
     return 0;
 }
 
+// whole file into memory, inflated if it is gzip (BGZF members in parallel, anything else serially)
+int load_text(const char* path, int threads, std::vector<char>& text) {
+    std::vector<unsigned char> raw;
+    {
+        FILE* fh = fopen(path, "rb");
+        if (!fh) return fail(std::string(path) + ": cannot open");
+        fseek(fh, 0, SEEK_END);
+        const long sz = ftell(fh);
+        fseek(fh, 0, SEEK_SET);
+        raw.resize(sz > 0 ? (size_t)sz : 0);
+        const size_t got = raw.empty() ? 0 : fread(raw.data(), 1, raw.size(), fh);
+        fclose(fh);
+        if (got != raw.size()) return fail(std::string(path) + ": short read");
+    }
+    if (raw.size() >= 2 && raw[0] == 0x1f && raw[1] == 0x8b) {
+        std::vector<Block> blocks;
+        if (parse_bgzf(raw, blocks)) return inflate_bgzf(raw, blocks, text, threads, path);
+        return inflate_serial(raw, text, path);
+    }
+    text.assign(reinterpret_cast<const char*>(raw.data()), reinterpret_cast<const char*>(raw.data()) + raw.size());
+    return 0;
+}
+
 struct Span {
     int64_t off;
     int32_t len;
@@ -465,30 +488,9 @@ int ugvc_vcf_read(const char* path, const char* const* contig_names, int n_conti
     if (sample < 0 || sample > 1000000) return fail("bad sample index");
     *out = nullptr;
     const int threads = pick_threads(n_threads);
-    std::vector<unsigned char> raw;
-    {
-        FILE* fh = fopen(path, "rb");
-        if (!fh) return fail(std::string(path) + ": cannot open");
-        fseek(fh, 0, SEEK_END);
-        const long sz = ftell(fh);
-        fseek(fh, 0, SEEK_SET);
-        raw.resize(sz > 0 ? (size_t)sz : 0);
-        const size_t got = raw.empty() ? 0 : fread(raw.data(), 1, raw.size(), fh);
-        fclose(fh);
-        if (got != raw.size()) return fail(std::string(path) + ": short read");
-    }
     std::unique_ptr<ugvc_vcf> h(new ugvc_vcf());
     h->path = path;
-    if (raw.size() >= 2 && raw[0] == 0x1f && raw[1] == 0x8b) {
-        std::vector<Block> blocks;
-        if (parse_bgzf(raw, blocks)) {
-            if (inflate_bgzf(raw, blocks, h->text, threads, h->path)) return -1;
-        } else if (inflate_serial(raw, h->text, h->path)) return -1;
-        std::vector<unsigned char>().swap(raw);
-    } else {
-        h->text.assign(reinterpret_cast<const char*>(raw.data()), reinterpret_cast<const char*>(raw.data()) + raw.size());
-        std::vector<unsigned char>().swap(raw);
-    }
+    if (load_text(path, threads, h->text)) return -1;
     const char* base = h->text.data();
     const int64_t tn = (int64_t)h->text.size();
 
@@ -767,5 +769,219 @@ int ugvc_vcf_write_filtered(const ugvc_vcf* h, const char* out_path, const float
     if (!io_ok) return fail(std::string(out_path) + ": write failed");
     return 0;
 }
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------
+// Side tables: FASTA -> base codes, BED / interval_list -> (contig, start, end) rows
+// ------------------------------------------------------------------------------------------------------------
+struct ugvc_fasta {
+    std::vector<uint8_t> codes;
+    std::vector<int64_t> off;
+    std::string names;
+};
+
+struct ugvc_intervals {
+    std::vector<int64_t> contig, start, end;
+};
+
+extern "C" {
+
+int ugvc_fasta_read(const char* path, int n_threads, ugvc_fasta** out) {
+    if (!path || !out) return fail("NULL argument");
+    *out = nullptr;
+    const int threads = pick_threads(n_threads);
+    std::vector<char> text;
+    if (load_text(path, threads, text)) return -1;
+    const char* base = text.data();
+    const int64_t tn = (int64_t)text.size();
+    if (tn == 0 || base[0] != '>') return fail(std::string(path) + ": not a FASTA file");
+    // headers: every line that starts with '>'
+    std::vector<int64_t> hdr;                       // offset of '>'
+    {
+        const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(threads, tn / (1 << 20)));
+        std::vector<std::vector<int64_t>> found((size_t)parts);
+        parallel_ranges(tn, parts, [&](int p, int64_t lo, int64_t hi) {
+            for (int64_t q = lo; q < hi;) {
+                const void* g = memchr(base + q, '>', (size_t)(hi - q));
+                if (!g) break;
+                const int64_t at = (const char*)g - base;
+                if (at == 0 || base[at - 1] == '\n') found[(size_t)p].push_back(at);
+                q = at + 1;
+            }
+        });
+        for (auto& f : found) hdr.insert(hdr.end(), f.begin(), f.end());
+    }
+    const size_t nrec = hdr.size();
+    std::unique_ptr<ugvc_fasta> h(new ugvc_fasta());
+    std::vector<int64_t> seq_lo(nrec), seq_hi(nrec);
+    for (size_t k = 0; k < nrec; ++k) {
+        const void* nl = memchr(base + hdr[k], '\n', (size_t)(tn - hdr[k]));
+        const int64_t e = nl ? (const char*)nl - base : tn;
+        // name: first whitespace-delimited token after '>'
+        int64_t a = hdr[k] + 1, b = a;
+        while (a < e && is_space(base[a])) ++a;
+        b = a;
+        while (b < e && !is_space(base[b])) ++b;
+        if (k) h->names.push_back('\n');
+        h->names.append(base + a, (size_t)(b - a));
+        seq_lo[k] = std::min(e + 1, tn);
+        seq_hi[k] = k + 1 < nrec ? hdr[k + 1] : tn;
+    }
+    // work items: <= 8 MB pieces of every record's sequence range; count, prefix, encode
+    struct Piece { int64_t lo, hi, out; size_t rec; };
+    std::vector<Piece> pieces;
+    for (size_t k = 0; k < nrec; ++k)
+        for (int64_t q = seq_lo[k]; q < seq_hi[k] || q == seq_lo[k]; q += (int64_t)8 << 20) {
+            pieces.push_back(Piece{q, std::min(seq_hi[k], q + ((int64_t)8 << 20)), 0, k});
+            if (q + ((int64_t)8 << 20) >= seq_hi[k]) break;
+        }
+    std::vector<int64_t> cnt(pieces.size());
+    parallel_items((int64_t)pieces.size(), threads, [&](int64_t i) {
+        const Piece& p = pieces[(size_t)i];
+        int64_t c = 0;
+        for (int64_t q = p.lo; q < p.hi; ++q) c += base[q] != '\n' && base[q] != '\r';
+        cnt[(size_t)i] = c;
+    });
+    h->off.assign(nrec + 1, 0);
+    int64_t run = 0;
+    for (size_t i = 0; i < pieces.size(); ++i) {
+        pieces[i].out = run;
+        run += cnt[i];
+        h->off[pieces[i].rec + 1] = run;
+    }
+    for (size_t k = 1; k <= nrec; ++k) h->off[k] = std::max(h->off[k], h->off[k - 1]);   // records without sequence
+    h->codes.resize((size_t)run);
+    uint8_t code[256];
+    memset(code, 0, sizeof code);
+    code['A'] = code['a'] = 1; code['C'] = code['c'] = 2; code['G'] = code['g'] = 3; code['T'] = code['t'] = 4;
+    parallel_items((int64_t)pieces.size(), threads, [&](int64_t i) {
+        const Piece& p = pieces[(size_t)i];
+        uint8_t* d = h->codes.data() + p.out;
+        for (int64_t q = p.lo; q < p.hi; ++q) {
+            const unsigned char ch = (unsigned char)base[q];
+            if (ch != '\n' && ch != '\r') *d++ = code[ch];
+        }
+    });
+    *out = h.release();
+    return 0;
+}
+
+int ugvc_fasta_get_view(const ugvc_fasta* h, ugvc_fasta_view* v) {
+    if (!h || !v) return fail("NULL argument");
+    v->total = (int64_t)h->codes.size();
+    v->n_contigs = (int32_t)(h->off.size() - 1);
+    v->codes = h->codes.data();
+    v->contig_off = h->off.data();
+    v->names = h->names.data();
+    v->names_bytes = (int64_t)h->names.size();
+    return 0;
+}
+
+void ugvc_fasta_free(ugvc_fasta* h) { delete h; }
+
+int ugvc_intervals_read(const char* path, const char* const* contig_names, int n_contigs, int n_threads, ugvc_intervals** out) {
+    if (!path || !out || (n_contigs > 0 && !contig_names)) return fail("NULL argument");
+    *out = nullptr;
+    const int threads = pick_threads(n_threads);
+    std::vector<char> text;
+    if (load_text(path, threads, text)) return -1;
+    const char* base = text.data();
+    const int64_t tn = (int64_t)text.size();
+    std::vector<std::string> names((size_t)std::max(n_contigs, 0));
+    std::unordered_map<std::string_view, int> idx;
+    for (int c = 0; c < n_contigs; ++c) names[(size_t)c] = contig_names[c] ? contig_names[c] : "";
+    for (int c = 0; c < n_contigs; ++c) idx[std::string_view(names[(size_t)c])] = c;
+    const size_t plen = strlen(path);
+    const bool by_ext = plen >= 14 && strcmp(path + plen - 14, ".interval_list") == 0;
+    // one-based from the first '@' line on (Picard header), or for the whole file by extension
+    int64_t one_from = by_ext ? 0 : INT64_MAX;
+    for (int64_t s = 0; s < tn && !by_ext;) {
+        const void* nl = memchr(base + s, '\n', (size_t)(tn - s));
+        const int64_t e = nl ? (const char*)nl - base : tn;
+        if (base[s] == '@') { one_from = s; break; }
+        s = e + 1;
+    }
+    const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(threads, tn / (1 << 18)));
+    std::vector<ugvc_intervals> part((size_t)parts);
+    std::vector<std::string> errs((size_t)parts);
+    parallel_ranges(tn, parts, [&](int p, int64_t lo, int64_t hi) {
+        int64_t s = lo;
+        if (lo > 0) {
+            const void* nl = memchr(base + lo - 1, '\n', (size_t)(tn - lo + 1));
+            if (!nl) return;
+            s = (const char*)nl - base + 1;
+        }
+        ugvc_intervals& o = part[(size_t)p];
+        while (s < hi && s < tn) {
+            const void* nl = memchr(base + s, '\n', (size_t)(tn - s));
+            const int64_t e = nl ? (const char*)nl - base : tn;
+            const int64_t ls = s;
+            s = e + 1;
+            bool blank = true;
+            for (int64_t q = ls; q < e && blank; ++q) blank = is_space(base[q]);
+            if (blank || base[ls] == '#' || base[ls] == '@') continue;
+            if ((e - ls >= 5 && memcmp(base + ls, "track", 5) == 0) || (e - ls >= 7 && memcmp(base + ls, "browser", 7) == 0)) continue;
+            // fields: tab-separated; with fewer than three tab fields, any whitespace separates
+            Span f[3];
+            int nf = 0;
+            {
+                const char* q = base + ls;
+                const char* le = base + e;
+                int tabs = 0;
+                for (const char* t = q; t < le; ++t) tabs += *t == '\t';
+                if (tabs >= 2) {
+                    for (; nf < 3; ++nf) {
+                        const char* t = static_cast<const char*>(memchr(q, '\t', (size_t)(le - q)));
+                        const char* fe = t ? t : le;
+                        f[nf] = Span{(int64_t)(q - base), (int32_t)(fe - q)};
+                        if (!t) { ++nf; break; }
+                        q = t + 1;
+                    }
+                } else {
+                    while (nf < 3) {
+                        while (q < le && is_space(*q)) ++q;
+                        if (q >= le) break;
+                        const char* fe = q;
+                        while (fe < le && !is_space(*fe)) ++fe;
+                        f[nf++] = Span{(int64_t)(q - base), (int32_t)(fe - q)};
+                        q = fe;
+                    }
+                }
+            }
+            if (nf < 3) { if (errs[(size_t)p].empty()) errs[(size_t)p] = std::string(path) + ": interval line with fewer than 3 columns"; return; }
+            auto it = idx.find(std::string_view(base + f[0].off, (size_t)f[0].len));
+            if (it == idx.end()) continue;               // contig not in the reference: cannot annotate any variant
+            int64_t a, b;
+            if (!parse_int(base + f[1].off, f[1].len, a) || !parse_int(base + f[2].off, f[2].len, b)) {
+                if (errs[(size_t)p].empty()) errs[(size_t)p] = std::string(path) + ": interval coordinates are not integers";
+                return;
+            }
+            o.contig.push_back(it->second);
+            o.start.push_back(a - (ls >= one_from ? 1 : 0));
+            o.end.push_back(b);
+        }
+    });
+    for (auto& e : errs) if (!e.empty()) return fail(e);
+    std::unique_ptr<ugvc_intervals> h(new ugvc_intervals());
+    for (auto& o : part) {
+        h->contig.insert(h->contig.end(), o.contig.begin(), o.contig.end());
+        h->start.insert(h->start.end(), o.start.begin(), o.start.end());
+        h->end.insert(h->end.end(), o.end.begin(), o.end.end());
+    }
+    *out = h.release();
+    return 0;
+}
+
+int ugvc_intervals_get_view(const ugvc_intervals* h, ugvc_intervals_view* v) {
+    if (!h || !v) return fail("NULL argument");
+    v->n = (int64_t)h->contig.size();
+    v->contig = h->contig.data();
+    v->start = h->start.data();
+    v->end = h->end.data();
+    return 0;
+}
+
+void ugvc_intervals_free(ugvc_intervals* h) { delete h; }
 
 }  // extern "C"

@@ -28,6 +28,15 @@ class _View(C.Structure):
                 ("text", C.c_void_p), ("filter_off", C.c_void_p), ("filter_len", C.c_void_p)]
 
 
+class _FastaView(C.Structure):
+    _fields_ = [("total", C.c_int64), ("n_contigs", C.c_int32), ("codes", C.c_void_p), ("contig_off", C.c_void_p),
+                ("names", C.c_void_p), ("names_bytes", C.c_int64)]
+
+
+class _IntervalsView(C.Structure):
+    _fields_ = [("n", C.c_int64), ("contig", C.c_void_p), ("start", C.c_void_p), ("end", C.c_void_p)]
+
+
 def load_library():
     global _lib
     if _lib is None:
@@ -49,6 +58,18 @@ def load_library():
         lib.ugvc_vcf_format_f32.restype = C.c_int
         lib.ugvc_vcf_format_f32.argtypes = [C.c_float, C.c_char_p, C.c_int]
         lib.ugvc_vcf_abi_version.restype = C.c_int
+        lib.ugvc_fasta_read.restype = C.c_int
+        lib.ugvc_fasta_read.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+        lib.ugvc_fasta_get_view.restype = C.c_int
+        lib.ugvc_fasta_get_view.argtypes = [C.c_void_p, C.POINTER(_FastaView)]
+        lib.ugvc_fasta_free.restype = None
+        lib.ugvc_fasta_free.argtypes = [C.c_void_p]
+        lib.ugvc_intervals_read.restype = C.c_int
+        lib.ugvc_intervals_read.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        lib.ugvc_intervals_get_view.restype = C.c_int
+        lib.ugvc_intervals_get_view.argtypes = [C.c_void_p, C.POINTER(_IntervalsView)]
+        lib.ugvc_intervals_free.restype = None
+        lib.ugvc_intervals_free.argtypes = [C.c_void_p]
         _lib = lib
     return _lib
 
@@ -140,3 +161,53 @@ def format_f32(x: float) -> str:
     if n < 0:
         raise RuntimeError("format_f32 failed")
     return buf.value.decode()
+
+
+def read_fasta(path: str, contigs: list | None = None, n_threads: int = 0) -> S.Reference:
+    """io.fasta.read_fasta through the native reader (threaded inflate + encode)."""
+    lib = load_library()
+    h = C.c_void_p()
+    if lib.ugvc_fasta_read(os.fsencode(path), int(n_threads), C.byref(h)):
+        raise ValueError(_err(lib))
+    try:
+        v = _FastaView()
+        lib.ugvc_fasta_get_view(h, C.byref(v))
+        names = C.string_at(v.names, v.names_bytes).decode().split("\n") if v.n_contigs else []
+        off = _arr(v.contig_off, int(v.n_contigs) + 1, np.int64)
+        if contigs is None:
+            codes = _arr(v.codes, int(v.total), np.uint8)
+        else:
+            keep = [k for k, nm in enumerate(names) if nm in contigs]
+            if not keep:
+                raise ValueError(f"{path}: no sequences read")
+            buf = (C.c_char * int(v.total)).from_address(v.codes) if v.total else b""
+            whole = np.frombuffer(buf, dtype=np.uint8, count=int(v.total))
+            codes = np.concatenate([whole[off[k]: off[k + 1]] for k in keep])
+            sizes = [int(off[k + 1] - off[k]) for k in keep]
+            off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+            names = [names[k] for k in keep]
+    finally:
+        lib.ugvc_fasta_free(h)
+    return S.Reference(codes, off, names)
+
+
+def read_intervals(path: str, contig_names: list, merge: bool = True, n_threads: int = 0) -> S.IntervalTrack:
+    """io.bed.read_intervals through the native tokeniser; sorting / merging as in bed.track_from_arrays."""
+    from . import bed
+    lib = load_library()
+    names = (C.c_char_p * len(contig_names))(*[n.encode() for n in contig_names])
+    h = C.c_void_p()
+    if lib.ugvc_intervals_read(os.fsencode(path), names, len(contig_names), int(n_threads), C.byref(h)):
+        raise ValueError(_err(lib))
+    try:
+        v = _IntervalsView()
+        lib.ugvc_intervals_get_view(h, C.byref(v))
+        n = int(v.n)
+        c, s, e = _arr(v.contig, n, np.int64), _arr(v.start, n, np.int64), _arr(v.end, n, np.int64)
+    finally:
+        lib.ugvc_intervals_free(h)
+    stem = os.path.basename(path)
+    for suf in (".gz", ".bed", ".interval_list"):
+        if stem.endswith(suf):
+            stem = stem[: -len(suf)]
+    return bed.track_from_arrays(c, s, e, len(contig_names), stem, merge)

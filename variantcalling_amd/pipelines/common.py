@@ -13,16 +13,17 @@ logger = logging.getLogger("ugvc")
 
 
 def load_side_tables(reference_file, runs_file, annotate_intervals, blacklist_file):
-    ref = fasta.read_fasta(reference_file)
+    from ..io import vcf_native                        # threaded native readers (libugvc_vcf.so); io.fasta / io.bed are their references
+    ref = vcf_native.read_fasta(reference_file)
     if ref.n_contigs > 255:
         # the contig column is u8: keep the primary contigs, as the reference's own
         # per-contig keys do (HDF5 keyed per chromosome, docs/train_models_pipeline.md:58-59)
         keep = ref.names[:255]
         logger.warning("reference has %d contigs; using the first 255", ref.n_contigs)
-        ref = fasta.read_fasta(reference_file, contigs=keep)
+        ref = vcf_native.read_fasta(reference_file, contigs=keep)
     # homopolymer runs are disjoint by nature; book-ended runs of different bases must stay separate
-    runs = bed.read_intervals(runs_file, ref.names, merge=False) if runs_file else None
-    tracks = [bed.read_intervals(p, ref.names, merge=True) for p in (annotate_intervals or [])]
+    runs = vcf_native.read_intervals(runs_file, ref.names, merge=False) if runs_file else None
+    tracks = [vcf_native.read_intervals(p, ref.names, merge=True) for p in (annotate_intervals or [])]
     if len(tracks) > S.MAX_TRACKS:
         raise ValueError(f"at most {S.MAX_TRACKS} --annotate_intervals files are supported")
     bl = bed.read_blacklist(blacklist_file, ref.names) if blacklist_file else None
