@@ -3,6 +3,5 @@ set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-echo "== bench"; timeout 600 python bench.py 2>&1 | tail -1 | tee gpurun_out/bench_r01_final.json | cut -c1-200
-echo "== profile"; bash tools/gpu_profile.sh r01_final 2>&1 | tail -22
-echo "== aux"; timeout 300 python tools/bench_aux.py 2>&1 | tail -3 | tee gpurun_out/bench_aux.log
+echo "== parity"; timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | grep -E "passed|failed|Error" | tail -3
+echo "== tune"; timeout 600 python tools/tune3.py 5000000 625000 2>&1 | grep -E "==|single-sum|pair-sum|without" | tee gpurun_out/tune7.log
