@@ -158,6 +158,14 @@ int ugvc_forest_gemm(ugvc_ctx* ctx, int group, const int32_t* rows, int64_t n_ro
  * value 0 non-skip / 1 possible-cycle-skip / 2 cycle-skip.  Exposed so CPU tests can check it
  * against the full flow-key computation. */
 int ugvc_host_css_lut(const char* flow4, uint8_t out[256]);
+/* Kernel-path selection and profiling knobs (A/B measurements, parity cross-checks; 0 = production path):
+ *   bits 0-4 section ablation of the featurize kernel (results are WRONG): 1 no forest kernel, 2 no joins,
+ *            4 no quantisation, 8 no window features, 16 no record append
+ *   32   featurize kernel without the one-tile-ahead column prefetch     64   phase clocks on (ugvc_debug_phase_clocks)
+ *   128  v4 featurize kernel (single-contig tiles, sentinel joins)       256  v1 universal fused kernel
+ *   512  v2 kernels                                                      1024 pair-sum forest kernel
+ *   2048 16 trees in flight in the forest kernel
+ *   bits 12-13 featurize workgroups per CU (1..3; 0 = 4)                 bits 14-15 forest waves (1: 12, 2: 8, 3: 4; 0 = 16) */
 int ugvc_set_kernel_variant(ugvc_ctx* ctx, int variant);
 /* Profiling aid: core-clock cycles wave 0 of every featurize workgroup spent between the kernel's phase
  * boundaries (kernel variant bit 6 turns the clocks on), summed over workgroups and launches since the
