@@ -339,11 +339,12 @@ int ugvc_model_upload(ugvc_ctx* ctx, int group, int kind, const int32_t* feature
     if (n_features > kMaxFeatures) return fail("model has more features than the engine computes");
     UGVC_HIP(hipSetDevice(ctx->device));
     std::vector<Node> nodes(n_nodes);
-    const float inf = std::numeric_limits<float>::infinity();
     for (int i = 0; i < n_nodes; ++i) {
         if (feature[i] < 0) {
             if (left[i] < 0 || left[i] >= n_leaves) return fail("leaf payload index out of range");
-            nodes[i] = Node{inf, 0, i, left[i]};
+            // a leaf loops on itself whichever way the compare goes (a NaN or +inf feature 0 must not leave it);
+            // its payload row travels in the bits of `thr`
+            nodes[i] = Node{__builtin_bit_cast(float, (int32_t)left[i]), 0, i, i};
         } else {
             if (feature[i] >= n_features) return fail("node feature index out of range");
             if (left[i] < 0 || left[i] >= n_nodes || right[i] < 0 || right[i] >= n_nodes)

@@ -110,8 +110,8 @@ __device__ __forceinline__ void walk_forest(const ForestView& f, const float* __
                 i3 = x3 < n3.thr ? n3.left : n3.right;
             }
         }
-        double2 v0 = leaves[nodes[i0].right], v1 = leaves[nodes[i1].right];
-        double2 v2 = leaves[nodes[i2].right], v3 = leaves[nodes[i3].right];
+        double2 v0 = leaves[__float_as_int(nodes[i0].thr)], v1 = leaves[__float_as_int(nodes[i1].thr)];
+        double2 v2 = leaves[__float_as_int(nodes[i2].thr)], v3 = leaves[__float_as_int(nodes[i3].thr)];
         if (KIND == UGVC_MODEL_RF) {   // strict tree order, f64 (== sklearn predict_proba)
             a0 += v0.x; a1 += v0.y; a0 += v1.x; a1 += v1.y;
             a0 += v2.x; a1 += v2.y; a0 += v3.x; a1 += v3.y;
@@ -127,7 +127,7 @@ __device__ __forceinline__ void walk_forest(const ForestView& f, const float* __
             if (KIND == UGVC_MODEL_RF) i0 = x0 <= n0.thr ? n0.left : n0.right;
             else i0 = x0 < n0.thr ? n0.left : n0.right;
         }
-        double2 v0 = leaves[nodes[i0].right];
+        double2 v0 = leaves[__float_as_int(nodes[i0].thr)];
         if (KIND == UGVC_MODEL_RF) { a0 += v0.x; a1 += v0.y; }
         else margin += (float)v0.x;
     }

@@ -16,8 +16,8 @@ constexpr int kMotif = 5;
 constexpr int kGcWindow = 10;
 constexpr int kRefFrontPad = 64;                              // zero bytes in front of the reference buffer (v4 window loads)
 
-// 16-byte tree node.  Leaves self-loop (thr = +inf, left = self) so a fixed-depth walk needs
-// no leaf test; `right` of a leaf is its payload row.
+// 16-byte tree node.  Leaves self-loop (left = right = self) so a fixed-depth walk needs no leaf
+// test; the bits of a leaf's `thr` are its payload row.
 struct __attribute__((aligned(16))) Node {
     float thr;
     int feat;

@@ -398,8 +398,9 @@ def configure(engine: Engine, ref, runs, tracks, blacklist, forests, flow_order=
     """Load every resident table of one filtering job (the reference builds the same state from
     --reference_file/--runs_file/--annotate_intervals/--blacklist/--model_file)."""
     engine.set_reference(ref)
-    if runs is not None:
-        engine.set_runs(runs, hpol_len, hpol_dist, mark_hpol)
+    if runs is None:                       # a context may be re-configured: no runs file = an empty runs table
+        runs = S.IntervalTrack(np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(ref.n_contigs + 1, np.int32), "runs")
+    engine.set_runs(runs, hpol_len, hpol_dist, mark_hpol)
     engine.set_tracks(tracks or [])
     engine.set_blacklist(blacklist)
     engine.set_flow_order(flow_order)
