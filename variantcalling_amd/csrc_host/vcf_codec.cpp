@@ -212,15 +212,20 @@ bool parse_float(const char* s, int len, double& out) {
     while (len > 0 && is_space(s[len - 1])) --len;
     if (len <= 0 || len > 63) return false;
     char buf[64];
+    int m = 0;
     for (int i = 0; i < len; ++i) {
         const char c = s[i];
         if (c == 'x' || c == 'X' || c == 'p' || c == 'P' || c == '(') return false;
-        buf[i] = c;
+        if (c == '_') {                     // PEP 515: one underscore between two digits is skipped, any other is an error
+            if (i == 0 || i + 1 >= len || s[i - 1] < '0' || s[i - 1] > '9' || s[i + 1] < '0' || s[i + 1] > '9') return false;
+            continue;
+        }
+        buf[m++] = c;
     }
-    buf[len] = 0;
+    buf[m] = 0;
     char* end = nullptr;
     const double v = strtod(buf, &end);
-    if (end != buf + len) return false;
+    if (end != buf + m) return false;
     out = v;
     return true;
 }
@@ -244,6 +249,7 @@ bool parse_int(const char* s, int len, int64_t& out) {       // Python int(bytes
     if (len <= 0 || len > 18) return false;
     int64_t v = 0;
     for (int i = 0; i < len; ++i) {
+        if (s[i] == '_' && i > 0 && i + 1 < len && s[i - 1] >= '0' && s[i - 1] <= '9' && s[i + 1] >= '0' && s[i + 1] <= '9') continue;
         if (s[i] < '0' || s[i] > '9') return false;
         v = v * 10 + (s[i] - '0');
     }
