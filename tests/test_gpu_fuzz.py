@@ -62,3 +62,32 @@ def test_random_configurations(engine, frozen_models, seed):
         else:
             assert np.max(np.abs(res.tree_score - exp.tree_score)) <= 1e-6, what
     engine.set_kernel_variant(0)
+
+
+@pytest.mark.parametrize("seed", list(range(6)))
+def test_random_pileups(engine, seed):
+    """Pileup tally on random depth profiles (empty loci, single reads, loci far deeper than a wave's LDS span),
+    one-sided strands (zero cells of the SOR table), every allele code and the full base-quality range."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.choice([1, 63, 64, 65, 1000, 30_000]))
+    shape = rng.choice(["poisson", "geometric", "spiky"])
+    if shape == "poisson":
+        d = rng.poisson(float(rng.choice([0.3, 5, 30, 120])), n)
+    elif shape == "geometric":
+        d = rng.geometric(0.05, n) - 1
+    else:
+        d = np.where(rng.random(n) < 0.01, rng.integers(1000, 20_000, n), rng.integers(0, 3, n))
+    d = d.astype(np.int64)
+    off = np.concatenate([[0], np.cumsum(d)]).astype(np.int64)
+    m = int(off[-1])
+    allele = rng.choice([0, 1, 2, 3], size=m, p=[0.45, 0.45, 0.08, 0.02]).astype(np.uint16)
+    strand = (rng.random(m) < float(rng.choice([0.0, 0.5, 1.0, 0.9]))).astype(np.uint16)
+    bq = rng.integers(0, 8192, m).astype(np.uint16) if rng.random() < 0.3 else rng.integers(2, 46, m).astype(np.uint16)
+    obs = (allele | (strand << 2) | (bq << 3)).astype(np.uint16)
+    got = engine.pileup_tally(off, obs)
+    exp = O.pileup_tally(off, obs)
+    for k in ("ref_fwd", "ref_rev", "alt_fwd", "alt_rev", "other", "dp", "bq_ref", "bq_alt", "ad_ref", "ad_alt"):
+        assert np.array_equal(got[k], exp[k]), (k, seed)
+    assert np.array_equal(got["vaf"], exp["vaf"]), seed
+    assert np.max(np.abs(got["sor"] - exp["sor"]), initial=0.0) <= 1e-5, seed
