@@ -121,6 +121,9 @@ int ugvc_model_upload(ugvc_ctx* ctx, int group, int kind, const int32_t* feature
                       int32_t n_nodes, const int32_t* tree_root, int32_t n_trees,
                       const double* leaf_value, int32_t n_leaves, int32_t n_features,
                       float base_score, int32_t max_depth);
+/* No model for this variant type (a re-configured context forgets the previous one): its variants get
+ * tree_score 0 and FILTER PASS, as when the reference's model dict has no entry for the type. */
+int ugvc_model_clear(ugvc_ctx* ctx, int group);
 
 /* ---- the hot path ----------------------------------------------------------------------
  * ugvc_filter_variants: annotate_concordance + blacklist apply + model predict + FILTER

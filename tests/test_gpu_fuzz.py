@@ -91,3 +91,86 @@ def test_random_pileups(engine, seed):
         assert np.array_equal(got[k], exp[k]), (k, seed)
     assert np.array_equal(got["vaf"], exp["vaf"]), seed
     assert np.max(np.abs(got["sor"] - exp["sor"]), initial=0.0) <= 1e-5, seed
+
+
+def _random_forest(rng, kind, n_features, n_trees, max_depth, normalised=True):
+    """A random ensemble in the pointer layout: unbalanced trees, repeated / extreme thresholds, any feature."""
+    from variantcalling_amd import schema as S
+    feat, thr, left, right, roots, leaves = [], [], [], [], [], []
+
+    def threshold(f):
+        if f == 0: return float(rng.choice([rng.exponential(60.0), 0.0, 2999.5, 1e6, -1.0]))
+        if f == 1: return float(rng.choice([rng.lognormal(0, 0.7), 0.0, 7.5]))
+        if f in (5, 13): return float(rng.choice([rng.random(), 0.0, 0.5, 1.0, 1.5, -0.25]))
+        if f in (11, 12): return float(rng.integers(0, 3125)) + float(rng.choice([0.0, 0.5]))
+        if f >= 15: return float(rng.choice([0.5, 0.5, 0.5, 0.25, 1.5]))
+        if f in (7, 10, 14): return float(rng.integers(0, 5)) + 0.5
+        return float(rng.integers(-1, 80)) + float(rng.choice([0.0, 0.5]))
+
+    def grow(depth):
+        me = len(feat)
+        feat.append(0); thr.append(0.0); left.append(0); right.append(0)
+        if depth >= max_depth or (depth > 0 and rng.random() < 0.25):
+            feat[me] = -1
+            left[me] = len(leaves)
+            if kind == S.MODEL_RF:
+                if normalised:
+                    n0, n1 = float(rng.integers(0, 50)), float(rng.integers(0, 50))
+                    if n0 + n1 == 0: n1 = 1.0
+                    leaves.append((n0 / (n0 + n1), n1 / (n0 + n1)))
+                else:
+                    leaves.append((float(rng.integers(0, 9)), float(rng.integers(1, 9))))
+            else:
+                leaves.append((float(np.float32(rng.normal(0, 0.3))), 0.0))
+            return me
+        f = int(rng.integers(0, n_features))
+        feat[me] = f
+        thr[me] = threshold(f)
+        left[me] = grow(depth + 1)
+        right[me] = grow(depth + 1)
+        return me
+
+    for _ in range(n_trees):
+        roots.append(grow(0))
+    return S.FlatForest(kind, np.array(feat, np.int32), np.array(thr, np.float32), np.array(left, np.int32),
+                        np.array(right, np.int32), np.array(roots, np.int32), np.array(leaves, np.float64),
+                        n_features=n_features, base_score=float(np.float32(rng.normal(0, 0.2))) if kind == S.MODEL_GBT else 0.0,
+                        max_depth=0)
+
+
+@pytest.mark.parametrize("seed", list(range(64)))
+def test_random_models(engine, small_callset, seed):
+    """Random ensembles (depth 1..10, 1..48 trees, any feature mix, odd thresholds, normalised and raw-count
+    payloads, missing groups) through every kernel path: exercises the rank coding, the code tables, the LDS
+    layouts and their fallbacks."""
+    from oracle import oracle as O
+    from variantcalling_amd import schema as S
+    from variantcalling_amd.engine import configure
+    cs = small_callset
+    rng = np.random.default_rng(9000 + seed)
+    kind = S.MODEL_RF if rng.random() < 0.7 else S.MODEL_GBT
+    nf = 17 + len(cs.tracks)
+    forests = []
+    for g in range(3):
+        if rng.random() < 0.15 and g > 0:
+            forests.append(None)                              # no model for this variant type: score 0, PASS
+            continue
+        forests.append(_random_forest(rng, kind, nf, int(rng.integers(1, 49)), int(rng.integers(1, 11)),
+                                      normalised=bool(rng.random() < 0.8)))
+    from variantcalling_amd import model_io
+    for f in forests:
+        if f is not None:
+            f.max_depth = max(model_io._depth(f.left, f.right, f.feature, int(r)) for r in f.tree_root)
+    configure(engine, cs.ref, cs.runs, cs.tracks, cs.blacklist, forests, "TGCA", 10, 10, True)
+    exp = O.filter_variants(cs.variants, cs.ref, cs.runs, cs.tracks, cs.blacklist, forests)
+    for path in (0, 128, 1024, 512, 256):
+        engine.set_kernel_variant(path)
+        res = engine.filter_variants(cs.variants)
+        what = f"seed {seed} path {path} kind {kind}"
+        assert np.array_equal(res.filter, exp.filter), what
+        assert np.array_equal(res.flags, exp.flags), what
+        if kind == S.MODEL_RF:
+            assert np.array_equal(res.tree_score, exp.tree_score), what
+        else:
+            assert np.max(np.abs(res.tree_score - exp.tree_score)) <= 1e-6, what
+    engine.set_kernel_variant(0)

@@ -390,6 +390,15 @@ int ugvc_model_upload(ugvc_ctx* ctx, int group, int kind, const int32_t* feature
                             n_leaves, n_features, kind, base_score, depth);
 }
 
+int ugvc_model_clear(ugvc_ctx* ctx, int group) {
+    if (!ctx) return fail("ctx is NULL");
+    if (group < 0 || group >= UGVC_N_GROUPS) return fail("group out of range");
+    UGVC_HIP(hipSetDevice(ctx->device));
+    UGVC_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->model[group].set = 0;
+    return clear_model_group(ctx, group);
+}
+
 static int check_variants(const ugvc_variants* v) {
     if (!v) return fail("variants is NULL");
     if (v->n < 0) return fail("negative variant count");

@@ -66,6 +66,19 @@ void v2_destroy(ugvc_ctx* ctx) {
     ctx->v2 = nullptr;
 }
 
+static void release_group(V2Group& g) {          // device tables of the previous model of this group, then a clean slate
+    for (DeviceBuf* b : {&g.d_nodes, &g.d_leaf_idx, &g.d_pairs, &g.d_leaf_f32, &g.d_plane_desc, &g.d_hi4, &g.d_last4, &g.d_p1})
+        if (b->p) (void)hipFree(b->p);
+    g = V2Group();
+}
+
+int clear_model_group(ugvc_ctx* ctx, int gi) {
+    V2State* s = state(ctx);
+    release_group(s->g[gi]);
+    s->dirty = true;
+    return 0;
+}
+
 static bool search_only_feature(int j) { return j == 0 || j == 1 || j == 5 || j == 13; }  // qual sor vaf gc
 
 int pack_model_group(ugvc_ctx* ctx, int gi, const int32_t* feature, const float* threshold, const int32_t* left,
@@ -73,7 +86,7 @@ int pack_model_group(ugvc_ctx* ctx, int gi, const int32_t* feature, const float*
                      const double* leaf_value, int n_leaves, int n_features, int kind, float base, int depth) {
     V2State* s = state(ctx);
     V2Group& g = s->g[gi];
-    g = V2Group();
+    release_group(g);
     g.set = true;
     g.kind = kind; g.T = n_trees; g.D = depth; g.base = base; g.n_features = n_features;
     g.feature.assign(feature, feature + n_nodes);

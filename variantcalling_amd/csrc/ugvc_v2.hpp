@@ -88,6 +88,7 @@ int pack_model_group(ugvc_ctx* ctx, int g, const int32_t* feature, const float* 
                      const int32_t* left, const int32_t* right, int n_nodes, const int32_t* tree_root,
                      int n_trees, const double* leaf_value, int n_leaves, int n_features, int kind,
                      float base, int depth);
+int clear_model_group(ugvc_ctx* ctx, int g);
 int finalize_pack(ugvc_ctx* ctx);
 int build_css_lut(ugvc_ctx* ctx);
 bool v2_available(ugvc_ctx* ctx);

@@ -59,6 +59,7 @@ ABI = {
     "ugvc_set_flow_order": (C.c_int, [_ctx, C.c_char_p]),
     "ugvc_model_upload": (C.c_int, [_ctx, C.c_int, C.c_int, _i32p, _f32p, _i32p, _i32p, C.c_int32, _i32p,
                                     C.c_int32, _f64p, C.c_int32, C.c_int32, C.c_float, C.c_int32]),
+    "ugvc_model_clear": (C.c_int, [_ctx, C.c_int]),
     "ugvc_filter_variants": (C.c_int, [_ctx, C.POINTER(CVariants), C.POINTER(CResults)]),
     "ugvc_variants_upload": (C.c_int, [_ctx, C.POINTER(CVariants)]),
     "ugvc_filter_resident": (C.c_int, [_ctx]),
@@ -207,6 +208,10 @@ class Engine:
         for g, f in enumerate(forests):
             if f is not None:
                 self.set_model(g, f)
+            else:                           # a re-configured context must not keep the previous job's model
+                self._check(self.lib.ugvc_model_clear(self._h, g))
+        for g in range(len(forests), S.N_GROUPS):
+            self._check(self.lib.ugvc_model_clear(self._h, g))
 
     def set_kernel_variant(self, v: int):
         self._check(self.lib.ugvc_set_kernel_variant(self._h, v))
