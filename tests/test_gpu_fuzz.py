@@ -174,3 +174,93 @@ def test_random_models(engine, small_callset, seed):
         else:
             assert np.max(np.abs(res.tree_score - exp.tree_score)) <= 1e-6, what
     engine.set_kernel_variant(0)
+
+
+@pytest.mark.parametrize("seed", list(range(40)))
+def test_random_side_tables_and_clustered_variants(engine, small_callset, frozen_models, seed):
+    """Variants piled into a few clusters (dense tiles, repeated positions, contig starts and ends) against random
+    interval tables: empty, sparse, or an interval every few bases (the staged slices overflow the LDS pool), runs
+    of random lengths, blacklist keys on and next to variants and on tile boundaries."""
+    import copy
+    from oracle import oracle as O
+    from variantcalling_amd import schema as S
+    from variantcalling_amd.engine import configure
+    from variantcalling_amd.io import bed
+    cs = small_callset
+    ref = cs.ref
+    rng = np.random.default_rng(11_000 + seed)
+    nc = ref.n_contigs
+    clen = np.diff(ref.contig_off).astype(np.int64)
+    n = int(rng.choice([300, 5_000, 30_000]))
+    vt = copy.deepcopy(cs.variants.slice(0, n))
+    contig = np.sort(rng.integers(0, nc, n)).astype(np.uint8) if rng.random() < 0.8 else np.full(n, int(rng.integers(0, nc)), np.uint8)
+    pos = np.zeros(n, np.int64)
+    for c in range(nc):
+        m = contig == c
+        k = int(m.sum())
+        if not k:
+            continue
+        centers = rng.choice(np.array([1, 2, clen[c] // 2, clen[c] - 1, clen[c]] + list(rng.integers(1, clen[c], 3))),
+                             size=k)
+        spread = int(rng.choice([1, 50, 5000, 2_000_000]))
+        pos[m] = np.sort(np.clip(centers + rng.integers(-spread, spread + 1, k), 1, clen[c]))
+    vt.contig, vt.pos = contig, pos.astype(np.int32)
+    # longest allele must still fit the contig for deletions: keep the table valid
+    vt.validate()
+
+    def random_track(name, density, merge=True):
+        cc, ss, ee = [], [], []
+        for c in range(nc):
+            k = int(rng.poisson(density * clen[c])) if density > 0 else 0
+            k = min(k, 400_000)
+            st = rng.integers(0, clen[c], k)
+            ln = rng.geometric(float(rng.choice([0.5, 0.05, 0.002])), k)
+            if k and rng.random() < 0.5:
+                st[0], ln[0] = 0, 7                                  # abuts the contig start
+                st[-1], ln[-1] = clen[c] - 3, 3                      # and its end
+            cc.append(np.full(k, c)); ss.append(st); ee.append(np.minimum(st + ln, clen[c]))
+        return bed.track_from_arrays(np.concatenate(cc).astype(np.int64), np.concatenate(ss).astype(np.int64),
+                                     np.concatenate(ee).astype(np.int64), nc, name, merge)
+
+    dens = [float(rng.choice([0.0, 1e-6, 1e-4, 3e-3])) for _ in range(3)]
+    if rng.random() < 0.4:
+        # an interval every ~4 bases around the variant clusters of contig 0: dense tiles
+        lo = max(0, int(pos[contig == contig[0]].min()) - 2000)
+        st = np.arange(lo, min(lo + 400_000, clen[contig[0]] - 2), 4)
+        dense = bed.track_from_arrays(np.full(st.size, int(contig[0]), np.int64), st, st + 2, nc, "dense", True)
+    else:
+        dense = None
+    tracks = [random_track(f"t{j}", dens[j]) for j in range(3)]
+    if dense is not None:
+        tracks[int(rng.integers(0, 3))] = dense
+    runs = random_track("runs", float(rng.choice([0.0, 2e-4, 2e-3])), merge=True)
+
+    def overlapping(tr):                                             # overlapping intervals whose ends still ascend per contig
+        ends = tr.ends.astype(np.int64).copy()
+        for c in range(nc):
+            a, b = int(tr.contig_ptr[c]), int(tr.contig_ptr[c + 1])
+            if b > a:
+                ends[a:b] = np.maximum.accumulate(ends[a:b])
+        return S.IntervalTrack(tr.starts, ends.astype(np.int32), tr.contig_ptr, tr.name)
+    if rng.random() < 0.3:
+        j = int(rng.integers(0, 3))
+        if tracks[j] is not dense:
+            tracks[j] = overlapping(random_track("ov", 3e-4, merge=False))
+    if rng.random() < 0.15:
+        runs = overlapping(random_track("ovruns", 2e-4, merge=False))   # overlapping runs: the v2 kernels take over
+    keys = vt.keys()
+    bl_parts = [keys[:: int(rng.integers(1, 7))], keys[255::256], keys[::256] + np.uint64(1), keys[::97] - np.uint64(1),
+                (rng.integers(0, nc, 2000).astype(np.uint64) << np.uint64(32)) | rng.integers(1, int(clen.min()), 2000).astype(np.uint64)]
+    bl = np.unique(np.concatenate(bl_parts)) if rng.random() < 0.85 else None
+    hp_len, hp_dist = int(rng.choice([1, 10])), int(rng.choice([0, 3, 10, 1000]))
+    forests = frozen_models[RF]
+    configure(engine, ref, runs, tracks, bl, forests, "TGCA", hp_len, hp_dist, True)
+    exp = O.filter_variants(vt, ref, runs, tracks, bl, forests, hpol_len=hp_len, hpol_dist=hp_dist)
+    for path in (0, 128, 512, 256):
+        engine.set_kernel_variant(path)
+        res = engine.filter_variants(vt)
+        what = f"seed {seed} path {path}"
+        assert np.array_equal(res.flags, exp.flags), what
+        assert np.array_equal(res.filter, exp.filter), what
+        assert np.array_equal(res.tree_score, exp.tree_score), what
+    engine.set_kernel_variant(0)
