@@ -93,7 +93,7 @@ def test_random_pileups(engine, seed):
     assert np.max(np.abs(got["sor"] - exp["sor"]), initial=0.0) <= 1e-5, seed
 
 
-def _random_forest(rng, kind, n_features, n_trees, max_depth, normalised=True):
+def _random_forest(rng, kind, n_features, n_trees, max_depth, normalised=True):        # normalised: True | "coarse" | False
     """A random ensemble in the pointer layout: unbalanced trees, repeated / extreme thresholds, any feature."""
     from variantcalling_amd import schema as S
     feat, thr, left, right, roots, leaves = [], [], [], [], [], []
@@ -115,7 +115,8 @@ def _random_forest(rng, kind, n_features, n_trees, max_depth, normalised=True):
             left[me] = len(leaves)
             if kind == S.MODEL_RF:
                 if normalised:
-                    n0, n1 = float(rng.integers(0, 50)), float(rng.integers(0, 50))
+                    top = 3 if normalised == "coarse" else 50          # coarse fractions: exact vote ties are common
+                    n0, n1 = float(rng.integers(0, top)), float(rng.integers(0, top))
                     if n0 + n1 == 0: n1 = 1.0
                     leaves.append((n0 / (n0 + n1), n1 / (n0 + n1)))
                 else:
@@ -156,7 +157,7 @@ def test_random_models(engine, small_callset, seed):
             forests.append(None)                              # no model for this variant type: score 0, PASS
             continue
         forests.append(_random_forest(rng, kind, nf, int(rng.integers(1, 49)), int(rng.integers(1, 11)),
-                                      normalised=bool(rng.random() < 0.8)))
+                                      normalised=[True, True, "coarse", "coarse", False][int(rng.integers(0, 5))]))
     from variantcalling_amd import model_io
     for f in forests:
         if f is not None:
@@ -256,6 +257,91 @@ def test_random_side_tables_and_clustered_variants(engine, small_callset, frozen
     forests = frozen_models[RF]
     configure(engine, ref, runs, tracks, bl, forests, "TGCA", hp_len, hp_dist, True)
     exp = O.filter_variants(vt, ref, runs, tracks, bl, forests, hpol_len=hp_len, hpol_dist=hp_dist)
+    for path in (0, 128, 512, 256):
+        engine.set_kernel_variant(path)
+        res = engine.filter_variants(vt)
+        what = f"seed {seed} path {path}"
+        assert np.array_equal(res.flags, exp.flags), what
+        assert np.array_equal(res.filter, exp.filter), what
+        assert np.array_equal(res.tree_score, exp.tree_score), what
+    engine.set_kernel_variant(0)
+
+
+@pytest.mark.parametrize("seed", list(range(30)))
+def test_random_alleles_on_a_homopolymer_rich_reference(engine, frozen_models, seed):
+    """A small synthetic reference full of long homopolymers, N blocks and tiny contigs; variants with hand-made
+    alleles: hmer insertions / deletions of every length (runs longer than the 12-base look-ahead and the 48-byte
+    window), long deletions, multi-base substitutions, N alleles, alleles that run over the contig end."""
+    from oracle import oracle as O
+    from variantcalling_amd import schema as S
+    from variantcalling_amd.engine import configure
+    rng = np.random.default_rng(13_000 + seed)
+    nc = int(rng.choice([1, 3, 6]))
+    parts = []
+    for c in range(nc):
+        L = int(rng.choice([7, 60, 5_000, 60_000]))
+        seq = rng.integers(1, 5, L).astype(np.uint8)
+        for _ in range(int(rng.integers(0, 1 + L // 200))):          # homopolymers, some far longer than the window
+            a = int(rng.integers(0, L)); ln = int(rng.choice([2, 5, 11, 12, 13, 30, 47, 48, 49, 200]))
+            seq[a: a + ln] = int(rng.integers(1, 5))
+        for _ in range(int(rng.integers(0, 3))):                     # N blocks
+            a = int(rng.integers(0, L)); seq[a: a + int(rng.choice([1, 20, 300]))] = 0
+        parts.append(seq)
+    off = np.concatenate([[0], np.cumsum([p.size for p in parts])]).astype(np.int64)
+    ref = S.Reference(np.concatenate(parts), off, [f"c{c}" for c in range(nc)])
+    rows = []
+    n = int(rng.choice([50, 700, 4000]))
+    for _ in range(n):
+        c = int(rng.integers(0, nc)); L = parts[c].size
+        pos = int(rng.integers(1, L + 1))
+        kind = rng.choice(["snv", "ins_h", "del_h", "ins", "del", "mnp", "nall", "longdel"])
+        r0 = int(parts[c][pos - 1]) or 1
+        nxt = int(parts[c][pos]) if pos < L else int(rng.integers(1, 5))
+        if kind == "snv":
+            refa, alta = [r0], [int(rng.integers(0, 5))]
+        elif kind == "ins_h":
+            refa, alta = [r0], [r0] + [nxt or 1] * int(rng.choice([1, 2, 8, 9, 10, 30]))
+        elif kind == "del_h":
+            k = int(rng.choice([1, 2, 8, 9, 12, 40]))
+            refa, alta = [r0] + [int(x) for x in parts[c][pos: pos + k]], [r0]
+            if len(refa) == 1:
+                refa = [r0, nxt or 1]
+        elif kind == "ins":
+            refa, alta = [r0], [r0] + [int(x) for x in rng.integers(0, 5, int(rng.integers(1, 12)))]
+        elif kind == "del":
+            refa, alta = [r0] + [int(x) for x in rng.integers(1, 5, int(rng.integers(1, 12)))], [r0]
+        elif kind == "mnp":
+            k = int(rng.integers(2, 6))
+            refa, alta = [int(x) for x in rng.integers(1, 5, k)], [int(x) for x in rng.integers(0, 5, k)]
+        elif kind == "nall":
+            refa, alta = [0], [0, 0]
+        else:
+            k = int(rng.choice([60, 300, 2000]))
+            refa, alta = [r0] + [int(x) for x in rng.integers(1, 5, k)], [r0]
+        if refa == alta:
+            alta = alta + [1]
+        rows.append((c, pos, refa, alta))
+    rows.sort(key=lambda r: (r[0], r[1]))
+    pool, ro, ao = [], [], []
+    for _, _, refa, alta in rows:
+        ro.append(len(pool)); pool += refa
+        ao.append(len(pool)); pool += alta
+    m = len(rows)
+    vt = S.VariantTable(
+        contig=np.array([r[0] for r in rows], np.uint8), pos=np.array([r[1] for r in rows], np.int32),
+        ref_len=np.array([len(r[2]) for r in rows], np.uint16), alt_len=np.array([len(r[3]) for r in rows], np.uint16),
+        ref_off=np.array(ro, np.uint32), alt_off=np.array(ao, np.uint32), alleles=np.array(pool, np.uint8),
+        qual=rng.exponential(60, m).astype(np.float32), sor=rng.lognormal(0, 0.7, m).astype(np.float32),
+        dp=rng.poisson(30, m).astype(np.int32), ad_ref=rng.poisson(15, m).astype(np.int32),
+        ad_alt=rng.poisson(15, m).astype(np.int32), gq=rng.integers(0, 100, m).astype(np.uint8), gt=np.ones(m, np.uint8))
+    vt.validate()
+    flow = str(rng.choice(["TGCA", "ACGT", "GATC"]))
+    forests = frozen_models[RF]
+    # the frozen model tests three track features: give it three (empty) tracks, no runs, no blacklist
+    empty = [S.IntervalTrack(np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(nc + 1, np.int32), f"t{j}") for j in range(3)]
+    configure(engine, ref, None, empty, None, forests, flow, 10, 10, True)
+    exp = O.filter_variants(vt, ref, None, empty, None, forests, flow_order=flow)
+    X_exp = None
     for path in (0, 128, 512, 256):
         engine.set_kernel_variant(path)
         res = engine.filter_variants(vt)
