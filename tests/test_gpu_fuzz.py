@@ -350,3 +350,23 @@ def test_random_alleles_on_a_homopolymer_rich_reference(engine, frozen_models, s
         assert np.array_equal(res.filter, exp.filter), what
         assert np.array_equal(res.tree_score, exp.tree_score), what
     engine.set_kernel_variant(0)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_shards_scored_alone_reassemble_to_the_whole(engine, small_callset, frozen_models, world):
+    """What every rank of a multi-GPU run does (score its equal-count slice on its own) gives, slice
+    by slice, the columns of the single-GPU run: no result depends on a neighbour outside the slice."""
+    from variantcalling_amd import shard, schema as S
+    from variantcalling_amd.engine import configure
+    cs = small_callset
+    configure(engine, cs.ref, cs.runs, cs.tracks, cs.blacklist, frozen_models[RF], "TGCA", 10, 10, True)
+    whole = engine.filter_variants(cs.variants)
+    parts, counts = [], []
+    cap = shard.shard_cap(cs.variants.n, world)
+    for r in range(world):
+        mine = shard.shard_of(cs.variants, r, world)
+        parts.append(shard.pad_result(engine.filter_variants(mine), cap))
+        counts.append(mine.n)
+    got = shard.reassemble(parts, counts)
+    assert np.array_equal(got.filter, whole.filter) and np.array_equal(got.flags, whole.flags)
+    assert np.array_equal(got.tree_score, whole.tree_score)
