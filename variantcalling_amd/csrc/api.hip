@@ -34,6 +34,14 @@ int upload(ugvc_ctx* ctx, DeviceBuf& b, const void* src, size_t bytes) {
     return 0;
 }
 
+// every 64th element of a sorted table: the L2-resident first level of K0's bracket search
+template <class T>
+static int upload_coarse(ugvc_ctx* ctx, DeviceBuf& dst, const T* a, int64_t n) {
+    std::vector<T> c((size_t)((n + 63) / 64));
+    for (size_t k = 0; k < c.size(); ++k) c[k] = a[k * 64];
+    return upload(ctx, dst, c.data(), c.size() * sizeof(T));
+}
+
 static void release(DeviceBuf& b) {
     if (b.p) (void)hipFree(b.p);
     b.p = nullptr;
@@ -59,16 +67,17 @@ int build_args(ugvc_ctx* ctx, FilterArgs& a, bool want_x) {
     a.gq = ctx->v_gq.as<uint8_t>();
     a.ref = ctx->ref.as<uint8_t>() + kRefFrontPad;
     a.contig_off = ctx->contig_off.as<int64_t>();
-    a.runs = TrackView{ctx->runs_s.as<int32_t>(), ctx->runs_e.as<int32_t>(), ctx->runs_p.as<int32_t>()};
+    a.runs = TrackView{ctx->runs_s.as<int32_t>(), ctx->runs_e.as<int32_t>(), ctx->runs_p.as<int32_t>(), ctx->runs_c.as<int32_t>()};
     a.has_runs = ctx->has_runs;
     a.hpol_dist = ctx->hpol_dist;
     a.mark_hpol = ctx->mark_hpol;
     a.n_tracks = ctx->n_tracks;
     for (int t = 0; t < ctx->n_tracks; ++t) {
         if (!ctx->track_set[t]) return fail("annotation track " + std::to_string(t) + " not uploaded");
-        a.tracks[t] = TrackView{ctx->trk_s[t].as<int32_t>(), ctx->trk_e[t].as<int32_t>(), ctx->trk_p[t].as<int32_t>()};
+        a.tracks[t] = TrackView{ctx->trk_s[t].as<int32_t>(), ctx->trk_e[t].as<int32_t>(), ctx->trk_p[t].as<int32_t>(), ctx->trk_c[t].as<int32_t>()};
     }
     a.bl = ctx->bl.as<uint64_t>();
+    a.bl_coarse = ctx->bl_c.as<uint64_t>();
     a.n_bl = ctx->n_bl;
     const int F = UGVC_N_BASE_FEATURES + ctx->n_tracks;
     for (int g = 0; g < UGVC_N_GROUPS; ++g) {
@@ -154,7 +163,7 @@ int ugvc_ctx_destroy(ugvc_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     ugvc_comm_destroy(ctx);
     v2_destroy(ctx);
-    DeviceBuf* all[] = {&ctx->ref, &ctx->contig_off, &ctx->runs_s, &ctx->runs_e, &ctx->runs_p, &ctx->bl, &ctx->bl_ptr, &ctx->v_tiles,
+    DeviceBuf* all[] = {&ctx->ref, &ctx->contig_off, &ctx->runs_s, &ctx->runs_e, &ctx->runs_p, &ctx->runs_c, &ctx->bl, &ctx->bl_ptr, &ctx->bl_c, &ctx->v_tiles,
                         &ctx->v_contig, &ctx->v_pos, &ctx->v_rl, &ctx->v_al, &ctx->v_ro, &ctx->v_ao,
                         &ctx->v_alleles, &ctx->v_qual, &ctx->v_sor, &ctx->v_dp, &ctx->v_adr, &ctx->v_ada,
                         &ctx->v_gq, &ctx->r_score, &ctx->r_filter, &ctx->r_flags, &ctx->x_mat, &ctx->x_group,
@@ -165,6 +174,7 @@ int ugvc_ctx_destroy(ugvc_ctx* ctx) {
         release(ctx->trk_s[t]);
         release(ctx->trk_e[t]);
         release(ctx->trk_p[t]);
+        release(ctx->trk_c[t]);
     }
     for (auto& m : ctx->model) {
         release(m.nodes); release(m.roots); release(m.leaves); release(m.dense); release(m.dense_leaves);
@@ -256,6 +266,7 @@ int ugvc_runs_upload(ugvc_ctx* ctx, const int32_t* starts, const int32_t* ends, 
     if (upload(ctx, ctx->runs_s, s.data(), s.size() * 4)) return -1;
     if (upload(ctx, ctx->runs_e, e.data(), e.size() * 4)) return -1;
     if (upload(ctx, ctx->runs_p, p.data(), p.size() * 4)) return -1;
+    if (upload_coarse(ctx, ctx->runs_c, s.data(), (int64_t)s.size())) return -1;
     UGVC_HIP(hipStreamSynchronize(ctx->stream));
     ctx->runs_n = (int64_t)s.size();
     ctx->runs_fast = 1;           // the v3 kernel derives #ends < pos from #starts < pos: needs disjoint sorted runs
@@ -276,6 +287,7 @@ int ugvc_track_upload(ugvc_ctx* ctx, int track_id, const int32_t* starts, const 
     if (upload(ctx, ctx->trk_s[track_id], starts, (size_t)n * 4)) return -1;
     if (upload(ctx, ctx->trk_e[track_id], ends, (size_t)n * 4)) return -1;
     if (upload(ctx, ctx->trk_p[track_id], contig_ptr, (size_t)(ctx->n_contigs + 1) * 4)) return -1;
+    if (upload_coarse(ctx, ctx->trk_c[track_id], starts, n)) return -1;
     UGVC_HIP(hipStreamSynchronize(ctx->stream));
     ctx->trk_n[track_id] = n;
     ctx->trk_fast[track_id] = 1;
@@ -304,6 +316,7 @@ int ugvc_blacklist_upload(ugvc_ctx* ctx, const uint64_t* keys, int64_t n) {
         for (int c = 0; c <= 257; ++c)
             bp[c] = (int32_t)(std::lower_bound(keys, keys + n, (uint64_t)c << 32) - keys);
     if (upload(ctx, ctx->bl_ptr, bp.data(), bp.size() * 4)) return -1;
+    if (upload_coarse(ctx, ctx->bl_c, keys, n)) return -1;
     UGVC_HIP(hipStreamSynchronize(ctx->stream));
     ctx->n_bl = n;
     return 0;

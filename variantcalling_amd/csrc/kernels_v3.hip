@@ -82,31 +82,34 @@ __device__ __forceinline__ bool table_present(const FilterArgs& f, int t) {
     return t == 0 ? f.has_runs != 0 : (t - 1) < f.n_tracks;
 }
 
-// 16-ary lower bound: 15 independent pivot loads per round instead of one dependent load per halving - K0 is
-// pure latency (one search per tile and table), so rounds, not loads, are what it pays for (22 -> 6 rounds on a
-// 3 M-entry table).
+// Two-level lower bound: the 1/64 sample `coarse` (coarse[k] = a[64 k], L2-resident) narrows [lo, hi) to one
+// 64-element block, the block itself is finished by binary search: ~16 L2-hit steps + 6 steps on two cache lines
+// instead of 22 steps of HBM latency.
 template <class T>
-__device__ __forceinline__ int lb_wide_g(const T* __restrict__ a, int lo, int hi, T key) {
-    while (hi - lo > 16) {
-        const int step = (hi - lo) >> 4;
-        T x[15];
-#pragma unroll
-        for (int k = 0; k < 15; ++k) x[k] = a[lo + (k + 1) * step];
-        int c = 0;
-#pragma unroll
-        for (int k = 0; k < 15; ++k) c += x[k] < key ? 1 : 0;          // sorted: the pivots below the key are a prefix
-        const int nlo = c == 0 ? lo : lo + c * step + 1;
-        hi = c == 15 ? hi : lo + (c + 1) * step;
-        lo = nlo;
+__device__ __forceinline__ int lb_two_level_g(const T* __restrict__ a, const T* __restrict__ coarse, int lo, int hi, T key) {
+    if (coarse && hi - lo > 128) {
+        // blocks whose first element lies inside (lo, hi): j in [jl, jh); count those below the key
+        const int jl = (lo >> 6) + 1, jh = (hi + 63) >> 6;
+        int base = jl, len = jh - jl;
+        while (len > 0) {
+            const int half = len >> 1;
+            const bool lt = coarse[base + half] < key;
+            base = lt ? base + half + 1 : base;
+            len = lt ? len - half - 1 : half;
+        }
+        // base = first block in [jl, jh] whose first element is >= key: the answer lies in block base - 1 (or at its end)
+        const int blo = (base - 1) << 6, bhi = base << 6;
+        lo = blo > lo ? blo : lo;
+        hi = bhi < hi ? bhi : hi;
     }
-    const int n = hi - lo;
-    int c = 0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const T x = k < n ? a[lo + k] : key;
-        c += (k < n && x < key) ? 1 : 0;
+    int b = lo, len = hi - lo;
+    while (len > 0) {
+        const int half = len >> 1;
+        const bool lt = a[b + half] < key;
+        b = lt ? b + half + 1 : b;
+        len = lt ? len - half - 1 : half;
     }
-    return lo + c;
+    return b;
 }
 
 // ---- K0: brackets3[b][a] = first index of searched array a (a < 6: starts of table a; a == 6:
@@ -119,10 +122,6 @@ __global__ void bracket3_kernel(const V2Args v) {
     const int b = (int)(gid >> 3), a = (int)(gid & 7);
     if (b > nb || a >= kJoin3) return;
     const FilterArgs& f = v.f;
-    // few tiles (a shard of a multi-GPU run): the launch is pure latency and the 16-ary search wins (10.8 us at
-    // 2.4 K tiles); many tiles: the searches overlap one another and the binary search's fewer loads win
-    // (19.7 vs 23.6 us at 19.5 K tiles)
-    const bool wide = nb < 8192;
     int out = 0;
     if (a == kJoin3 - 1) {
         if (f.n_bl > 0) {
@@ -130,7 +129,7 @@ __global__ void bracket3_kernel(const V2Args v) {
             else {
                 const int64_t i = (int64_t)b * kBlock;
                 const uint64_t key = ((uint64_t)f.contig[i] << 32) | (uint32_t)f.pos[i];
-                out = wide ? lb_wide_g<uint64_t>(f.bl, 0, (int)f.n_bl, key) : lb_u64_g(f.bl, 0, (int)f.n_bl, key);
+                out = lb_two_level_g<uint64_t>(f.bl, f.bl_coarse, 0, (int)f.n_bl, key);
             }
         }
     } else if (table_present(f, a)) {
@@ -139,8 +138,7 @@ __global__ void bracket3_kernel(const V2Args v) {
         else {
             const int64_t i = (int64_t)b * kBlock;
             const int c = f.contig[i];
-            out = wide ? lb_wide_g<int32_t>(tv.starts, tv.ptr[c], tv.ptr[c + 1], f.pos[i])
-                       : lb_i32_g(tv.starts, tv.ptr[c], tv.ptr[c + 1], f.pos[i]);
+            out = lb_two_level_g<int32_t>(tv.starts, tv.coarse, tv.ptr[c], tv.ptr[c + 1], f.pos[i]);
         }
     }
     v.brackets3[gid] = out;

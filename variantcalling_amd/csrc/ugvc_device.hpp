@@ -42,6 +42,7 @@ struct TrackView {
     const int32_t* starts;
     const int32_t* ends;
     const int32_t* ptr;        // CSR by contig
+    const int32_t* coarse;     // starts[64 k]: a 1/64 sample that stays in L2 (K0's bracket search), or null
 };
 
 struct FilterArgs {
@@ -68,6 +69,7 @@ struct FilterArgs {
     TrackView tracks[UGVC_MAX_TRACKS];
     int n_tracks;
     const uint64_t* bl;
+    const uint64_t* bl_coarse; // bl[64 k], or null
     int64_t n_bl;
     ForestView forest[UGVC_N_GROUPS];
     uint8_t flow[4];
@@ -99,15 +101,15 @@ struct ugvc_ctx {
     ugvc::DeviceBuf ref, contig_off;
     int n_contigs = 0;
     int64_t ref_len = 0;
-    ugvc::DeviceBuf runs_s, runs_e, runs_p;
+    ugvc::DeviceBuf runs_s, runs_e, runs_p, runs_c;
     int has_runs = 0, hpol_dist = 10, mark_hpol = 1;
-    ugvc::DeviceBuf trk_s[UGVC_MAX_TRACKS], trk_e[UGVC_MAX_TRACKS], trk_p[UGVC_MAX_TRACKS];
+    ugvc::DeviceBuf trk_s[UGVC_MAX_TRACKS], trk_e[UGVC_MAX_TRACKS], trk_p[UGVC_MAX_TRACKS], trk_c[UGVC_MAX_TRACKS];
     int track_set[UGVC_MAX_TRACKS] = {0, 0, 0, 0, 0};
     int n_tracks = 0;
     int64_t runs_n = 0, trk_n[UGVC_MAX_TRACKS] = {0, 0, 0, 0, 0};
     // v3 needs: runs disjoint and sorted; tracks with non-decreasing starts AND ends per contig
     int runs_fast = 1, trk_fast[UGVC_MAX_TRACKS] = {1, 1, 1, 1, 1};
-    ugvc::DeviceBuf bl, bl_ptr;        // bl_ptr: first key of every contig id 0..256 (v4 kernel)
+    ugvc::DeviceBuf bl, bl_ptr, bl_c;  // bl_ptr: first key of every contig id 0..256 (v4 kernel); bl_c: every 64th key
     int64_t n_bl = 0;
     uint8_t flow[4] = {4, 3, 2, 1};   // TGCA
     struct Model {
