@@ -3,5 +3,5 @@ set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-free -g | head -2
-( time timeout 900 python bench.py --variants 50000000 --steps 10 --warmup 2 --cpu-sample 0 ) 2>&1 | tail -5 | tee gpurun_out/bench_50M.log | cut -c1-900
+timeout 600 python bench.py --variants 1000000 --snv-only --steps 50 --warmup 5 2>&1 | tail -1 | tee gpurun_out/bench_c2.json | cut -c1-400
+timeout 600 python tools/bench_c5.py 2>&1 | tail -6 | tee gpurun_out/bench_c5.log
