@@ -184,6 +184,32 @@ def test_gbt_semantics():
     assert np.allclose(s, 1 / (1 + np.exp(-exp.astype(np.float64))), atol=1e-7)
 
 
+def test_xgboost_json_flattening():
+    """`flatten_xgb_json` on a hand-written document in XGBoost's save_model JSON schema (xgboost itself is not
+    installable here): split_indices / split_conditions / left_children / right_children per tree, leaf values in
+    split_conditions, base_score as a probability -> margin offset logit(base_score)."""
+    doc = {"learner": {"learner_model_param": {"base_score": "0.25", "num_feature": "3"},
+                       "gradient_booster": {"model": {"trees": [
+                           {"left_children": [1, -1, -1], "right_children": [2, -1, -1], "split_indices": [2, 0, 0],
+                            "split_conditions": [1.5, -0.4, 0.6], "base_weights": [0, 0, 0]},
+                           {"left_children": [1, 3, -1, -1, -1], "right_children": [2, 4, -1, -1, -1],
+                            "split_indices": [0, 1, 0, 0, 0], "split_conditions": [10.0, 0.5, 0.2, -0.1, 0.3],
+                            "base_weights": [0, 0, 0, 0, 0]}]}}}}
+    import json
+    for d in (doc, json.dumps(doc)):
+        f = model_io.flatten_xgb_json(d)
+        assert f.kind == S.MODEL_GBT and f.n_trees == 2 and f.n_features == 3 and f.max_depth == 2
+        assert abs(f.base_score - np.log(0.25 / 0.75)) < 1e-12
+        assert f.tree_root.tolist() == [0, 3] and f.feature.tolist() == [2, -1, -1, 0, 1, -1, -1, -1]
+        X = np.array([[5.0, 0.4, 1.0], [5.0, 0.6, 2.0], [10.0, 0.0, 1.5], [np.nan, 0.0, 0.0]], np.float32)
+        m, s = O.forest_predict(f, X)
+        b = np.float32(f.base_score)
+        # tree 0: x2 < 1.5 ? -0.4 : 0.6 ; tree 1: x0 < 10 ? (x1 < 0.5 ? -0.1 : 0.3) : 0.2 ; NaN never goes left
+        exp = np.array([b + np.float32(-0.4) + np.float32(-0.1), b + np.float32(0.6) + np.float32(0.3),
+                        b + np.float32(0.6) + np.float32(0.2), b + np.float32(-0.4) + np.float32(0.2)], np.float32)
+        assert np.array_equal(m, exp)
+
+
 # ------------------------------------------------------------------ two restatements agree
 @pytest.mark.parametrize("flow", ["TGCA", "GTAC"])
 def test_vectorised_oracle_matches_reference_idiom(frozen_models, flow):
