@@ -72,7 +72,10 @@ int ugvc_vcf_get_view(const ugvc_vcf* h, ugvc_vcf_view* view);
  * marks additional COHORT_FP rows.  `out_path` ending in ".gz" is written as BGZF (65280-byte blocks,
  * zlib level 6, EOF marker). */
 int ugvc_vcf_write_filtered(const ugvc_vcf* h, const char* out_path, const float* tree_score, const uint8_t* filter,
-                            const uint8_t* flags, const uint8_t* cohort_extra, int64_t n, int n_threads);
+                            const uint8_t* flags, const uint8_t* cohort_extra, int64_t n, int n_threads, int write_index);
+/* write_index != 0 and a ".gz" path: `out_path`.tbi is written too (tabix index, format VCF; the reference ends its
+ * write loop with pysam.tabix_index, ugvc/pipelines/vcfbed/calibrate_bridging_snvs.py:130).  Returns 1 (file written,
+ * no index) when the records are not grouped by contig and sorted by position - tabix refuses such files as well. */
 
 void ugvc_vcf_free(ugvc_vcf* h);
 const char* ugvc_vcf_last_error(void);

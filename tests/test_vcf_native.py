@@ -323,3 +323,143 @@ def test_random_records_parse_like_the_python_reference(tmp_path, seed):
     pv.write_filtered_vcf(str(tmp_path / "a.vcf"), a, res)
     nv.write_filtered_vcf(str(tmp_path / "b.vcf"), b, res)
     assert open(str(tmp_path / "a.vcf"), "rb").read() == open(str(tmp_path / "b.vcf"), "rb").read()
+
+
+# ------------------------------------------------------------------ tabix index of the written file
+def _read_tbi(path):
+    import struct
+    data = gzip.open(path, "rb").read()
+    assert data[:4] == b"TBI\x01"
+    n_ref, fmt, col_seq, col_beg, col_end, meta, skip, l_nm = struct.unpack_from("<8i", data, 4)
+    names = data[36:36 + l_nm].split(b"\0")[:-1]
+    off = 36 + l_nm
+    refs = []
+    for _ in range(n_ref):
+        n_bin, = struct.unpack_from("<i", data, off); off += 4
+        bins = {}
+        for _ in range(n_bin):
+            b, n_chunk = struct.unpack_from("<Ii", data, off); off += 8
+            bins[b] = [struct.unpack_from("<QQ", data, off + 16 * i) for i in range(n_chunk)]
+            off += 16 * n_chunk
+        n_intv, = struct.unpack_from("<i", data, off); off += 4
+        lin = list(struct.unpack_from(f"<{n_intv}Q", data, off)); off += 8 * n_intv
+        refs.append((bins, lin))
+    n_no_coor, = struct.unpack_from("<Q", data, off); off += 8
+    assert off == len(data) and n_no_coor == 0
+    return [n.decode() for n in names], refs, (fmt, col_seq, col_beg, col_end, meta, skip)
+
+
+def _reg2bins(beg, end):
+    end -= 1
+    out = [0]
+    for shift, first in ((26, 1), (23, 9), (20, 73), (17, 585), (14, 4681)):
+        out += list(range(first + (beg >> shift), first + (end >> shift) + 1))
+    return out
+
+
+class _Bgzf:
+    """Random access by virtual offset over a BGZF file held in memory."""
+    def __init__(self, raw):
+        self.blocks, off = {}, 0
+        while off < len(raw):
+            bsize = int.from_bytes(raw[off + 16: off + 18], "little") + 1
+            self.blocks[off] = (zlib.decompress(raw[off + 18: off + bsize - 8], -15), bsize)
+            off += bsize
+
+    def lines(self, v_beg, v_end):
+        co, uo = v_beg >> 16, v_beg & 0xFFFF
+        while (co << 16 | uo) < v_end and co in self.blocks:
+            buf = b""
+            while True:
+                data, bsize = self.blocks[co]
+                nl = data.find(b"\n", uo)
+                if nl >= 0:
+                    buf += data[uo:nl]; uo = nl + 1
+                    if uo == len(data):
+                        co, uo = co + bsize, 0
+                    break
+                buf += data[uo:]; co, uo = co + bsize, 0
+                if co not in self.blocks:
+                    break
+            yield buf
+
+
+def test_tabix_index_answers_region_queries(tmp_path):
+    """The .tbi beside the written .vcf.gz (tabix specification: binning + linear index over BGZF virtual offsets)
+    returns exactly the records a scan of the file finds, for random regions, long REF alleles, INFO/END records and
+    windows without records; unsorted input gets no index."""
+    rng = np.random.default_rng(21)
+    names = ["chr1", "chr2", "chrM"]
+    lens = [3_000_000, 900_000, 16_000]
+    lines = ["##fileformat=VCFv4.2", "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\ts1"]
+    recs = []
+    for c, L in zip(names, lens):
+        for p in np.sort(rng.integers(1, L, 6000 if c != "chrM" else 300)):
+            kind = rng.random()
+            if kind < 0.9:
+                ref, alt, info, end = "A", "C", "SOR=1.0", int(p)
+            elif kind < 0.97:
+                k = int(rng.choice([2, 40, 3000, 20_000]))
+                ref, alt, info, end = "A" * k, "A", "SOR=0.5", int(p) - 1 + k
+            else:
+                e = int(p) + int(rng.choice([10, 50_000, 400_000]))
+                ref, alt, info, end = "N", "<DEL>", f"SVTYPE=DEL;END={e};SOR=2", e
+            lines.append(f"{c}\t{p}\t.\t{ref}\t{alt}\t50\t.\t{info}\tGT:AD:DP:GQ\t0/1:5,5:10:50")
+            recs.append((c, int(p) - 1, end))
+    p_in = str(tmp_path / "in.vcf")
+    open(p_in, "w").write("\n".join(lines) + "\n")
+    b = nv.read_vcf(p_in, names)
+    n = b.table.n
+    res = S.FilterResult(rng.random(n).astype(np.float32), rng.integers(0, 2, n).astype(np.uint8), np.zeros(n, np.uint8))
+    out = str(tmp_path / "out.vcf.gz")
+    assert nv.write_filtered_vcf(out, b, res) is True
+    tbi_names, refs, cols = _read_tbi(out + ".tbi")
+    assert tbi_names == names and cols == (2, 1, 2, 0, ord("#"), 0)
+    raw = open(out, "rb").read()
+    bg = _Bgzf(raw)
+    all_lines = [ln for ln in gzip.decompress(raw).split(b"\n") if ln and not ln.startswith(b"#")]
+    assert len(all_lines) == n
+
+    def span(line):
+        f = line.split(b"\t")
+        beg = int(f[1]) - 1
+        end = beg + len(f[3])
+        m = re.search(rb"(?:^|;)END=(\d+)", f[7])
+        if m and int(m.group(1)) > beg:
+            end = int(m.group(1))
+        return f[0].decode(), beg, end
+
+    spans = [span(ln) for ln in all_lines]
+    for _ in range(300):
+        c = int(rng.integers(0, 3))
+        qb = int(rng.integers(0, lens[c]))
+        qe = qb + int(rng.choice([1, 100, 16_384, 20_000, 500_000]))
+        bins, lin = refs[c]
+        w = qb >> 14
+        min_off = lin[w] if w < len(lin) else (lin[-1] if lin else 0)
+        got = set()
+        for bn in _reg2bins(qb, qe):
+            for cb, ce in bins.get(bn, []):
+                if ce <= min_off:
+                    continue
+                for ln in bg.lines(cb, ce):
+                    cc, sb, se = span(ln)
+                    if cc == names[c] and sb < qe and se > qb:
+                        got.add(ln)
+        want = {ln for ln, (cc, sb, se) in zip(all_lines, spans) if cc == names[c] and sb < qe and se > qb}
+        assert got == want, (names[c], qb, qe, len(got), len(want))
+    # every chunk starts on a record boundary of its contig and the linear index never decreases
+    for c, (bins, lin) in enumerate(refs):
+        assert all(x <= y for x, y in zip(lin, lin[1:]))
+        for chunks in bins.values():
+            for cb, ce in chunks:
+                first = next(bg.lines(cb, ce))
+                assert first.split(b"\t")[0].decode() == names[c]
+    # unsorted input: the file is written, the index is not
+    open(p_in, "w").write("\n".join(lines[:2] + lines[2:][::-1]) + "\n")
+    b2 = nv.read_vcf(p_in, names)
+    out2 = str(tmp_path / "out2.vcf.gz")
+    assert nv.write_filtered_vcf(out2, b2, res) is False and not os.path.exists(out2 + ".tbi")
+    assert len(gzip.open(out2, "rb").read().splitlines()) == n + 7
+    # plain-text output: nothing to index
+    assert nv.write_filtered_vcf(str(tmp_path / "out3.vcf"), b, res) is False

@@ -331,6 +331,7 @@ struct ugvc_vcf {
     std::vector<uint32_t> ref_off, alt_off;
     std::vector<float> qual, sor, tlod;
     std::vector<int64_t> order, filter_off;
+    std::vector<std::string> contig_names;  // index = contig column (for the tabix index of the output)
 };
 
 namespace {
@@ -479,6 +480,166 @@ bool parse_record(const char* base, Span line, int64_t k, const std::unordered_m
 
 }  // namespace
 
+namespace {
+
+// ---- tabix index of the written file (the reference ends its write loop with pysam.tabix_index:
+// ugvc/pipelines/vcfbed/calibrate_bridging_snvs.py:130).  Format: SAMv1 / tabix specification - binning index
+// (min shift 14, depth 5) + 16 kb linear index over BGZF virtual offsets, format VCF (columns 1, 2; END= honoured),
+// the whole index BGZF-compressed.  Skipped (with a 1 return) when the records are not grouped by contig and sorted
+// by position, which tabix itself refuses.
+int reg2bin(int64_t beg, int64_t end) {
+    --end;
+    if (beg >> 14 == end >> 14) return ((1 << 15) - 1) / 7 + (int)(beg >> 14);
+    if (beg >> 17 == end >> 17) return ((1 << 12) - 1) / 7 + (int)(beg >> 17);
+    if (beg >> 20 == end >> 20) return ((1 << 9) - 1) / 7 + (int)(beg >> 20);
+    if (beg >> 23 == end >> 23) return ((1 << 6) - 1) / 7 + (int)(beg >> 23);
+    if (beg >> 26 == end >> 26) return ((1 << 3) - 1) / 7 + (int)(beg >> 26);
+    return 0;
+}
+
+void put32(std::string& o, uint32_t x) { for (int i = 0; i < 4; ++i) o.push_back((char)(x >> (8 * i))); }
+void put64(std::string& o, uint64_t x) { for (int i = 0; i < 8; ++i) o.push_back((char)(x >> (8 * i))); }
+
+int bgzf_write_all(const std::string& data, const std::string& path) {
+    FILE* fh = fopen(path.c_str(), "wb");
+    if (!fh) return fail(path + ": cannot open for writing");
+    bool ok = true;
+    constexpr size_t kBlk = 65280;
+    for (size_t lo = 0; lo < data.size() && ok; lo += kBlk) {
+        const size_t len = std::min(kBlk, data.size() - lo);
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { ok = false; break; }
+        std::string o(18 + deflateBound(&zs, (uLong)len) + 8, '\0');
+        zs.next_in = reinterpret_cast<unsigned char*>(const_cast<char*>(data.data() + lo));
+        zs.avail_in = (uInt)len;
+        zs.next_out = reinterpret_cast<unsigned char*>(&o[18]);
+        zs.avail_out = (uInt)(o.size() - 26);
+        const int rc = deflate(&zs, Z_FINISH);
+        const size_t clen = zs.total_out;
+        deflateEnd(&zs);
+        if (rc != Z_STREAM_END) { ok = false; break; }
+        static const unsigned char hd[16] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 'B', 'C', 0x02, 0};
+        memcpy(&o[0], hd, 16);
+        const uint32_t bsize = (uint32_t)(clen + 25);
+        o[16] = (char)(bsize & 0xff); o[17] = (char)(bsize >> 8);
+        const uint32_t crc = (uint32_t)crc32(0L, reinterpret_cast<const unsigned char*>(data.data() + lo), (uInt)len);
+        unsigned char* t = reinterpret_cast<unsigned char*>(&o[18 + clen]);
+        for (int i = 0; i < 4; ++i) { t[i] = (unsigned char)(crc >> (8 * i)); t[4 + i] = (unsigned char)((uint32_t)len >> (8 * i)); }
+        o.resize(18 + clen + 8);
+        ok = fwrite(o.data(), 1, o.size(), fh) == o.size();
+    }
+    static const unsigned char kEof[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0,
+                                           0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (ok) ok = fwrite(kEof, 1, 28, fh) == 28;
+    if (fclose(fh) != 0) ok = false;
+    return ok ? 0 : fail(path + ": write failed");
+}
+
+int write_tbi(const ugvc_vcf* h, const char* out_path, const std::vector<int64_t>& row_of, const std::vector<uint32_t>& out_len,
+              size_t header_len, const std::vector<uint32_t>& blk_clen, int /*threads*/) {
+    const int64_t n = h->n;
+    const char* base = h->text.data();
+    constexpr uint64_t kBlk = 65280;
+    std::vector<uint64_t> coff(blk_clen.size() + 1, 0);
+    for (size_t b = 0; b < blk_clen.size(); ++b) coff[b + 1] = coff[b] + blk_clen[b];
+    auto voff = [&](uint64_t u) { return (coff[(size_t)(u / kBlk)] << 16) | (u % kBlk); };
+    struct Ref {
+        std::vector<std::pair<uint32_t, std::pair<uint64_t, uint64_t>>> chunks;   // (bin, [beg, end)) in file order
+        std::vector<uint64_t> lin;
+    };
+    std::vector<Ref> refs;
+    std::vector<int> tid_of(h->contig_names.size(), -1);
+    std::vector<int> name_of_tid;
+    int cur_c = -1;
+    int64_t last_beg = -1;
+    uint64_t u = header_len;
+    for (int64_t j = 0; j < n; ++j) {
+        const size_t k = (size_t)row_of[(size_t)j];
+        const int c = h->contig[k];
+        const int64_t beg = (int64_t)h->pos[k] - 1;
+        int64_t end = beg + h->ref_len[k];
+        {   // INFO/END (symbolic alleles): "END=" at the start of INFO or after a ';'
+            const Span ln = h->rec_lines[(size_t)j];
+            const char* s = base + ln.off;
+            const char* e = s + ln.len;
+            int tabs = 0;
+            const char* q = s;
+            while (q < e && tabs < 7) { if (*q == '\t') ++tabs; ++q; }
+            const char* ie = static_cast<const char*>(memchr(q, '\t', (size_t)(e - q)));
+            if (!ie) ie = e;
+            for (const char* p = q; p + 4 <= ie;) {
+                if (memcmp(p, "END=", 4) == 0 && (p == q || p[-1] == ';')) {
+                    int64_t v = 0;
+                    const char* d = p + 4;
+                    bool any = false;
+                    while (d < ie && *d >= '0' && *d <= '9') { v = v * 10 + (*d - '0'); ++d; any = true; }
+                    if (any && v > beg) end = v;
+                    break;
+                }
+                const char* nx = static_cast<const char*>(memchr(p, ';', (size_t)(ie - p)));
+                if (!nx) break;
+                p = nx + 1;
+            }
+        }
+        if (beg < 0) return 1;
+        if (c != cur_c) {
+            if (tid_of[(size_t)c] >= 0) return 1;                 // contig seen before: not grouped, tabix would refuse
+            tid_of[(size_t)c] = (int)refs.size();
+            name_of_tid.push_back(c);
+            refs.emplace_back();
+            cur_c = c;
+            last_beg = -1;
+        }
+        if (beg < last_beg) return 1;                             // unsorted
+        last_beg = beg;
+        Ref& r = refs.back();
+        const uint64_t v0 = voff(u), v1 = voff(u + out_len[(size_t)j]);
+        const uint32_t bin = (uint32_t)reg2bin(beg, end > beg ? end : beg + 1);
+        if (!r.chunks.empty() && r.chunks.back().first == bin) r.chunks.back().second.second = v1;
+        else r.chunks.push_back({bin, {v0, v1}});
+        const size_t w0 = (size_t)(beg >> 14), w1 = (size_t)(((end > beg ? end : beg + 1) - 1) >> 14);
+        if (r.lin.size() <= w1) r.lin.resize(w1 + 1, ~0ull);
+        for (size_t w = w0; w <= w1; ++w)
+            if (r.lin[w] == ~0ull) r.lin[w] = v0;
+        u += out_len[(size_t)j];
+    }
+    std::string o;
+    o.append("TBI\1", 4);
+    put32(o, (uint32_t)refs.size());
+    put32(o, 2); put32(o, 1); put32(o, 2); put32(o, 0); put32(o, '#'); put32(o, 0);
+    std::string nm;
+    for (int c : name_of_tid) { nm.append(h->contig_names[(size_t)c]); nm.push_back('\0'); }
+    put32(o, (uint32_t)nm.size());
+    o.append(nm);
+    for (Ref& r : refs) {
+        // group the chunks by bin (a bin's chunks stay in file order)
+        std::vector<size_t> idx(r.chunks.size());
+        std::iota(idx.begin(), idx.end(), (size_t)0);
+        std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return r.chunks[a].first < r.chunks[b].first; });
+        uint32_t n_bin = 0;
+        for (size_t i = 0; i < idx.size(); ++i) n_bin += i == 0 || r.chunks[idx[i]].first != r.chunks[idx[i - 1]].first;
+        put32(o, n_bin);
+        for (size_t i = 0; i < idx.size();) {
+            size_t e = i;
+            while (e < idx.size() && r.chunks[idx[e]].first == r.chunks[idx[i]].first) ++e;
+            put32(o, r.chunks[idx[i]].first);
+            put32(o, (uint32_t)(e - i));
+            for (size_t q = i; q < e; ++q) { put64(o, r.chunks[idx[q]].second.first); put64(o, r.chunks[idx[q]].second.second); }
+            i = e;
+        }
+        for (size_t w = 1; w < r.lin.size(); ++w) if (r.lin[w] == ~0ull) r.lin[w] = r.lin[w - 1];
+        if (!r.lin.empty() && r.lin[0] == ~0ull) r.lin[0] = 0;
+        for (size_t w = 1; w < r.lin.size(); ++w) if (r.lin[w] == ~0ull) r.lin[w] = r.lin[w - 1];
+        put32(o, (uint32_t)r.lin.size());
+        for (uint64_t x : r.lin) put64(o, x);
+    }
+    put64(o, 0);                                                   // records without coordinates
+    return bgzf_write_all(o, std::string(out_path) + ".tbi");
+}
+
+}  // namespace
+
 extern "C" {
 
 const char* ugvc_vcf_last_error(void) { return g_err.c_str(); }
@@ -543,6 +704,7 @@ int ugvc_vcf_read(const char* path, const char* const* contig_names, int n_conti
     std::vector<std::string> names((size_t)n_contigs);
     for (int c = 0; c < n_contigs; ++c) names[(size_t)c] = contig_names[c] ? contig_names[c] : "";
     for (int c = 0; c < n_contigs; ++c) contig_idx[std::string_view(names[(size_t)c])] = c;   // duplicates: the last wins
+    h->contig_names = names;
     Parsed P;
     P.resize((size_t)n);
     const int pparts = (int)std::max<int64_t>(1, std::min<int64_t>(threads, n / 2048));
@@ -627,7 +789,7 @@ int ugvc_vcf_get_view(const ugvc_vcf* h, ugvc_vcf_view* v) {
 }
 
 int ugvc_vcf_write_filtered(const ugvc_vcf* h, const char* out_path, const float* tree_score, const uint8_t* filter,
-                            const uint8_t* flags, const uint8_t* cohort_extra, int64_t n, int n_threads) {
+                            const uint8_t* flags, const uint8_t* cohort_extra, int64_t n, int n_threads, int write_index) {
     if (!h || !out_path || !tree_score || !filter || !flags) return fail("NULL argument");
     if (n != h->n) return fail("result columns do not match the record count of the input");
     const int threads = pick_threads(n_threads);
@@ -662,6 +824,9 @@ int ugvc_vcf_write_filtered(const ugvc_vcf* h, const char* out_path, const float
     for (int64_t k = 0; k < n; ++k) row_of[(size_t)h->order[(size_t)k]] = k;
 
     bool io_ok = true;
+    std::vector<uint32_t> blk_clen;                          // compressed size of every data block, file order
+    std::vector<uint32_t> out_len((size_t)n);                // bytes of every output record line (with its newline)
+    const size_t header_len = stream.size();
     static const unsigned char kEof[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0,
                                            0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     constexpr size_t kBlk = 65280;
@@ -699,8 +864,10 @@ int ugvc_vcf_write_filtered(const ugvc_vcf* h, const char* out_path, const float
             o.resize(18 + clen + 8);
         });
         if (bad) { io_ok = false; return; }
-        for (auto& o : comp)
+        for (auto& o : comp) {
             if (fwrite(o.data(), 1, o.size(), fh) != o.size()) io_ok = false;
+            blk_clen.push_back((uint32_t)o.size());
+        }
         stream.erase(0, std::min(stream.size(), nb * kBlk));
     };
 
@@ -717,6 +884,7 @@ int ugvc_vcf_write_filtered(const ugvc_vcf* h, const char* out_path, const float
             for (int64_t j = b0 + lo; j < b0 + hi; ++j) {
                 const Span ln = h->rec_lines[(size_t)j];
                 const size_t k = (size_t)row_of[(size_t)j];
+                const size_t o_before = o.size();
                 const char* s = base + ln.off;
                 const char* e = s + ln.len;
                 const char* tab[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -764,6 +932,7 @@ int ugvc_vcf_write_filtered(const ugvc_vcf* h, const char* out_path, const float
                 if (fl & 1u) o.append(";HPOL_RUN");
                 o.append(f7e, (size_t)(e - f7e));
                 o.push_back('\n');
+                out_len[(size_t)j] = (uint32_t)(o.size() - o_before);
             }
         });
         for (auto& p : part) stream.append(p);
@@ -773,6 +942,7 @@ int ugvc_vcf_write_filtered(const ugvc_vcf* h, const char* out_path, const float
     if (io_ok && gz && fwrite(kEof, 1, 28, fh) != 28) io_ok = false;
     if (fclose(fh) != 0) io_ok = false;
     if (!io_ok) return fail(std::string(out_path) + ": write failed");
+    if (gz && write_index) return write_tbi(h, out_path, row_of, out_len, header_len, blk_clen, threads);
     return 0;
 }
 

@@ -10,8 +10,8 @@ Replaces the two per-record pysam loops that bracket the hot path in the referen
     (docs/howto-callset-filter.md:65; ugvc/pipelines/evaluate_concordance.py:47), same order as the input;
     the in-tree example of the write pattern is ugvc/pipelines/vcfbed/calibrate_bridging_snvs.py:101-130.
 Multi-allelic records are featurised on their first ALT allele (BUILDER-DEFINED).  Output `.gz` files are
-BGZF (htslib-compatible blocks + EOF marker); no tabix index is written (the GPU
-codec is the next row, this is the host reference for it)."""
+BGZF (htslib-compatible blocks + EOF marker).  This module is the host reference of the native codec
+(io.vcf_native / libugvc_vcf.so), which additionally writes the tabix index."""
 from __future__ import annotations
 
 import gzip

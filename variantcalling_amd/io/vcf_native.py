@@ -52,7 +52,7 @@ def load_library():
         lib.ugvc_vcf_get_view.argtypes = [C.c_void_p, C.POINTER(_View)]
         lib.ugvc_vcf_write_filtered.restype = C.c_int
         lib.ugvc_vcf_write_filtered.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                                C.c_int64, C.c_int]
+                                                C.c_int64, C.c_int, C.c_int]
         lib.ugvc_vcf_free.restype = None
         lib.ugvc_vcf_free.argtypes = [C.c_void_p]
         lib.ugvc_vcf_format_f32.restype = C.c_int
@@ -144,15 +144,18 @@ def read_vcf(path: str, contig_names: list, is_mutect: bool = False, sample: int
 
 
 def write_filtered_vcf(path: str, vcf: NativeVcfFile, res: S.FilterResult, blacklist_cg: np.ndarray | None = None,
-                       n_threads: int = 0) -> None:
+                       n_threads: int = 0, index: bool = True) -> bool:
+    """Returns True when a tabix index `path`.tbi was written beside a .gz output (sorted input), else False."""
     lib = load_library()
     ts = np.ascontiguousarray(res.tree_score, np.float32)
     fl = np.ascontiguousarray(res.filter, np.uint8)
     fg = np.ascontiguousarray(res.flags, np.uint8)
     cg = None if blacklist_cg is None else np.ascontiguousarray(np.asarray(blacklist_cg).astype(bool), np.uint8)
-    if lib.ugvc_vcf_write_filtered(vcf._h, os.fsencode(path), ts.ctypes.data, fl.ctypes.data, fg.ctypes.data,
-                                   None if cg is None else cg.ctypes.data, int(ts.size), int(n_threads)):
+    rc = lib.ugvc_vcf_write_filtered(vcf._h, os.fsencode(path), ts.ctypes.data, fl.ctypes.data, fg.ctypes.data,
+                                     None if cg is None else cg.ctypes.data, int(ts.size), int(n_threads), int(index))
+    if rc < 0:
         raise RuntimeError(_err(lib))
+    return bool(index) and path.endswith(".gz") and rc == 0
 
 
 def format_f32(x: float) -> str:
