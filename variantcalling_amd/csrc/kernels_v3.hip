@@ -839,7 +839,17 @@ __device__ __forceinline__ void walk4(uint32_t hi_b, uint32_t last_b, uint32_t p
         tb[k] = hi_b + 4u * (uint32_t)((t + k) * H);
         idx[k] = 1;
     }
-    for (int d = 0; d < D - 1; ++d) {
+    if (D > 1) {
+        // the root is the same word for every lane: no index to carry in, the child is 2 + (code > thr)
+        uint32_t w[NT], code[NT];
+#pragma unroll
+        for (int k = 0; k < NT; ++k) w[k] = lds_u32(tb[k] + 4u);
+#pragma unroll
+        for (int k = 0; k < NT; ++k) code[k] = lds_u16(planes_lane_b + (w[k] >> 16));
+#pragma unroll
+        for (int k = 0; k < NT; ++k) idx[k] = code[k] > (w[k] & 0xFFFFu) ? 3u : 2u;
+    }
+    for (int d = 1; d < D - 1; ++d) {
         uint32_t w[NT], code[NT];
 #pragma unroll
         for (int k = 0; k < NT; ++k) w[k] = lds_u32(tb[k] + 4u * idx[k]);
@@ -898,9 +908,15 @@ __global__ __launch_bounds__(kK2Threads) void forest3_kernel(const V2Args v) {
     if (nb[big] < 1) return;
     int g = 0, lb = blockIdx.x;
     while (g < UGVC_N_GROUPS - 1 && lb >= nb[g]) { lb -= nb[g]; ++g; }
+    // the split came through LDS, so the compiler holds g and everything read through it (D, T, table
+    // pointers, the per-tree bases of the walk) in VGPRs and spends ~20 % more vector instructions on
+    // wave-uniform arithmetic: pin them to SGPRs here
+    g = rfl(g);
+    lb = rfl(lb);
+    const int nbg = rfl(nb[g]);
     const PackedGroupView pg = v.pg[g];
-    const unsigned n = cnt[g];
-    if (n == 0 || nb[g] == 0) return;
+    const unsigned n = (unsigned)rfl((int)cnt[g]);
+    if (n == 0 || nbg == 0) return;
 
     if (wave == 0) {                                             // exclusive scan of the group's shard counts
         unsigned x[4], s = 0;
@@ -980,12 +996,16 @@ __global__ __launch_bounds__(kK2Threads) void forest3_kernel(const V2Args v) {
     const int hslot = ((lane & 31) << 1) | (lane >> 5);
     const uint32_t nodes_b = lds_addr(nodes);
     const uint32_t planes_lane_b = lds_addr(planes + hslot);
-    const unsigned waves = (unsigned)nb[g] * n_waves;
+    const unsigned waves = (unsigned)nbg * n_waves;
     const uint4* __restrict__ rec = v.records[g];
     const int T = pg.T;
-    for (unsigned chunk = (unsigned)lb * n_waves + wave; (uint64_t)chunk * 64 < n; chunk += waves) {
+    // chunk slots are wave-major over the group's workgroups: the last, partial round then leaves a
+    // few waves busy on every CU instead of all sixteen on a few CUs
+    // the record of a chunk is fetched one chunk ahead: the shard search and the HBM round trip of the
+    // next 64 records run under the current chunk's walk
+    auto fetch = [&](unsigned chunk, bool& live) -> uint4 {
         const unsigned r = chunk * 64 + lane;
-        const bool live = r < n;
+        live = r < n;
         const unsigned rr = live ? r : n - 1;
         int lo = 0, len = kShards;
         while (len > 1) {                                        // shard of record rr
@@ -994,7 +1014,16 @@ __global__ __launch_bounds__(kK2Threads) void forest3_kernel(const V2Args v) {
             lo = ge ? lo + half : lo;
             len = ge ? len - half : half;
         }
-        const uint4 q = rec[(size_t)lo * v.shard_cap + (rr - shard_off[lo])];
+        return rec[(size_t)lo * v.shard_cap + (rr - shard_off[lo])];
+    };
+    unsigned chunk = (unsigned)rfl(wave) * (unsigned)nbg + (unsigned)lb;
+    bool live_next = false;
+    uint4 q_next = make_uint4(0, 0, 0, 0);
+    if ((uint64_t)chunk * 64 < n) q_next = fetch(chunk, live_next);
+    for (; (uint64_t)chunk * 64 < n; chunk += waves) {
+        const uint4 q = q_next;
+        const bool live = live_next;
+        if ((uint64_t)(chunk + waves) * 64 < n) q_next = fetch(chunk + waves, live_next);
         for (int p = 0; p < P; ++p) {
             const uint32_t pd = pg.plane_desc[p];                // dword[0:2) | bit_off[2:7) | width[7:11)
             const uint32_t dw = pd & 3;
