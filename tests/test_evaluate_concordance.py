@@ -1,0 +1,179 @@
+"""pipelines/evaluate_concordance.py end to end on HDF5 in / out, pinned on the reference's own expected table.
+
+The reference's system test (test/system/test_evaluate_concordance.py:11-24) runs the tool on test.untrained.h5 (an LFS
+pointer here) and compares PREFIX.stats.csv byte for byte with expected.out.stats.csv, which IS in the tree.  That table
+fixes, per variant category, the six integer counts and the derived precision / recall / f1 with their rounding and
+text form; the test below rebuilds a concordance frame with exactly those counts, stores it as per-contig HDF5 keys
+with our writer, runs the tool and demands the reference's bytes."""
+import os
+
+import numpy as np
+import pytest
+
+from variantcalling_amd.io import concordance, h5
+from variantcalling_amd.pipelines import evaluate_concordance
+
+# /root/reference/test/resources/system/test_evaluate_concordance/expected.out.stats.csv, verbatim
+EXPECTED_STATS = """group;tp;fp;fn;precision;recall;f1;initial_tp;initial_fp;initial_fn;initial_precision;initial_recall;initial_f1
+SNP;1712;5;14;0.99709;0.99189;0.99448;1713;15;13;0.99132;0.99247;0.99189
+Non-hmer INDEL;84;2;4;0.97674;0.95455;0.96552;85;6;3;0.93407;0.96591;0.94972
+HMER indel <= 4;26;0;1;1.0;0.96296;0.98113;27;23;0;0.54;1.0;0.7013
+HMER indel (4,8);11;1;0;0.91667;1.0;0.95652;11;5;0;0.6875;1.0;0.81481
+HMER indel [8,10];17;3;2;0.85;0.89474;0.87179;19;3;0;0.86364;1.0;0.92683
+HMER indel 11,12;10;4;9;0.71429;0.52632;0.60606;10;4;9;0.71429;0.52632;0.60606
+HMER indel > 12;1;7;46;0.125;0.02128;0.03636;1;7;46;0.125;0.02128;0.03636
+INDELS;149;17;62;0.89759;0.70616;0.79045;153;48;58;0.76119;0.72512;0.74272
+H-INDELS;65;15;58;0.8125;0.52846;0.64039;68;42;55;0.61818;0.55285;0.58369
+"""
+REF_FILE = "/root/reference/test/resources/system/test_evaluate_concordance/expected.out.stats.csv"
+
+
+def _frame_with_expected_counts(rng):
+    """Rows whose per-category counts are those of the table: (indel, hmer length) picks the category."""
+    cats = [(False, 0), (True, 0), (True, 3), (True, 6), (True, 9), (True, 11), (True, 20)]
+    lines = EXPECTED_STATS.strip().split("\n")[1:8]
+    recs = []
+    for (indel, hmer), line in zip(cats, lines):
+        f = line.split(";")
+        tp1, fp1, tp0, fp0, fn0 = int(f[1]), int(f[2]), int(f[7]), int(f[8]), int(f[9])
+        for cls, total, passing_n in (("tp", tp0, tp1), ("fp", fp0, fp1), ("fn", fn0, 0)):
+            for k in range(total):
+                ok = k < passing_n
+                # HPOL_RUN alone is an ignored filter (evaluate_concordance.py:44-48): still a passing call
+                flt = ("PASS" if k % 3 else "HPOL_RUN") if ok else ("LOW_SCORE" if k % 2 else "HPOL_RUN;LOW_SCORE")
+                score = (0.6 + 0.4 * rng.random()) if ok else 0.4 * rng.random()
+                recs.append((indel, hmer, cls, None if cls == "fn" else flt, np.nan if cls == "fn" else score))
+    order = rng.permutation(len(recs))
+    recs = [recs[i] for i in order]
+    n = len(recs)
+    chrom = np.array([f"chr{1 + (i % 3)}" for i in range(n)], dtype=object)
+    fr = h5.Frame([("chrom", chrom), ("pos", np.arange(1, n + 1, dtype=np.int64) * 13),
+                   ("indel", np.array([r[0] for r in recs])), ("hmer_indel_length", np.array([r[1] for r in recs], np.int64)),
+                   ("classify", np.array([r[2] for r in recs], dtype=object)),
+                   ("classify_gt", np.array([r[2] for r in recs], dtype=object)),
+                   ("filter", np.array([r[3] for r in recs], dtype=object)),
+                   ("tree_score", np.array([r[4] for r in recs], np.float64))])
+    return fr
+
+
+def _split_by_chrom(fr):
+    out = {}
+    for c in sorted(set(fr["chrom"])):
+        m = fr["chrom"] == c
+        out[c] = h5.Frame([(k, v[m]) for k, v in fr.items()])
+    return out
+
+
+def test_expected_table_constant_is_the_reference_file():
+    if not os.path.exists(REF_FILE):
+        pytest.skip("reference tree not present")
+    assert open(REF_FILE).read() == EXPECTED_STATS
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_stats_csv_matches_reference_bytes(tmp_path, seed):
+    rng = np.random.default_rng(seed)
+    fr = _frame_with_expected_counts(rng)
+    keys = _split_by_chrom(fr)
+    keys["concordance"] = h5.Frame([(k, v[:5]) for k, v in fr.items()])     # bookkeeping keys the tool must skip
+    keys["input_args"] = h5.Frame([("arg", np.array(["x"], dtype=object))])
+    src = str(tmp_path / "in.h5")
+    h5.write_hdf(src, keys)
+    pref = str(tmp_path / "out")
+    evaluate_concordance.run(["--input_file", src, "--output_prefix", pref])
+    assert open(pref + ".stats.csv").read() == EXPECTED_STATS
+    acc = h5.read_hdf(pref + ".h5", "optimal_recall_precision")
+    assert list(acc.keys()) == EXPECTED_STATS.split("\n")[0].split(";")
+    assert list(acc["group"]) == [l.split(";")[0] for l in EXPECTED_STATS.strip().split("\n")[1:]]
+    assert acc["tp"].tolist() == [1712, 84, 26, 11, 17, 10, 1, 149, 65] and acc["recall"][0] == 0.99189
+    curve = h5.read_hdf(pref + ".h5", "recall_precision_curve")
+    assert list(curve["group"]) == list(acc["group"])
+    thr = open(pref + ".thresholds.csv").read().strip().split("\n")
+    assert thr[0] == "group,threshold" and len(thr) == 10
+    # scores were drawn so that 0.4 .. 0.6 separates kept from filtered calls: the best-f1 threshold sits there
+    snp = curve["threshold"][0]
+    assert 0.0 <= snp <= 0.65
+    p, r = curve["precision"][0], curve["recall"][0]
+    assert p.shape == r.shape == curve["f1"][0].shape == curve["predictions"][0].shape and p.size > 10
+    assert np.all((p >= 0) & (p <= 1)) and np.all(np.diff(r) <= 1e-12)      # recall falls as the threshold rises
+    # a single key instead of "all"
+    evaluate_concordance.run(["--input_file", src, "--output_prefix", pref + "1", "--dataset_key", "chr1", "--ignore_genotype",
+                              "--output_bed"])
+    one = h5.read_hdf(pref + "1.h5", "optimal_recall_precision")
+    m = fr["chrom"] == "chr1"
+    assert int(one["initial_tp"][0]) == int(((fr["classify"] == "tp") & m & ~fr["indel"]).sum())
+    assert len(open(pref + "1.tp.bed").read().splitlines()) == int(((fr["classify"] == "tp") & m).sum())
+
+
+def test_ignored_filters_and_grouping_column(tmp_path):
+    rng = np.random.default_rng(3)
+    fr = _frame_with_expected_counts(rng)
+    fr["lane"] = np.array(["a", "b"], dtype=object)[np.arange(fr.n_rows) % 2]
+    src = str(tmp_path / "in.h5")
+    h5.write_hdf(src, {"all_calls": fr})
+    pref = str(tmp_path / "o")
+    evaluate_concordance.run(["--input_file", src, "--output_prefix", pref, "--ignore_filters", "NONE", "--use_for_group_testing", "lane"])
+    acc = h5.read_hdf(pref + ".h5", "optimal_recall_precision")
+    assert list(acc["group"]) == ["a", "b"]
+    ok = evaluate_concordance.passing(fr["filter"], ["NONE"])
+    for g, row in zip("ab", range(2)):
+        m = fr["lane"] == g
+        assert acc["tp"][row] == int(((fr["classify"] == "tp") & m & ok).sum())      # HPOL_RUN now filters
+        assert acc["initial_fn"][row] == int(((fr["classify"] == "fn") & m).sum())
+
+
+def test_frame_table_round_trip(tmp_path):
+    """concordance frame -> SoA table -> frame: the adapters of train_models_pipeline's HDF5 input / output."""
+    from variantcalling_amd import schema as S
+    names = ["chr1", "chr2", "chrX"]
+    n = 40
+    rng = np.random.default_rng(9)
+    chrom = np.array(names, dtype=object)[rng.integers(0, 3, n)]
+    alleles = np.empty(n, object)
+    ref = np.empty(n, object)
+    ad = np.empty(n, object)
+    gt = np.empty(n, object)
+    for i in range(n):
+        r = "".join(rng.choice(list("ACGT"), size=int(rng.integers(1, 4))))
+        a = "".join(rng.choice(list("ACGT"), size=int(rng.integers(1, 4))))
+        ref[i] = r
+        alleles[i] = (r, a) if i % 7 else (r, a, "T")
+        ad[i] = (int(rng.integers(0, 30)), int(rng.integers(0, 30)))
+        gt[i] = [(0, 1), (1, 1), (0, 0), (1, 2)][int(rng.integers(0, 4))]
+    cls = np.array(["tp", "fp", "fn"], dtype=object)[rng.integers(0, 3, n)]
+    alleles[cls == "fn"] = None                                       # a missed truth variant has no call
+    fr = h5.Frame([("chrom", chrom), ("pos", rng.integers(1, 1000, n).astype(np.int64)), ("ref", ref), ("alleles", alleles),
+                   ("gt_ultima", gt), ("classify", cls), ("qual", rng.random(n) * 50), ("sor", rng.random(n)),
+                   ("dp", rng.integers(0, 60, n).astype(np.float64)), ("ad", ad)])
+    fr["chrom"][3] = "chrUn_decoy"                                    # not in the reference: dropped
+    path = str(tmp_path / "c.h5")
+    h5.write_hdf(path, {"chr_all": fr})
+    back = concordance.read_concordance(path)
+    vt, rows, label = concordance.frame_to_table(back, names)
+    keep = [i for i in range(n) if cls[i] != "fn" and i != 3]
+    assert sorted(rows.tolist()) == keep
+    key = [(names.index(fr["chrom"][i]), int(fr["pos"][i])) for i in rows]
+    assert key == sorted(key)
+    for k, i in enumerate(rows):
+        assert S.decode_bases(vt.alleles[vt.ref_off[k]:vt.ref_off[k] + vt.ref_len[k]]) == ref[i]
+        assert S.decode_bases(vt.alleles[vt.alt_off[k]:vt.alt_off[k] + vt.alt_len[k]]) == alleles[i][1]
+        assert (vt.ad_ref[k], vt.ad_alt[k]) == ad[i] and vt.dp[k] == int(fr["dp"][i])
+        assert vt.gt[k] == (2 if gt[i] == (1, 1) else (1 if 1 in gt[i] else 0))
+        assert label[k] == (1 if cls[i] == "tp" else 0)
+        assert vt.qual[k] == np.float32(fr["qual"][i])
+    res = S.FilterResult(tree_score=rng.random(vt.n).astype(np.float32), filter=(rng.random(vt.n) < 0.5).astype(np.uint8),
+                         flags=rng.integers(0, 4, vt.n).astype(np.uint8))
+    out = concordance.table_to_frame(vt, names, label, res)
+    h5.write_hdf(path, {"scored_concordance": out})
+    again = h5.read_hdf(path, "scored_concordance")
+    vt2, rows2, label2 = concordance.frame_to_table(again, names)
+    assert np.array_equal(rows2, np.arange(vt.n)) and np.array_equal(label2, label)
+    for c in S.VariantTable.COLS:
+        if c != "gq":
+            assert np.array_equal(getattr(vt2, c), getattr(vt, c)), c
+    assert np.array_equal(vt2.alleles, vt.alleles)
+    assert np.array_equal(again["tree_score"], res.tree_score.astype(np.float64))
+    flt = again["filter"]
+    for i in range(vt.n):
+        assert ("LOW_SCORE" in flt[i]) == bool(res.filter[i]) and ("HPOL_RUN" in flt[i]) == bool(res.flags[i] & 1)
+        assert (flt[i] == "PASS") == (res.filter[i] == 0 and res.flags[i] & 3 == 0)

@@ -85,9 +85,29 @@ def test_train_then_filter(tmp_path):
                            "rf_model_ignore_gt_excl_hpol_runs", "dt_model_ignore_gt_excl_hpol_runs"}
     rows = [x.split(";") for x in open(prefix + ".stats.csv").read().splitlines()]
     assert rows[0][0] == "group" and rows[1][0] == "SNP" and float(rows[1][6]) > 0.7      # SNP f1 after filtering
-    res = np.load(prefix + ".results.npz")
+    from variantcalling_amd.io import h5
+    res = h5.read_hdf(prefix + ".h5", "training_set")
     ft = O.featurize(cs.variants, cs.ref, cs.runs, cs.tracks)
-    assert np.array_equal(res["X"], ft["X"]) and np.array_equal(res["group"], ft["group"].astype(np.uint8))
+    feat = S.feature_names(len(cs.tracks))
+    assert list(res.keys()) == ["chrom", "pos", "label", "group"] + list(feat)
+    assert np.array_equal(np.stack([res[f] for f in feat], axis=1), ft["X"]) and np.array_equal(res["group"], ft["group"])
+    assert np.array_equal(res["pos"], cs.variants.pos)
+    scored = h5.read_hdf(prefix + ".h5", "scored_concordance")
+    acc = h5.read_hdf(prefix + ".h5", "optimal_recall_precision")
+    assert [str(x) for x in acc["tp"]] == [r[1] for r in rows[1:]] and list(acc["group"]) == [r[0] for r in rows[1:]]
+    assert scored.n_rows == cs.variants.n and set(scored["filter"]) <= {"PASS", "LOW_SCORE", "HPOL_RUN", "COHORT_FP", "HPOL_RUN;LOW_SCORE",
+                                                                     "COHORT_FP;LOW_SCORE", "HPOL_RUN;COHORT_FP", "HPOL_RUN;COHORT_FP;LOW_SCORE"}
+    # exact-label mode: the scored frame (classify = tp / fp) is itself a comparison HDF5; training on it sees the same
+    # labels and builds the same feature matrix
+    h5.write_hdf(str(tmp_path / "labelled.h5"), {"chr_a": scored})
+    prefix2 = str(tmp_path / "test.model2")
+    rc = train_models_pipeline.run(["train_models_pipeline", "--input_file", str(tmp_path / "labelled.h5"), "--reference", d["fa"],
+                                    "--runs_intervals", d["runs"], "--flow_order", "TGCA", "--output_file_prefix", prefix2] + d["ann"])
+    assert rc == 0
+    res2 = h5.read_hdf(prefix2 + ".h5", "training_set")
+    assert np.array_equal(res2["label"], res["label"]) and np.array_equal(res2["pos"], res["pos"])
+    for f in feat:
+        assert np.array_equal(res2[f], res[f]), f
     for name in ("dt_model_ignore_gt_excl_hpol_runs", "rf_model_ignore_gt_incl_hpol_runs"):
         out = str(tmp_path / f"{name}.vcf")
         filter_variants_pipeline.run(["filter_variants_pipeline", "--input_file", d["vcf"], "--model_file", prefix + ".pkl",

@@ -148,16 +148,20 @@ def category_bits(indel, hmer_len) -> np.ndarray:
 
 
 def accuracy_rows(counts) -> list:
-    """Accuracy-table rows from integer counts[c] = (true, false, true & passing, false & passing) per category -
-    the counts come from the host (`accuracy_table`) or from the GPU (`Engine.eval_counts`)."""
+    """Accuracy-table rows from integer counts[c] = (true, false, true & passing, false & passing[, missed]) per
+    category - the counts come from the host (`accuracy_table`) or from the GPU (`Engine.eval_counts`).  `missed`
+    (truth variants without a call, classify == "fn") adds to fn before and after filtering; a filtered true call
+    becomes a false negative (report_utils.py:449-457).  Column set, order and the 5-digit rounding:
+    test/resources/system/test_evaluate_concordance/expected.out.stats.csv."""
     rows = []
     for c, name in enumerate(CATEGORIES):
         tp0, fp0, tp1, fp1 = (int(x) for x in counts[c][:4])
-        fn1 = tp0 - tp1
+        fn0 = int(counts[c][4]) if len(counts[c]) > 4 else 0
+        fn1 = fn0 + tp0 - tp1
         p1, r1 = float(get_precision(fp1, tp1)), float(get_recall(fn1, tp1))
-        p0, r0 = float(get_precision(fp0, tp0)), float(get_recall(0, tp0))
+        p0, r0 = float(get_precision(fp0, tp0)), float(get_recall(fn0, tp0))
         rows.append(dict(group=name, tp=tp1, fp=fp1, fn=fn1, precision=round(p1, 5), recall=round(r1, 5),
-                         f1=round(float(get_f1(p1, r1)), 5), initial_tp=tp0, initial_fp=fp0, initial_fn=0,
+                         f1=round(float(get_f1(p1, r1)), 5), initial_tp=tp0, initial_fp=fp0, initial_fn=fn0,
                          initial_precision=round(p0, 5), initial_recall=round(r0, 5),
                          initial_f1=round(float(get_f1(p0, r0)), 5)))
     return rows

@@ -7,9 +7,11 @@ docs/train_models_pipeline.md:17-81.  Two modes (docs :5-10): approximate ground
 matrix is built on the GPU (`ugvc_feature_matrix`); fitting is scikit-learn on the host as in the reference
 (random forest / decision tree, one model per variant-type group, exome re-weighting docs :66-72); the
 optional `--evaluate_concordance` pass scores on the GPU.
-Deviations forced by this environment (no pytables/h5py): exact-label input is an `.npz` dump of the SoA
-table with a `label` column instead of the comparison HDF5, and the results table is written as
-`PREFIX.results.npz` + `PREFIX.stats.csv` instead of `PREFIX.h5`."""
+Exact-label input is the comparison HDF5 (per-contig pandas frames with a `classify` column, read by io/h5.py +
+io/concordance.py; `--list_of_contigs_to_read` picks the keys) or an `.npz` dump of the SoA table with a `label`
+column.  Outputs: PREFIX.pkl (+ PREFIX.npz, the flattened forests), PREFIX.h5 with the keys `training_set` (chrom,
+pos, label, group and the F feature columns) and, with --evaluate_concordance, `scored_concordance` and
+`optimal_recall_precision`, and PREFIX.stats.csv."""
 from __future__ import annotations
 
 import argparse
@@ -21,6 +23,7 @@ import sys
 import numpy as np
 
 from .. import evaluate, model_io, schema as S
+from ..io import concordance, h5
 from ..io import vcf_native as vcfio      # native codec (libugvc_vcf.so); io.vcf is its pure-Python reference
 from . import common
 
@@ -61,6 +64,10 @@ def _read_labelled(args, ref, bl):
         vt = S.VariantTable(**{c: np.ascontiguousarray(z[c]) for c in S.VariantTable.COLS}, alleles=z["alleles"])
         vt.validate()
         return vt, z["label"].astype(np.int8)
+    if args.input_file.endswith((".h5", ".hdf", ".hdf5")):
+        fr = concordance.read_concordance(args.input_file, key="all", contigs=args.list_of_contigs_to_read or None)
+        vt, _, label = concordance.frame_to_table(fr, ref.names, is_mutect=args.mutect)
+        return vt, label
     vcf = vcfio.read_vcf(args.input_file, ref.names, is_mutect=args.mutect)
     vt = vcf.table
     label = np.full(vt.n, -1, dtype=np.int8)
@@ -133,8 +140,9 @@ def run(argv: list[str]):
         flat = {k: _flatten(v) for k, v in models.items() if len(v) == S.N_GROUPS}
         if flat:
             model_io.save_models(args.output_file_prefix + ".npz", flat, meta=dict(features=list(names)))
-        np.savez_compressed(args.output_file_prefix + ".results.npz", X=X, group=group, label=label,
-                            contig=vt.contig, pos=vt.pos)
+        chrom = np.array(ref.names, dtype=object)[vt.contig]
+        results = {"training_set": h5.Frame([("chrom", chrom), ("pos", vt.pos.astype(np.int64)), ("label", label.astype(np.int64)),
+                                             ("group", group.astype(np.int64))] + [(nm, X[:, j]) for j, nm in enumerate(names)])}
         if args.evaluate_concordance:
             name = args.apply_model or "rf_model_ignore_gt_incl_hpol_runs"
             if name not in models:
@@ -153,8 +161,10 @@ def run(argv: list[str]):
                 w = csv.DictWriter(fh, fieldnames=list(rows[0]), delimiter=";")
                 w.writeheader()
                 w.writerows(rows)
-            np.savez_compressed(args.output_file_prefix + ".scored.npz", tree_score=res.tree_score, filter=res.filter,
-                                flags=res.flags, label=label)
+            results["scored_concordance"] = concordance.table_to_frame(vt, ref.names, label, res)
+            results["optimal_recall_precision"] = h5.Frame(
+                [(k, np.array([r[k] for r in rows], dtype=object if k == "group" else None)) for k in rows[0]])
+        h5.write_hdf(args.output_file_prefix + ".h5", results)
     return 0
 
 
