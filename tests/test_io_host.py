@@ -77,8 +77,19 @@ def test_blacklist_formats(tmp_path):
     assert np.array_equal(bed.read_blacklist(q, names), want)
     np.save(str(tmp_path / "k.npy"), want[::-1])
     assert np.array_equal(bed.read_blacklist(str(tmp_path / "k.npy"), names), want)
-    with pytest.raises(ValueError):
-        bed.read_blacklist(str(tmp_path / "x.h5"), names)
+    # --blacklist cohort_fp.h5: loci as a (chrom, pos) MultiIndex or as columns of a pandas fixed-format frame
+    from variantcalling_amd.io import h5
+    chrom, pos = np.array(["chr1", "chr2", "chr1", "chrUn"], dtype=object), np.array([9, 7, 5, 3])
+    h5.write_hdf(str(tmp_path / "x.h5"), {"blacklist": h5.Frame([("n", np.arange(4))], index=[chrom, pos], index_names=["chrom", "pos"])})
+    assert np.array_equal(bed.read_blacklist(str(tmp_path / "x.h5"), names), want)
+    h5.write_hdf(str(tmp_path / "y.hdf"), {"a": h5.Frame([("chrom", chrom[:2]), ("pos", pos[:2])]),
+                                            "b": h5.Frame([("chrom", chrom[2:]), ("pos", pos[2:])]), "c": h5.Frame([("z", np.zeros(1))])})
+    assert np.array_equal(bed.read_blacklist(str(tmp_path / "y.hdf"), names), want)
+    h5.write_hdf(str(tmp_path / "z.h5"), {"c": h5.Frame([("z", np.zeros(1))])})
+    with pytest.raises(ValueError, match="no frame or series"):
+        bed.read_blacklist(str(tmp_path / "z.h5"), names)
+    with pytest.raises(ValueError, match="unsupported blacklist format"):
+        bed.read_blacklist(str(tmp_path / "x.txt"), names)
 
 
 def test_vcf_round_trip_and_write_back(tmp_path, cs):

@@ -85,9 +85,10 @@ def keys_from_loci(contig_idx, pos) -> np.ndarray:
 def read_blacklist(path: str, contig_names: list) -> np.ndarray:
     """Cohort false-positive loci as sorted unique keys contig<<32|pos.  Accepted: .npz/.npy of keys or
     (contig, pos); .bed (every 1-based position start+1..end); .pkl holding an iterable of (chrom, pos),
-    a dict of such iterables, or a pandas DataFrame / index with chrom and pos.  The reference's own
-    blacklist pickle holds objects of a class that lives in the absent submodule, and
-    its .h5 form needs pytables - neither can be read here, which is reported, not guessed."""
+    a dict of such iterables, or a pandas DataFrame / index with chrom and pos; .h5 / .hdf (`--blacklist
+    cohort_fp.h5`, docs/train_models_pipeline.md:88): every pandas frame / series of the file that carries loci as a
+    (chrom, pos) MultiIndex or as chrom and pos columns (io/h5.py).  The reference's own blacklist pickle holds objects
+    of a class that lives in the absent submodule: that is reported, not guessed."""
     idx = {n: i for i, n in enumerate(contig_names)}
     if path.endswith(".npy"):
         return np.unique(np.load(path).astype(np.uint64))
@@ -131,4 +132,23 @@ def read_blacklist(path: str, contig_names: list) -> np.ndarray:
             return np.zeros(0, np.uint64)
         a = np.array(loci, dtype=np.int64)
         return keys_from_loci(a[:, 0], a[:, 1])
-    raise ValueError(f"{path}: unsupported blacklist format (use .pkl of (chrom, pos) loci, .bed, .npy or .npz)")
+    if path.endswith((".h5", ".hdf", ".hdf5")):
+        from . import h5
+        chroms, poss = [], []
+        with h5.H5File(path) as f:
+            keys = [k for k in f.keys() if f[k].attrs.get("pandas_type") in ("frame", "series")]
+        for k in keys:
+            fr = h5.read_hdf(path, k)
+            if "chrom" in fr and "pos" in fr:
+                chroms.append(np.asarray(fr["chrom"], dtype=object)); poss.append(np.asarray(fr["pos"]))
+            elif isinstance(fr.index, list) and len(fr.index) >= 2 and list(fr.index_names or [])[:2] in (["chrom", "pos"], [None, None]):
+                chroms.append(np.asarray(fr.index[0], dtype=object)); poss.append(np.asarray(fr.index[1]))
+        if not chroms:
+            raise ValueError(f"{path}: no frame or series with (chrom, pos) loci among the keys {keys}")
+        c = np.concatenate(chroms)
+        p_ = np.concatenate(poss).astype(np.int64)
+        known = np.array([x in idx for x in c], dtype=bool)
+        if not known.any():
+            return np.zeros(0, np.uint64)
+        return keys_from_loci(np.array([idx[x] for x in c[known]], dtype=np.int64), p_[known])
+    raise ValueError(f"{path}: unsupported blacklist format (use .h5 / .pkl of (chrom, pos) loci, .bed, .npy or .npz)")
