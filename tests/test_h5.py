@@ -201,3 +201,21 @@ def test_errors_are_loud(tmp_path):
         h5.write_hdf(str(p), {"a": {"x": np.zeros(3), "y": np.zeros(4)}})
     with pytest.raises(h5.H5Error, match="cannot be stored"):
         h5.write_hdf(str(p), {"a": {"x": np.zeros(3, np.complex128)}})
+
+
+def test_append_mode_keeps_other_keys(tmp_path):
+    """`to_hdf(path, key)` twice on one file, as evaluate_concordance.py:101,105 does."""
+    path = str(tmp_path / "a.h5")
+    a = h5.Frame([("x", np.arange(4.0)), ("s", np.array(list("abcd"), dtype=object))], index=np.array([3, 1, 2, 0]))
+    b = h5.Frame([("y", np.arange(3, dtype=np.int64))])
+    h5.write_hdf(path, {"first": a}, mode="a")
+    h5.write_hdf(path, {"second": b}, mode="a")
+    h5.write_hdf(path, {"second": h5.Frame([("y", np.arange(5, dtype=np.int64))])}, mode="a")     # overwrite one key
+    with h5.H5File(path) as f:
+        assert f.keys() == ["first", "second"]
+    got = h5.read_hdf(path, "first")
+    assert np.array_equal(got["x"], a["x"]) and list(got["s"]) == list("abcd") and np.array_equal(got.index, [3, 1, 2, 0])
+    assert h5.read_hdf(path, "second")["y"].tolist() == [0, 1, 2, 3, 4]
+    h5.write_hdf(path, {"only": b})
+    with h5.H5File(path) as f:
+        assert f.keys() == ["only"]

@@ -953,9 +953,25 @@ def _write_axis(img, children, gattrs, key, index, names, n):
     _write_index(img, children, key, index, (names or [None])[0])
 
 
-def write_hdf(path, objects):
+def write_hdf(path, objects, mode="w"):
     """Write {key: Frame | dict of equal-length 1-D arrays} as pandas fixed-format frames (`DataFrame.to_hdf(path,
-    key)` for every key; the file is replaced).  Object columns are pickled exactly as pandas does."""
+    key)` for every key).  mode "w" replaces the file; mode "a" (pandas' default) keeps the frames already stored
+    under other keys - the file is small bookkeeping next to the data, so it is simply rewritten.  Object columns are
+    pickled exactly as pandas does."""
+    if mode not in ("w", "a"):
+        raise ValueError(f"mode must be 'w' or 'a', not {mode!r}")
+    if mode == "a":
+        import os
+        if os.path.exists(path) and os.path.getsize(path):
+            with H5File(path) as f:
+                old = [k for k in f.keys() if k not in objects]
+                kinds = {k: f[k].attrs.get("pandas_type") for k in old}
+            bad = [k for k in old if kinds[k] != "frame"]
+            if bad:
+                raise H5Error(f"{path}: cannot carry over the non-frame objects {bad}")
+            merged = OrderedDict((k, read_hdf(path, k)) for k in old)
+            merged.update(objects)
+            objects = merged
     img = _Image()
     img._vl_fix = []
     built = []
