@@ -206,6 +206,23 @@ int ugvc_timed_pileup(ugvc_ctx* ctx, int iters, float* ms_total);
 int ugvc_sec_likelihood_ratio(ugvc_ctx* ctx, const int32_t* actual, const int32_t* expected,
                               int64_t n_loci, int k, double* likelihood, double* ratio);
 
+/* ---- SEC database: build + apply.  The tools (sec_training,
+ * correct_systematic_errors: /root/reference/ugvc/__main__.py:19,56) are absent and undocumented (README.md:12); the
+ * statistic is in-tree (stats_utils.py:12-70) and a call the cohort's noise explains is tagged "SEC"
+ * (ugvc/reports/report_utils.py:71-75).  BUILDER-DEFINED around those two facts:
+ *   build : n_obs (key, k counts) observations of a cohort, any order, keys = contig << 32 | pos  ->  sorted unique
+ *           keys + per-locus summed counts (out arrays sized n_obs by the caller; *out_n = loci);
+ *   upload: the database a context applies (keys sorted, unique; k = 2: ref, alt; k = 3: ref, alt, other);
+ *   apply : per RESIDENT variant on a database locus: observed = (ad_ref, ad_alt[, max(dp - ad_ref - ad_alt, 0)]),
+ *           expected rescaled to the observed depth with scale_contingency_table when scale_expected != 0,
+ *           ratio[i] = multinomial_likelihood_ratio(observed, expected)[1], is_sec[i] = ratio >= min_ratio; off the
+ *           database ratio = NaN, is_sec = 0.  mark != 0 also ORs UGVC_FLAG_SEC into the resident flags column (after
+ *           ugvc_filter_resident), which the gather / download then carry.  ratio / is_sec may be NULL. */
+int ugvc_sec_db_build(ugvc_ctx* ctx, const uint64_t* keys, const int32_t* counts, int64_t n_obs, int k,
+                      uint64_t* out_keys, int32_t* out_expected, int64_t* out_n);
+int ugvc_sec_db_upload(ugvc_ctx* ctx, const uint64_t* keys, const int32_t* expected, int64_t n_db, int k);
+int ugvc_sec_apply(ugvc_ctx* ctx, double min_ratio, int scale_expected, int mark, double* ratio, uint8_t* is_sec);
+
 /* ---- is_homopolymer_snp + VAF gate (/root/reference/ugvc/pipelines/vcfbed/
  * calibrate_bridging_snvs.py:9-66,110-126): out_pass[i]=1 when the record is un-filtered. */
 typedef struct ugvc_bridging_params {

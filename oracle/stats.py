@@ -55,6 +55,40 @@ def sec_batch(actual: np.ndarray, expected: np.ndarray):
     return lik, lik / np.exp(logpmf(a, a))
 
 
+def sec_db_build(keys: np.ndarray, counts: np.ndarray):
+    """SEC database from cohort observations (BUILDER-DEFINED, include/ugvc_mi355x.h "SEC database"): per locus key the
+    summed counts.  Checker of ugvc_sec_db_build."""
+    keys = np.asarray(keys, dtype=np.uint64)
+    counts = np.asarray(counts, dtype=np.int64)
+    uk, inv = np.unique(keys, return_inverse=True)
+    out = np.zeros((uk.size, counts.shape[1]), np.int64)
+    np.add.at(out, inv, counts)
+    return uk, out
+
+
+def sec_apply(keys, dp, ad_ref, ad_alt, db_keys, db_expected, min_ratio=0.05, scale_expected=True):
+    """Checker of ugvc_sec_apply: per variant on a database locus, observed = (ad_ref, ad_alt[, max(dp - ad_ref - ad_alt,
+    0)]), expected optionally passed through scale_contingency_table(expected, sum(observed)) (stats_utils.py:12-28),
+    ratio = multinomial_likelihood_ratio(observed, expected)[1] (:66-70) - each call the scalar restatement above."""
+    keys = np.asarray(keys, dtype=np.uint64)
+    db_keys = np.asarray(db_keys, dtype=np.uint64)
+    k = np.asarray(db_expected).shape[1]
+    ratio = np.full(keys.size, np.nan)
+    hit = np.zeros(keys.size, bool)
+    j = np.searchsorted(db_keys, keys)
+    for i in range(keys.size):
+        if j[i] >= db_keys.size or db_keys[j[i]] != keys[i]:
+            continue
+        r, a = max(int(ad_ref[i]), 0), max(int(ad_alt[i]), 0)
+        obs = [r, a] + ([max(int(dp[i]) - r - a, 0)] if k > 2 else []) + [0] * max(0, k - 3)
+        exp = [int(x) for x in db_expected[j[i]]]
+        if scale_expected:
+            exp = [int(x) for x in scale_contingency_table(exp, sum(obs))]
+        ratio[i] = multinomial_likelihood_ratio(obs, exp)[1]
+        hit[i] = ratio[i] >= min_ratio
+    return ratio, hit
+
+
 def phred(p):
     """math_utils.py:31-47."""
     return -10 * np.log10(np.array(p, dtype=float))

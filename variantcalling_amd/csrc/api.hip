@@ -115,6 +115,7 @@ int build_args(ugvc_ctx* ctx, FilterArgs& a, bool want_x) {
 // kernel_variant bit 8 (256) forces v1 (A/B measurements, parity cross-checks).
 // kernel_variant bit 9 (512) forces v2 over v3.
 int launch_score(ugvc_ctx* ctx, const FilterArgs& a) {
+    if (a.flags == ctx->r_flags.as<uint8_t>()) ctx->scored = 1;
     if (!(ctx->kernel_variant & 256) && v2_available(ctx)) {
         if (!(ctx->kernel_variant & 512) && v3_available(ctx)) {
             // kernel variant bit 7 (128): the v4 featurize kernel (single-contig tiles, sentinel-padded joins, packed
@@ -167,7 +168,7 @@ int ugvc_ctx_destroy(ugvc_ctx* ctx) {
                         &ctx->v_contig, &ctx->v_pos, &ctx->v_rl, &ctx->v_al, &ctx->v_ro, &ctx->v_ao,
                         &ctx->v_alleles, &ctx->v_qual, &ctx->v_sor, &ctx->v_dp, &ctx->v_adr, &ctx->v_ada,
                         &ctx->v_gq, &ctx->r_score, &ctx->r_filter, &ctx->r_flags, &ctx->x_mat, &ctx->x_group,
-                        &ctx->pl_off, &ctx->pl_obsb, &ctx->pl_out, &ctx->g_score[0], &ctx->g_filter[0], &ctx->g_flags[0],
+                        &ctx->pl_off, &ctx->pl_obsb, &ctx->pl_out, &ctx->sec_keys, &ctx->sec_coarse, &ctx->sec_exp, &ctx->g_score[0], &ctx->g_filter[0], &ctx->g_flags[0],
                         &ctx->g_score[1], &ctx->g_filter[1], &ctx->g_flags[1]};
     for (auto* b : all) release(*b);
     for (int t = 0; t < UGVC_MAX_TRACKS; ++t) {
@@ -470,6 +471,7 @@ int ugvc_variants_upload(ugvc_ctx* ctx, const ugvc_variants* v) {
     if (ensure(ctx->r_score, n * 4) || ensure(ctx->r_filter, n) || ensure(ctx->r_flags, n)) return -1;
     UGVC_HIP(hipStreamSynchronize(ctx->stream));
     ctx->n = v->n;
+    ctx->scored = 0;
     return 0;
 }
 

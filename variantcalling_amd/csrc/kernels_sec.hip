@@ -1,0 +1,227 @@
+// SEC (systematic error correction) database: build + apply on the GPU.
+//
+// What the reference tree fixes: the statistic - scale_contingency_table, correct_multinomial_frequencies,
+// multinomial_likelihood, multinomial_likelihood_ratio (/root/reference/ugvc/utils/stats_utils.py:12-70, known answers
+// test/unit/utils/test_stats_utils.py:18-110) - and that a call explained by the cohort's noise is tagged "SEC"
+// (ugvc/reports/report_utils.py:71-75).  The tools around it (sec_training, correct_systematic_errors;
+// ugvc/__main__.py:19,56) are in the absent submodule and undocumented (README.md:12), so the database layout and
+// the decision rule below are BUILDER-DEFINED and say so wherever they surface:
+//   * database = sorted unique locus keys (contig << 32 | pos, the blacklist key) + k expected counts per locus, the
+//     cohort's summed allele tallies (k = 2: ref, alt; k = 3: ref, alt, other);
+//   * build   = concatenated per-sample (key, counts) observations -> stable radix sort by key -> segmented sums
+//     (rocPRIM via hipCUB: library primitives for a library-shaped step);
+//   * apply   = per resident variant: exact key lookup (two-level: every 64th key first, then one 64-key block);
+//     observed = (ad_ref, ad_alt[, max(dp - ad_ref - ad_alt, 0)]); expected optionally rescaled to the observed depth
+//     with scale_contingency_table (round half to even, as numpy); ratio = multinomial_likelihood_ratio(observed,
+//     expected)[1]; is_sec = ratio >= min_ratio; NaN / 0 off the database.  With `mark` the SEC bit is OR-ed into the
+//     resident flags column, so the gathered callset carries it.
+#include <hipcub/hipcub.hpp>
+
+#include "ugvc_device.hpp"
+
+namespace ugvc {
+
+constexpr int kSecMaxK = 8;
+
+__device__ __forceinline__ double sec_log_pmf(const int* x, const int* e, int k) {     // as kernels_aux.hip:log_multinomial_pmf
+    double tot = 0.0;
+    int n = 0;
+    for (int i = 0; i < k; ++i) { tot += (double)e[i] + 1.0; n += x[i]; }
+    double lp = lgamma((double)n + 1.0);
+    for (int i = 0; i < k; ++i) {
+        const double p = ((double)e[i] + 1.0) / tot;
+        if (x[i] > 0) lp += (double)x[i] * log(p);
+        lp -= lgamma((double)x[i] + 1.0);
+    }
+    return lp;
+}
+
+__global__ __launch_bounds__(256) void sec_apply_kernel(const uint8_t* __restrict__ contig, const int32_t* __restrict__ pos,
+                                                        const int32_t* __restrict__ dp, const int32_t* __restrict__ adr,
+                                                        const int32_t* __restrict__ ada, int64_t n,
+                                                        const uint64_t* __restrict__ keys, const uint64_t* __restrict__ coarse,
+                                                        const int32_t* __restrict__ expected, int64_t n_db, int k, double min_ratio,
+                                                        int scale, double* __restrict__ ratio, uint8_t* __restrict__ is_sec,
+                                                        uint8_t* __restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t key = ((uint64_t)contig[i] << 32) | (uint32_t)pos[i];
+    // lower bound over the sampled keys, then inside the 64-key block it names
+    const int64_t nc = (n_db + 63) >> 6;
+    int64_t lo = 0, len = nc;
+    while (len > 0) {
+        const int64_t half = len >> 1;
+        if (coarse[lo + half] <= key) { lo += half + 1; len -= half + 1; }
+        else len = half;
+    }
+    double r = __longlong_as_double(0x7ff8000000000000ll);
+    uint8_t hit = 0;
+    if (lo > 0) {
+        const int64_t b0 = (lo - 1) << 6;
+        int64_t l2 = b0, n2 = (n_db - b0 < 64 ? n_db - b0 : 64);
+        while (n2 > 0) {
+            const int64_t half = n2 >> 1;
+            if (keys[l2 + half] < key) { l2 += half + 1; n2 -= half + 1; }
+            else n2 = half;
+        }
+        if (l2 < n_db && keys[l2] == key) {
+            int a[kSecMaxK], e[kSecMaxK];
+            const int r0 = adr[i] > 0 ? adr[i] : 0, a0 = ada[i] > 0 ? ada[i] : 0;
+            a[0] = r0;
+            a[1] = a0;
+            if (k > 2) { const int o = dp[i] - r0 - a0; a[2] = o > 0 ? o : 0; }
+            for (int c = 3; c < k; ++c) a[c] = 0;
+            long long s = 0, na = 0;
+            for (int c = 0; c < k; ++c) { e[c] = expected[l2 * k + c]; s += e[c]; na += a[c]; }
+            if (scale && s > 0) {
+                const double f = (double)na / (double)s;              // stats_utils.py:24-27: np.round(table * (n / sum))
+                for (int c = 0; c < k; ++c) e[c] = (int)rint((double)e[c] * f);
+            }
+            const double l = exp(sec_log_pmf(a, e, k));
+            const double lmax = exp(sec_log_pmf(a, a, k));
+            r = l / lmax;
+            hit = r >= min_ratio ? 1 : 0;
+        }
+    }
+    if (ratio) ratio[i] = r;
+    if (is_sec) is_sec[i] = hit;
+    if (flags && hit) flags[i] |= UGVC_FLAG_SEC;
+}
+
+__global__ void sec_iota_kernel(uint32_t* idx, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) idx[i] = (uint32_t)i;
+}
+
+__global__ void sec_gather_col_kernel(const int32_t* __restrict__ counts, const uint32_t* __restrict__ idx, int64_t n, int k, int c,
+                                      long long* __restrict__ col) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) col[i] = counts[(int64_t)idx[i] * k + c];
+}
+
+__global__ void sec_scatter_col_kernel(const long long* __restrict__ sums, int64_t n, int k, int c, int32_t* __restrict__ out,
+                                       int* __restrict__ overflow) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long v = sums[i];
+    if (v > 2147483647ll) { *overflow = 1; out[i * k + c] = 2147483647; }
+    else out[i * k + c] = (int32_t)v;
+}
+
+}  // namespace ugvc
+
+using namespace ugvc;
+
+extern "C" {
+
+int ugvc_sec_db_build(ugvc_ctx* ctx, const uint64_t* keys, const int32_t* counts, int64_t n_obs, int k, uint64_t* out_keys,
+                      int32_t* out_expected, int64_t* out_n) {
+    if (!ctx || !out_n || (n_obs > 0 && (!keys || !counts || !out_keys || !out_expected))) return fail("NULL argument");
+    if (k < 2 || k > kSecMaxK) return fail("k must be in 2..8");
+    if (n_obs < 0 || n_obs >= ((int64_t)1 << 31)) return fail("n_obs out of range");
+    *out_n = 0;
+    if (n_obs == 0) return 0;
+    for (int64_t i = 0; i < n_obs * k; ++i)
+        if (counts[i] < 0) return fail("counts must be non-negative");
+    UGVC_HIP(hipSetDevice(ctx->device));
+    DeviceBuf d_k0, d_k1, d_i0, d_i1, d_cnt, d_col, d_uk, d_sum, d_num, d_out, d_ovf, d_tmp;
+    DeviceBuf* all[] = {&d_k0, &d_k1, &d_i0, &d_i1, &d_cnt, &d_col, &d_uk, &d_sum, &d_num, &d_out, &d_ovf, &d_tmp};
+    int rc = 0;
+    const size_t N = (size_t)n_obs;
+    const unsigned grid = (unsigned)((n_obs + 255) / 256);
+    do {
+        if ((rc = upload(ctx, d_k0, keys, N * 8)) || (rc = upload(ctx, d_cnt, counts, N * k * 4))) break;
+        if ((rc = ensure(d_k1, N * 8)) || (rc = ensure(d_i0, N * 4)) || (rc = ensure(d_i1, N * 4)) || (rc = ensure(d_col, N * 8)) ||
+            (rc = ensure(d_uk, N * 8)) || (rc = ensure(d_sum, N * 8)) || (rc = ensure(d_num, 8)) || (rc = ensure(d_out, N * k * 4)) ||
+            (rc = ensure(d_ovf, 4))) break;
+        size_t t_sort = 0, t_red = 0;
+        if (hipcub::DeviceRadixSort::SortPairs(nullptr, t_sort, d_k0.as<uint64_t>(), d_k1.as<uint64_t>(), d_i0.as<uint32_t>(),
+                                               d_i1.as<uint32_t>(), (int)n_obs, 0, 64, ctx->stream) != hipSuccess ||
+            hipcub::DeviceReduce::ReduceByKey(nullptr, t_red, d_k1.as<uint64_t>(), d_uk.as<uint64_t>(), d_col.as<long long>(),
+                                              d_sum.as<long long>(), d_num.as<int>(), hipcub::Sum(), (int)n_obs, ctx->stream) != hipSuccess) {
+            rc = fail("hipcub temp-storage query failed");
+            break;
+        }
+        if ((rc = ensure(d_tmp, std::max(t_sort, t_red)))) break;
+        if (hipMemsetAsync(d_ovf.p, 0, 4, ctx->stream) != hipSuccess) { rc = fail("hipMemsetAsync failed"); break; }
+        hipLaunchKernelGGL(sec_iota_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_i0.as<uint32_t>(), n_obs);
+        size_t t = d_tmp.cap;
+        if (hipcub::DeviceRadixSort::SortPairs(d_tmp.p, t, d_k0.as<uint64_t>(), d_k1.as<uint64_t>(), d_i0.as<uint32_t>(), d_i1.as<uint32_t>(),
+                                               (int)n_obs, 0, 64, ctx->stream) != hipSuccess) { rc = fail("radix sort failed"); break; }
+        int n_unique = 0;
+        for (int c = 0; c < k && !rc; ++c) {
+            hipLaunchKernelGGL(sec_gather_col_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_cnt.as<int32_t>(), d_i1.as<uint32_t>(), n_obs, k,
+                               c, d_col.as<long long>());
+            t = d_tmp.cap;
+            if (hipcub::DeviceReduce::ReduceByKey(d_tmp.p, t, d_k1.as<uint64_t>(), d_uk.as<uint64_t>(), d_col.as<long long>(),
+                                                  d_sum.as<long long>(), d_num.as<int>(), hipcub::Sum(), (int)n_obs, ctx->stream) != hipSuccess) {
+                rc = fail("reduce by key failed");
+                break;
+            }
+            if (c == 0) {
+                if (hipMemcpyAsync(&n_unique, d_num.p, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                    hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = fail("sec_db_build: device error"); break; }
+            }
+            hipLaunchKernelGGL(sec_scatter_col_kernel, dim3((unsigned)((n_unique + 255) / 256)), dim3(256), 0, ctx->stream,
+                               d_sum.as<long long>(), (int64_t)n_unique, k, c, d_out.as<int32_t>(), d_ovf.as<int>());
+        }
+        if (rc) break;
+        int ovf = 0;
+        if (hipMemcpyAsync(out_keys, d_uk.p, (size_t)n_unique * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(out_expected, d_out.p, (size_t)n_unique * k * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(&ovf, d_ovf.p, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = fail("sec_db_build: device error"); break; }
+        if (ovf) { rc = fail("a summed count exceeds int32"); break; }
+        *out_n = n_unique;
+    } while (0);
+    for (DeviceBuf* b : all) if (b->p) (void)hipFree(b->p);
+    return rc;
+}
+
+int ugvc_sec_db_upload(ugvc_ctx* ctx, const uint64_t* keys, const int32_t* expected, int64_t n_db, int k) {
+    if (!ctx) return fail("ctx is NULL");
+    if (n_db < 0 || (n_db > 0 && (!keys || !expected))) return fail("bad SEC database arguments");
+    if (k < 2 || k > kSecMaxK) return fail("k must be in 2..8");
+    for (int64_t i = 1; i < n_db; ++i)
+        if (keys[i] <= keys[i - 1]) return fail("SEC database keys must be sorted and unique");
+    for (int64_t i = 0; i < n_db * k; ++i)
+        if (expected[i] < 0) return fail("expected counts must be non-negative");
+    UGVC_HIP(hipSetDevice(ctx->device));
+    if (upload(ctx, ctx->sec_keys, keys, (size_t)n_db * 8) || upload(ctx, ctx->sec_exp, expected, (size_t)n_db * k * 4)) return -1;
+    std::vector<uint64_t> c((size_t)((n_db + 63) / 64));
+    for (size_t j = 0; j < c.size(); ++j) c[j] = keys[j * 64];
+    if (upload(ctx, ctx->sec_coarse, c.data(), c.size() * 8)) return -1;
+    UGVC_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->n_sec = n_db;
+    ctx->sec_k = k;
+    return 0;
+}
+
+int ugvc_sec_apply(ugvc_ctx* ctx, double min_ratio, int scale_expected, int mark, double* ratio, uint8_t* is_sec) {
+    if (!ctx) return fail("ctx is NULL");
+    if (!(min_ratio >= 0.0)) return fail("min_ratio must be >= 0");
+    if (!ctx->sec_k) return fail("no SEC database uploaded (ugvc_sec_db_upload)");
+    const int64_t n = ctx->n;
+    if (n == 0) return 0;
+    if (!ctx->v_pos.p) return fail("no variants resident (ugvc_variants_upload)");
+    if (mark && !(ctx->scored && ctx->r_flags.p)) return fail("mark needs the resident flags column of a scoring pass (ugvc_filter_resident)");
+    UGVC_HIP(hipSetDevice(ctx->device));
+    DeviceBuf d_r, d_s;
+    int rc = 0;
+    do {
+        if ((ratio && (rc = ensure(d_r, (size_t)n * 8))) || (is_sec && (rc = ensure(d_s, (size_t)n)))) break;
+        hipLaunchKernelGGL(sec_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->v_contig.as<uint8_t>(),
+                           ctx->v_pos.as<int32_t>(), ctx->v_dp.as<int32_t>(), ctx->v_adr.as<int32_t>(), ctx->v_ada.as<int32_t>(), n,
+                           ctx->sec_keys.as<uint64_t>(), ctx->sec_coarse.as<uint64_t>(), ctx->sec_exp.as<int32_t>(), ctx->n_sec, ctx->sec_k,
+                           min_ratio, scale_expected, ratio ? d_r.as<double>() : nullptr, is_sec ? d_s.as<uint8_t>() : nullptr,
+                           mark ? ctx->r_flags.as<uint8_t>() : nullptr);
+        if (hipGetLastError() != hipSuccess) { rc = fail("sec_apply: launch failed"); break; }
+        if ((ratio && hipMemcpyAsync(ratio, d_r.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) ||
+            (is_sec && hipMemcpyAsync(is_sec, d_s.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = fail("sec_apply: device error"); break; }
+    } while (0);
+    for (DeviceBuf* b : {&d_r, &d_s}) if (b->p) (void)hipFree(b->p);
+    return rc;
+}
+
+}  // extern "C"

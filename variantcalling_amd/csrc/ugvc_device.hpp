@@ -122,11 +122,16 @@ struct ugvc_ctx {
     ugvc::DeviceBuf v_contig, v_pos, v_rl, v_al, v_ro, v_ao, v_alleles, v_qual, v_sor, v_dp,
         v_adr, v_ada, v_gq;
     ugvc::DeviceBuf r_score, r_filter, r_flags, x_mat, x_group;
+    int scored = 0;                    // the resident result columns hold a scoring pass over the resident variants
     ugvc::DeviceBuf v_tiles;           // v4 kernel: int2 {first variant, count | contig << 16} per single-contig tile
     int n_tiles4 = 0;
     // pileup
     int64_t pl_n = 0, pl_obs = 0;
     ugvc::DeviceBuf pl_off, pl_obsb, pl_out;
+    // SEC database (kernels_sec.hip): sorted locus keys, every 64th key, k expected counts per locus
+    ugvc::DeviceBuf sec_keys, sec_coarse, sec_exp;
+    int64_t n_sec = 0;
+    int sec_k = 0;
     // gather
     ugvc::DeviceBuf g_score[2], g_filter[2], g_flags[2];   // double-buffered: pass i+1 writes one while the collective of pass i reads the other
     int g_cur = 0;                                         // buffer the last gather used

@@ -81,6 +81,9 @@ ABI = {
     "ugvc_pileup_upload": (C.c_int, [_ctx, _i64p, _u16p, C.c_int64]),
     "ugvc_timed_pileup": (C.c_int, [_ctx, C.c_int, _f32p]),
     "ugvc_sec_likelihood_ratio": (C.c_int, [_ctx, _i32p, _i32p, C.c_int64, C.c_int, _f64p, _f64p]),
+    "ugvc_sec_db_build": (C.c_int, [_ctx, _u64p, _i32p, C.c_int64, C.c_int, _u64p, _i32p, _i64p]),
+    "ugvc_sec_db_upload": (C.c_int, [_ctx, _u64p, _i32p, C.c_int64, C.c_int]),
+    "ugvc_sec_apply": (C.c_int, [_ctx, C.c_double, C.c_int, C.c_int, _f64p, _u8p]),
     "ugvc_bridging_snvs": (C.c_int, [_ctx, C.POINTER(CVariants), _u8p, _i32p, _i32p, _i32p,
                                      C.POINTER(CBridgingParams), _u8p, _u8p]),
     "ugvc_comm_unique_id": (C.c_int, [_u8p]),
@@ -360,6 +363,32 @@ class Engine:
         self._check(self.lib.ugvc_sec_likelihood_ratio(self._h, _p(a, _i32p), _p(e, _i32p), a.shape[0], a.shape[1],
                                                        _p(lik, _f64p), _p(ratio, _f64p)))
         return lik, ratio
+
+    # ---- SEC database (builder-defined around the in-tree statistic; include/ugvc_mi355x.h)
+    def sec_db_build(self, keys: np.ndarray, counts: np.ndarray):
+        """Cohort observations (u64 locus keys in any order, [n_obs, k] counts) -> (sorted unique keys, summed counts)."""
+        k_ = np.ascontiguousarray(keys, np.uint64)
+        c = _col(counts, np.int32)
+        if c.ndim != 2 or c.shape[0] != k_.size:
+            raise ValueError("counts must be [n_obs, k] with one row per key")
+        ok, oe, on = np.zeros(k_.size, np.uint64), np.zeros(c.shape, np.int32), C.c_int64()
+        self._check(self.lib.ugvc_sec_db_build(self._h, _p(k_, _u64p), _p(c, _i32p), k_.size, c.shape[1], _p(ok, _u64p),
+                                               _p(oe, _i32p), C.byref(on)))
+        return ok[:on.value].copy(), oe[:on.value].copy()
+
+    def set_sec_db(self, keys: np.ndarray, expected: np.ndarray):
+        k_ = np.ascontiguousarray(keys, np.uint64)
+        e = _col(expected, np.int32)
+        if e.ndim != 2 or e.shape[0] != k_.size:
+            raise ValueError("expected must be [n_db, k] with one row per key")
+        self._check(self.lib.ugvc_sec_db_upload(self._h, _p(k_, _u64p), _p(e, _i32p), k_.size, e.shape[1]))
+
+    def sec_apply(self, min_ratio: float = 0.05, scale_expected: bool = True, mark: bool = False):
+        """(ratio f64 [n] - NaN off the database, is_sec bool [n]) for the resident variants; mark=True also sets the
+        SEC bit in the resident flags column (needs a scoring pass first)."""
+        ratio, hit = np.zeros(self.n, np.float64), np.zeros(self.n, np.uint8)
+        self._check(self.lib.ugvc_sec_apply(self._h, float(min_ratio), int(scale_expected), int(mark), _p(ratio, _f64p), _p(hit, _u8p)))
+        return ratio, hit.astype(bool)
 
     # ---- calibrate_bridging_snvs
     def bridging_snvs(self, vt: S.VariantTable, is_pass, ad_alt_sum, bg_ad_alt_sum, bg_dp,
