@@ -17,31 +17,45 @@
 //     resident flags column, so the gathered callset carries it.
 #include <hipcub/hipcub.hpp>
 
+#include <cmath>
+#include <vector>
+
 #include "ugvc_device.hpp"
 
 namespace ugvc {
 
 constexpr int kSecMaxK = 8;
 
-__device__ __forceinline__ double sec_log_pmf(const int* x, const int* e, int k) {     // as kernels_aux.hip:log_multinomial_pmf
-    double tot = 0.0;
+constexpr int kSecLgTab = 4096;                                   // log(m!) for m = 0..4096 (host std::lgamma), beyond: lgamma()
+
+__device__ __forceinline__ double sec_log_fact(const double* __restrict__ tab, int m) {
+    return m <= kSecLgTab ? tab[m] : lgamma((double)m + 1.0);
+}
+
+// log pmf(x; n, p(e)) and log pmf(x; n, p(x)) of stats_utils.py:47-70 share lgamma(n+1) - sum lgamma(x_i+1): every
+// argument is an integer, so that part is table look-ups; what differs is sum x_i log p_i
+__device__ __forceinline__ void sec_log_pmf2(const int* x, const int* e, int k, const double* __restrict__ tab, double& lp_e, double& lp_x) {
+    double tot_e = 0.0, tot_x = 0.0;
     int n = 0;
-    for (int i = 0; i < k; ++i) { tot += (double)e[i] + 1.0; n += x[i]; }
-    double lp = lgamma((double)n + 1.0);
+    for (int i = 0; i < k; ++i) { tot_e += (double)e[i] + 1.0; tot_x += (double)x[i] + 1.0; n += x[i]; }
+    double g = sec_log_fact(tab, n), se = 0.0, sx = 0.0;
     for (int i = 0; i < k; ++i) {
-        const double p = ((double)e[i] + 1.0) / tot;
-        if (x[i] > 0) lp += (double)x[i] * log(p);
-        lp -= lgamma((double)x[i] + 1.0);
+        if (x[i] > 0) {
+            se += (double)x[i] * log(((double)e[i] + 1.0) / tot_e);
+            sx += (double)x[i] * log(((double)x[i] + 1.0) / tot_x);
+        }
+        g -= sec_log_fact(tab, x[i]);
     }
-    return lp;
+    lp_e = g + se;
+    lp_x = g + sx;
 }
 
 __global__ __launch_bounds__(256) void sec_apply_kernel(const uint8_t* __restrict__ contig, const int32_t* __restrict__ pos,
                                                         const int32_t* __restrict__ dp, const int32_t* __restrict__ adr,
                                                         const int32_t* __restrict__ ada, int64_t n,
                                                         const uint64_t* __restrict__ keys, const uint64_t* __restrict__ coarse,
-                                                        const int32_t* __restrict__ expected, int64_t n_db, int k, double min_ratio,
-                                                        int scale, double* __restrict__ ratio, uint8_t* __restrict__ is_sec,
+                                                        const int32_t* __restrict__ expected, const double* __restrict__ lg_tab, int64_t n_db, int k,
+                                                        double min_ratio, int scale, double* __restrict__ ratio, uint8_t* __restrict__ is_sec,
                                                         uint8_t* __restrict__ flags) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -77,9 +91,9 @@ __global__ __launch_bounds__(256) void sec_apply_kernel(const uint8_t* __restric
                 const double f = (double)na / (double)s;              // stats_utils.py:24-27: np.round(table * (n / sum))
                 for (int c = 0; c < k; ++c) e[c] = (int)rint((double)e[c] * f);
             }
-            const double l = exp(sec_log_pmf(a, e, k));
-            const double lmax = exp(sec_log_pmf(a, a, k));
-            r = l / lmax;
+            double lp_e, lp_x;
+            sec_log_pmf2(a, e, k, lg_tab, lp_e, lp_x);
+            r = exp(lp_e) / exp(lp_x);
             hit = r >= min_ratio ? 1 : 0;
         }
     }
@@ -191,6 +205,9 @@ int ugvc_sec_db_upload(ugvc_ctx* ctx, const uint64_t* keys, const int32_t* expec
     std::vector<uint64_t> c((size_t)((n_db + 63) / 64));
     for (size_t j = 0; j < c.size(); ++j) c[j] = keys[j * 64];
     if (upload(ctx, ctx->sec_coarse, c.data(), c.size() * 8)) return -1;
+    std::vector<double> lg((size_t)kSecLgTab + 1);
+    for (int m = 0; m <= kSecLgTab; ++m) lg[(size_t)m] = std::lgamma((double)m + 1.0);
+    if (upload(ctx, ctx->sec_lgtab, lg.data(), lg.size() * 8)) return -1;
     UGVC_HIP(hipStreamSynchronize(ctx->stream));
     ctx->n_sec = n_db;
     ctx->sec_k = k;
@@ -212,7 +229,8 @@ int ugvc_sec_apply(ugvc_ctx* ctx, double min_ratio, int scale_expected, int mark
         if ((ratio && (rc = ensure(d_r, (size_t)n * 8))) || (is_sec && (rc = ensure(d_s, (size_t)n)))) break;
         hipLaunchKernelGGL(sec_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->v_contig.as<uint8_t>(),
                            ctx->v_pos.as<int32_t>(), ctx->v_dp.as<int32_t>(), ctx->v_adr.as<int32_t>(), ctx->v_ada.as<int32_t>(), n,
-                           ctx->sec_keys.as<uint64_t>(), ctx->sec_coarse.as<uint64_t>(), ctx->sec_exp.as<int32_t>(), ctx->n_sec, ctx->sec_k,
+                           ctx->sec_keys.as<uint64_t>(), ctx->sec_coarse.as<uint64_t>(), ctx->sec_exp.as<int32_t>(), ctx->sec_lgtab.as<double>(), ctx->n_sec,
+                           ctx->sec_k,
                            min_ratio, scale_expected, ratio ? d_r.as<double>() : nullptr, is_sec ? d_s.as<uint8_t>() : nullptr,
                            mark ? ctx->r_flags.as<uint8_t>() : nullptr);
         if (hipGetLastError() != hipSuccess) { rc = fail("sec_apply: launch failed"); break; }

@@ -129,7 +129,7 @@ struct ugvc_ctx {
     int64_t pl_n = 0, pl_obs = 0;
     ugvc::DeviceBuf pl_off, pl_obsb, pl_out;
     // SEC database (kernels_sec.hip): sorted locus keys, every 64th key, k expected counts per locus
-    ugvc::DeviceBuf sec_keys, sec_coarse, sec_exp;
+    ugvc::DeviceBuf sec_keys, sec_coarse, sec_exp, sec_lgtab;
     int64_t n_sec = 0;
     int sec_k = 0;
     // gather

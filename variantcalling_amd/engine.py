@@ -383,9 +383,13 @@ class Engine:
             raise ValueError("expected must be [n_db, k] with one row per key")
         self._check(self.lib.ugvc_sec_db_upload(self._h, _p(k_, _u64p), _p(e, _i32p), k_.size, e.shape[1]))
 
-    def sec_apply(self, min_ratio: float = 0.05, scale_expected: bool = True, mark: bool = False):
+    def sec_apply(self, min_ratio: float = 0.05, scale_expected: bool = True, mark: bool = False, download: bool = True):
         """(ratio f64 [n] - NaN off the database, is_sec bool [n]) for the resident variants; mark=True also sets the
-        SEC bit in the resident flags column (needs a scoring pass first)."""
+        SEC bit in the resident flags column (needs a scoring pass first).  download=False leaves everything on the
+        device (with mark=True the verdict is in the resident flags) and returns None."""
+        if not download:
+            self._check(self.lib.ugvc_sec_apply(self._h, float(min_ratio), int(scale_expected), int(mark), None, None))
+            return None
         ratio, hit = np.zeros(self.n, np.float64), np.zeros(self.n, np.uint8)
         self._check(self.lib.ugvc_sec_apply(self._h, float(min_ratio), int(scale_expected), int(mark), _p(ratio, _f64p), _p(hit, _u8p)))
         return ratio, hit.astype(bool)
