@@ -11,7 +11,7 @@ CMD="python bench.py --steps 20 --warmup 3 --cpu-sample 0 $*"
 rm -rf gpurun_out/prof_$TAG
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG/trace -o trace -- $CMD > gpurun_out/prof_$TAG.bench.log 2>&1
 tail -2 gpurun_out/prof_$TAG.bench.log
-for c in FETCH_SIZE WRITE_SIZE; do
+for c in ${PMC_COUNTERS-FETCH_SIZE WRITE_SIZE}; do
   timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/prof_$TAG/pmc_$c -o pmc -- $CMD > gpurun_out/prof_$TAG.pmc_$c.log 2>&1
 done
 find gpurun_out/prof_$TAG -type f | head -30

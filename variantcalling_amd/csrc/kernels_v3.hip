@@ -877,6 +877,7 @@ __global__ __launch_bounds__(kK2Threads) void forest3_kernel(const V2Args v) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned shard_off[kShards + 1];
     __shared__ unsigned totals[UGVC_N_GROUPS];
+    __shared__ uint32_t pdesc[64];                               // the group's plane descriptors (F <= 32 features)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int n_waves = blockDim.x >> 6;
@@ -918,6 +919,9 @@ __global__ __launch_bounds__(kK2Threads) void forest3_kernel(const V2Args v) {
     const unsigned n = (unsigned)rfl((int)cnt[g]);
     if (n == 0 || nbg == 0) return;
 
+    // the descriptors go to LDS once: read from global memory per chunk they sit, as vector loads, in front of every
+    // chunk's decode and make it wait for the record prefetched for the NEXT chunk as well (in-order vmcnt)
+    if (tid < 64) pdesc[tid] = tid < pg.n_planes ? pg.plane_desc[tid] : 0u;
     if (wave == 0) {                                             // exclusive scan of the group's shard counts
         unsigned x[4], s = 0;
 #pragma unroll
@@ -1025,7 +1029,7 @@ __global__ __launch_bounds__(kK2Threads) void forest3_kernel(const V2Args v) {
         const bool live = live_next;
         if ((uint64_t)(chunk + waves) * 64 < n) q_next = fetch(chunk + waves, live_next);
         for (int p = 0; p < P; ++p) {
-            const uint32_t pd = pg.plane_desc[p];                // dword[0:2) | bit_off[2:7) | width[7:11)
+            const uint32_t pd = (uint32_t)rfl((int)pdesc[p]);    // dword[0:2) | bit_off[2:7) | width[7:11)
             const uint32_t dw = pd & 3;
             const uint32_t word = dw == 0 ? q.x : (dw == 1 ? q.y : q.z);
             planes[p * 64 + hslot] = (uint16_t)__builtin_amdgcn_ubfe(word, (pd >> 2) & 31, (pd >> 7) & 15);
