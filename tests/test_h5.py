@@ -219,3 +219,94 @@ def test_append_mode_keeps_other_keys(tmp_path):
     h5.write_hdf(path, {"only": b})
     with h5.H5File(path) as f:
         assert f.keys() == ["only"]
+
+
+# ---------------------------------------------------------------------------------- real pandas + PyTables
+CONDA_PY = "/opt/conda/bin/python3.9"
+SHIM = os.path.join(os.path.dirname(__file__), "..", "tools", "pandas_pytables_shim.py")
+
+
+def _gunzip(name, tmp_path):
+    import gzip
+    dst = str(tmp_path / name)
+    with gzip.open(os.path.join(GOLD, name + ".gz"), "rb") as src, open(dst, "wb") as out:
+        out.write(src.read())
+    return dst
+
+
+def _check_against_json(fr, exp, what):
+    """`exp` is tools/pandas_pytables_shim.py:frame_json of the DataFrame pandas holds (tuples as lists, NaN / None as null)."""
+    assert list(fr.keys()) == exp["columns"], what
+    for c, dt in zip(exp["columns"], exp["dtypes"]):
+        got, want = fr[c], exp["data"][c]
+        assert len(got) == len(want), (what, c)
+        if dt == "object":
+            for g, w in zip(got, want):
+                if w is None:
+                    assert g is None or g != g, (what, c, g)
+                else:
+                    assert (list(g) if isinstance(g, tuple) else g) == w, (what, c, g, w)
+        else:
+            assert str(got.dtype) == dt, (what, c, got.dtype, dt)
+            w = np.array([np.nan if x is None else x for x in want], dtype=got.dtype)
+            assert np.array_equal(got, w, equal_nan=got.dtype.kind == "f"), (what, c)
+    idx = fr.index if isinstance(fr.index, list) else [fr.index]
+    assert len(idx) == len(exp["index"]) and fr.index_names == exp["index_names"], (what, fr.index_names, exp["index_names"])
+    for a, b in zip(idx, exp["index"]):
+        assert list(a) == b, what
+
+
+def test_reads_what_pandas_wrote(tmp_path):
+    """Files produced by DataFrame.to_hdf / Series.to_hdf of real pandas 2.3 + PyTables 3.6 (tools/make_h5_golden.py):
+    fixed format with Range / Multi / string index, object blocks with tuples and None, an empty frame, a Series,
+    zlib-compressed blocks, and the table format with and without data columns."""
+    exp = json.load(open(os.path.join(GOLD, "pandas_expected.json")))["frames"]
+    seen = set()
+    for name in ("pd_fixed.h5", "pd_zlib.h5", "pd_table.h5"):
+        path = _gunzip(name, tmp_path)
+        with h5.H5File(path) as f:
+            keys = f.keys()
+        for k in keys:
+            _check_against_json(h5.read_hdf(path, k), exp[f"{name}:{k}"], f"{name}:{k}")
+            seen.add(f"{name}:{k}")
+    assert seen == {k for k in exp if not k.startswith("pd_blosc")} and len(seen) == 8
+    with pytest.raises(h5.H5Error, match="filter blosc is not supported"):
+        h5.read_hdf(_gunzip("pd_blosc.h5", tmp_path), "num")
+    # the concordance adapters on a frame as pandas stored it (tuples, None for missed calls)
+    from variantcalling_amd.io import concordance
+    fr = concordance.read_concordance(_gunzip("pd_fixed.h5", tmp_path), key="all", skip_keys=["concordance", "by_ref", "callable_size", "empty"])
+    vt, rows, label = concordance.frame_to_table(fr, ["chr1", "chr2", "chr3"])
+    called = [i for i in range(fr.n_rows) if fr["alleles"][i] is not None]
+    assert sorted(rows.tolist()) == called and vt.n == len(called)
+    assert np.array_equal(label, np.where(fr["classify"][rows] == "tp", 1, np.where(fr["classify"][rows] == "fp", 0, -1)))
+    assert np.array_equal(vt.gt, np.array([2 if fr["gt_ultima"][i] == (1, 1) else 1 for i in rows], np.uint8))
+
+
+@pytest.mark.skipif(not (os.path.exists(CONDA_PY) and os.path.exists(SHIM)), reason="no interpreter with pandas + PyTables here")
+def test_pandas_reads_what_we_write(tmp_path):
+    """The other direction, live: real pandas + PyTables open a file written by io.h5.write_hdf and see the same frames
+    (dtypes, values, tuples, None, NaN, Range / string / Multi index with names, empty frame, appended keys)."""
+    rng = np.random.default_rng(12)
+    n = 64
+    tup = np.empty(n, object)
+    for i in range(n):
+        tup[i] = ("A", "AT") if i % 3 else None
+    chrom = np.array([f"chr{1 + i % 2}" for i in range(n)], dtype=object)
+    cols = [("chrom", chrom), ("pos", np.arange(n, dtype=np.int64) * 5), ("alleles", tup), ("qual", rng.random(n)),
+            ("sor", rng.random(n).astype(np.float32)), ("dp", rng.integers(0, 60, n).astype(np.int32)), ("indel", rng.random(n) < 0.4),
+            ("gq", rng.integers(0, 99, n).astype(np.uint8)), ("tree_score", np.where(rng.random(n) < 0.2, np.nan, rng.random(n)))]
+    frames = {"plain": h5.Frame(cols), "multi": h5.Frame(cols, index=[chrom, cols[1][1]], index_names=["chrom", "pos"]),
+              "named": h5.Frame(cols[:4], index=np.array([f"v{i}" for i in range(n)], dtype=object), index_names=["id"]),
+              "empty": h5.Frame([("a", np.zeros(0)), ("b", np.zeros(0, np.int64)), ("s", np.zeros(0, object))])}
+    path = str(tmp_path / "ours.h5")
+    h5.write_hdf(path, frames)
+    h5.write_hdf(path, {"later": h5.Frame([("x", np.arange(3.0))])}, mode="a")
+    r = subprocess.run([CONDA_PY, SHIM, "read", path], capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    seen = json.loads(r.stdout)
+    assert sorted(seen) == ["empty", "later", "multi", "named", "plain"]
+    for k, fr in list(frames.items()) + [("later", h5.Frame([("x", np.arange(3.0))]))]:
+        exp = seen[k]
+        if fr.index is None:                                          # pandas shows the stored 0..n-1 index
+            fr = h5.Frame(fr, index=np.arange(fr.n_rows), index_names=[None])
+        _check_against_json(fr, exp, k)

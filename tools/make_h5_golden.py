@@ -7,6 +7,9 @@
 2. frame_contig.h5 (written by io.h5.write_hdf), frame_gzip.h5 / frame_gzip_only.h5 / frame_fletcher.h5 (the same
    objects re-created by libhdf5 through `h5repack`: chunked + shuffle + deflate, deflate only, fletcher32) and
    frame_expected.npz (the columns the files hold).
+3. pd_fixed / pd_zlib / pd_blosc / pd_table .h5.gz + pandas_expected.json - files written by REAL pandas + PyTables
+   (`DataFrame.to_hdf`, fixed and table format, zlib and blosc compression) through tools/pandas_pytables_shim.py in
+   /opt/conda's interpreter, gzip-ed because PyTables pre-allocates 1 MiB per pickled object block.
 Usage: python tools/make_h5_golden.py"""
 import json
 import os
@@ -88,9 +91,27 @@ def frames():
     np.savez_compressed(os.path.join(OUT, "frame_expected.npz"), **{k: (v.astype("U") if v.dtype == object else v) for k, v in cols})
 
 
+CONDA_PY = "/opt/conda/bin/python3.9"
+
+
+def pandas_files():
+    import gzip
+    import shutil
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        subprocess.run([CONDA_PY, os.path.join(ROOT, "tools", "pandas_pytables_shim.py"), "write", tmp], check=True, cwd=tmp)
+        for f in sorted(os.listdir(tmp)):
+            if f.endswith(".h5"):
+                with open(os.path.join(tmp, f), "rb") as src, gzip.GzipFile(os.path.join(OUT, f + ".gz"), "wb", 9, mtime=0) as dst:
+                    shutil.copyfileobj(src, dst)
+            else:
+                shutil.copy(os.path.join(tmp, f), os.path.join(OUT, f))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     reference_fixture()
     frames()
+    pandas_files()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -70,7 +70,7 @@ def _parse_type(buf, pos, osz=8):
         n = b0 | (b1 << 8)
         names, formats, offsets = [], [], []
         for _ in range(n):
-            e = buf.index(b"\0", p)
+            e = buf.find(b"\0", p)
             name = bytes(buf[p:e]).decode()
             if ver < 3:
                 p += (e - p + 8) & ~7                              # name + NUL padded to 8
@@ -100,7 +100,7 @@ def _parse_type(buf, pos, osz=8):
         base, p = _parse_type(buf, p, osz)
         names = []
         for _ in range(n):
-            e = buf.index(b"\0", p)
+            e = buf.find(b"\0", p)
             names.append(bytes(buf[p:e]).decode())
             p = p + ((e - p + 8) & ~7) if ver < 3 else e + 1
         vals = np.frombuffer(bytes(buf[p:p + n * base.size]), base.dtype, n)
@@ -682,20 +682,66 @@ def _read_axis(group, key):
         n = int(group.attrs[f"{key}_nlevels"])
         arrays, names = [], []
         for i in range(n):
-            lev, _ = _read_index_node(group, f"{key}_level{i}", enc)
+            lev, lev_name = _read_index_node(group, f"{key}_level{i}", enc)
             codes = np.asarray(_read_array(group, f"{key}_label{i}"))
             col = np.asarray(lev, dtype=object if lev.dtype == object else lev.dtype)[np.where(codes < 0, 0, codes)] if len(lev) else np.empty(len(codes), object)
             if (codes < 0).any():
                 col = col.astype(object)
                 col[codes < 0] = None
             arrays.append(col)
-            names.append(_unpickle_attr(group.attrs.get(f"{key}_name{i}")))
+            names.append(lev_name)                                # pandas keeps a level's name on the level node
         return arrays, names
     raise H5Error(f"axis variety {variety!r} is not supported")
 
 
+def _decode_strings(a, encoding, nan_rep):
+    out = np.empty(a.shape, object)
+    flat = out.reshape(-1)
+    for i, x in enumerate(a.reshape(-1)):
+        t = bytes(x).split(b"\0")[0].decode(encoding or "UTF-8")
+        flat[i] = np.nan if t == nan_rep else t
+    return out
+
+
+def _read_frame_table(g, key):
+    """pandas format="table" (`frame_table`): one PyTables Table of records {index, values_block_<i>[k], data
+    columns...}; `<field>_kind` on the table lists the frame columns a field carries, `non_index_axes` on the group
+    the column order.  Strings are fixed-width bytes with `nan_rep` standing for missing."""
+    if int(g.attrs.get("levels", 1)) != 1:
+        raise H5Error(f"{key}: table-format frames with a MultiIndex are not supported")
+    t = g["table"]
+    rec = t.read()
+    enc, nan_rep = g.attrs.get("encoding", "UTF-8"), g.attrs.get("nan_rep", "nan")
+    axes = _unpickle_attr(g.attrs.get("non_index_axes"))
+    order = list(axes[0][1]) if axes else None
+    fields = _unpickle_attr(g.attrs.get("values_cols"))
+    cols = {}
+    for fld in fields:
+        names = _unpickle_attr(t.attrs.get(f"{fld}_kind"))
+        dts = t.attrs.get(f"{fld}_dtype", "")
+        a = rec[fld]
+        if a.ndim == 1:
+            a = a[:, None]
+        if a.shape[1] != len(names):
+            raise H5Error(f"{key}: field {fld} is {a.shape[1]} wide for the columns {names}")
+        for j, nm in enumerate(names):
+            v = np.ascontiguousarray(a[:, j])
+            if v.dtype.kind == "S":
+                v = _decode_strings(v, enc, nan_rep)
+            elif isinstance(dts, str) and dts.startswith("datetime64"):
+                v = v.view("M8[ns]")
+            elif isinstance(dts, str) and dts.startswith("timedelta64"):
+                v = v.view("m8[ns]")
+            cols[nm] = v
+    index = rec["index"] if "index" in rec.dtype.names else None
+    if index is not None and index.dtype.kind == "S":
+        index = _decode_strings(index, enc, nan_rep)
+    order = order if order is not None else list(cols)
+    return Frame([(c, cols[c]) for c in order], index=None if index is None else np.ascontiguousarray(index), index_names=[None])
+
+
 def read_hdf(path, key=None):
-    """pandas.read_hdf for fixed-format frames and series.  Returns a Frame (a series comes back as a one-column
+    """pandas.read_hdf for fixed-format frames and series and for table-format frames.  Returns a Frame (a series comes back as a one-column
     frame named by the series' name, or "values")."""
     with H5File(path) as f:
         if key is None:
@@ -728,8 +774,10 @@ def read_hdf(path, key=None):
             vals = np.asarray(_read_array(g, "values"))
             name = _unpickle_attr(g.attrs.get("name"))
             return Frame([("values" if name is None or name == "N." else name, vals)], index=index, index_names=names)
-        if ptype in ("frame_table", "series_table", "appendable_frame"):
-            raise H5Error(f"{key}: table-format stores ({ptype}) are not supported, only format='fixed'")
+        if ptype == "frame_table":
+            return _read_frame_table(g, key)
+        if ptype in ("series_table", "appendable_frame", "appendable_series", "appendable_multiframe"):
+            raise H5Error(f"{key}: {ptype} stores are not supported (fixed-format frames / series and frame_table are)")
         raise H5Error(f"{key}: not a pandas object (pandas_type = {ptype!r})")
 
 
@@ -918,21 +966,22 @@ def _write_array(img, value, extra=()):
     return img.dataset(value, _ARRAY_ATTRS + [("transposed", transposed)] + list(extra))
 
 
-def _write_index(img, children, key, values, name=None):
+def _write_index(img, children, key, values, name=None, extra=()):
     """One index node: integers as int64, floats as float64, strings as a fixed-width byte array (kind "string"),
-    anything else as a pickled object array."""
+    anything else as a pickled object array.  The `name` attribute is the string itself, or a pickle for None - what
+    PyTables stores for a str / a non-str Python attribute."""
     values = np.asarray(values)
-    nm = ("name", _Pickled(name))
+    nm = ("name", name if isinstance(name, str) and name else _Pickled(name))
     if values.dtype.kind in "iu":
-        children[key] = (_write_array(img, values.astype(np.int64), [("kind", "integer"), nm]), None)
+        children[key] = (_write_array(img, values.astype(np.int64), [("kind", "integer"), nm] + list(extra)), None)
     elif values.dtype.kind == "f":
-        children[key] = (_write_array(img, values.astype(np.float64), [("kind", "float"), nm]), None)
+        children[key] = (_write_array(img, values.astype(np.float64), [("kind", "float"), nm] + list(extra)), None)
     elif values.dtype.kind in "OSU" and all(isinstance(x, (str, bytes)) for x in values.reshape(-1)):
         enc = [x.encode("utf-8") if isinstance(x, str) else x for x in values.reshape(-1)]
         width = max([len(x) for x in enc] + [1])
-        children[key] = (_write_array(img, np.array(enc, dtype=f"S{width}"), [("kind", "string"), nm]), None)
+        children[key] = (_write_array(img, np.array(enc, dtype=f"S{width}"), [("kind", "string"), nm] + list(extra)), None)
     else:
-        children[key] = (_write_array(img, values.astype(object), [("kind", "object"), nm]), None)
+        children[key] = (_write_array(img, values.astype(object), [("kind", "object"), nm] + list(extra)), None)
 
 
 def _write_axis(img, children, gattrs, key, index, names, n):
@@ -942,8 +991,9 @@ def _write_axis(img, children, gattrs, key, index, names, n):
         for i, col in enumerate(index):
             col = np.asarray(col)
             lev, codes = np.unique(col, return_inverse=True) if len(col) else (col, np.zeros(0, np.int64))
-            _write_index(img, children, f"{key}_level{i}", lev, names[i])
-            gattrs.append((f"{key}_name{i}", _Pickled(names[i]) if names[i] is None else names[i]))
+            # pandas keeps a level's name on the level node, twice: `name`, and `<axis>_name<name>` (sic)
+            lvl_name = names[i] if isinstance(names[i], str) and names[i] else _Pickled(names[i])
+            _write_index(img, children, f"{key}_level{i}", lev, names[i], extra=[(f"{key}_name{names[i]}", lvl_name)])
             cdt = np.int8 if len(lev) < 128 else (np.int16 if len(lev) < 32768 else (np.int32 if len(lev) < 2 ** 31 else np.int64))
             children[f"{key}_label{i}"] = (_write_array(img, codes.astype(cdt)), None)
         return
