@@ -298,13 +298,16 @@ def test_pandas_reads_what_we_write(tmp_path):
     frames = {"plain": h5.Frame(cols), "multi": h5.Frame(cols, index=[chrom, cols[1][1]], index_names=["chrom", "pos"]),
               "named": h5.Frame(cols[:4], index=np.array([f"v{i}" for i in range(n)], dtype=object), index_names=["id"]),
               "empty": h5.Frame([("a", np.zeros(0)), ("b", np.zeros(0, np.int64)), ("s", np.zeros(0, object))])}
+    frames["ser"] = h5.Frame([("callable", np.arange(4.0) * 2)], index=np.array(list("wxyz"), dtype=object), index_names=[None], series=True)
     path = str(tmp_path / "ours.h5")
     h5.write_hdf(path, frames)
     h5.write_hdf(path, {"later": h5.Frame([("x", np.arange(3.0))])}, mode="a")
     r = subprocess.run([CONDA_PY, SHIM, "read", path], capture_output=True, text=True, cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr[-2000:]
     seen = json.loads(r.stdout)
-    assert sorted(seen) == ["empty", "later", "multi", "named", "plain"]
+    assert sorted(seen) == ["empty", "later", "multi", "named", "plain", "ser"]
+    back = h5.read_hdf(path, "ser")
+    assert back.series and list(back) == ["callable"] and list(back.index) == list("wxyz")
     for k, fr in list(frames.items()) + [("later", h5.Frame([("x", np.arange(3.0))]))]:
         exp = seen[k]
         if fr.index is None:                                          # pandas shows the stored 0..n-1 index

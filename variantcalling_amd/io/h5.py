@@ -593,10 +593,29 @@ class Frame(OrderedDict):
     """Columns of a pandas frame (name -> 1-D numpy array) in their file order, plus `.index` (array, or a list of
     arrays for a MultiIndex) and `.index_names`."""
 
-    def __init__(self, cols=(), index=None, index_names=None):
+    def __init__(self, cols=(), index=None, index_names=None, series=False):
         super().__init__(cols)
         self.index = index
         self.index_names = index_names
+        self.series = series              # one column, stored / to be stored as a pandas Series (`pandas_type` = series)
+
+    @classmethod
+    def from_pandas(cls, obj):
+        """DataFrame / Series -> Frame (object columns stay object arrays; a default RangeIndex becomes None)."""
+        import pandas as pd
+        series = isinstance(obj, pd.Series)
+        df = obj.to_frame(obj.name if obj.name is not None else "values") if series else obj
+        idx = df.index
+        if isinstance(idx, pd.MultiIndex):
+            index, names = [idx.get_level_values(i).to_numpy() for i in range(idx.nlevels)], list(idx.names)
+        elif isinstance(idx, pd.RangeIndex) and idx.start == 0 and idx.step == 1 and idx.name is None:
+            index, names = None, None
+        else:
+            index, names = idx.to_numpy(), [idx.name]
+        fr = cls([(str(c), df[c].to_numpy()) for c in df.columns], index=index, index_names=names, series=series)
+        if series and obj.name is None:
+            fr.series_name = None
+        return fr
 
     @property
     def n_rows(self):
@@ -613,6 +632,9 @@ class Frame(OrderedDict):
             idx = pd.MultiIndex.from_arrays(self.index, names=self.index_names)
         elif self.index is not None:
             idx = pd.Index(self.index, name=(self.index_names or [None])[0])
+        if self.series and len(self) == 1:
+            (name, vals), = self.items()
+            return pd.Series(vals, index=idx, name=getattr(self, "series_name", name))
         return pd.DataFrame({k: v for k, v in self.items()}, index=idx, columns=list(self.keys()))
 
 
@@ -773,7 +795,10 @@ def read_hdf(path, key=None):
             index, names = _read_axis(g, "index")
             vals = np.asarray(_read_array(g, "values"))
             name = _unpickle_attr(g.attrs.get("name"))
-            return Frame([("values" if name is None or name == "N." else name, vals)], index=index, index_names=names)
+            fr = Frame([("values" if name is None or name == "N." else name, vals)], index=index, index_names=names, series=True)
+            if name is None or name == "N.":
+                fr.series_name = None
+            return fr
         if ptype == "frame_table":
             return _read_frame_table(g, key)
         if ptype in ("series_table", "appendable_frame", "appendable_series", "appendable_multiframe"):
@@ -1016,7 +1041,7 @@ def write_hdf(path, objects, mode="w"):
             with H5File(path) as f:
                 old = [k for k in f.keys() if k not in objects]
                 kinds = {k: f[k].attrs.get("pandas_type") for k in old}
-            bad = [k for k in old if kinds[k] != "frame"]
+            bad = [k for k in old if kinds[k] not in ("frame", "series", "frame_table")]
             if bad:
                 raise H5Error(f"{path}: cannot carry over the non-frame objects {bad}")
             merged = OrderedDict((k, read_hdf(path, k)) for k in old)
@@ -1031,6 +1056,19 @@ def write_hdf(path, objects, mode="w"):
         names = list(fr.keys())
         cols = [np.asarray(fr[c]) for c in names]
         n = fr.n_rows
+        if fr.series:
+            if len(names) != 1 or cols[0].ndim != 1:
+                raise ValueError(f"{key}: a series holds exactly one 1-D column")
+            v = cols[0].astype(object) if cols[0].dtype.kind in "US" else cols[0]
+            sname = getattr(fr, "series_name", names[0])
+            children = {}
+            gattrs = list(_GROUP_ATTRS) + [("pandas_type", "series"), ("pandas_version", "0.15.2"), ("encoding", "UTF-8"),
+                                           ("errors", "strict")]
+            _write_axis(img, children, gattrs, "index", fr.index, fr.index_names, n)
+            gattrs.append(("name", sname if isinstance(sname, str) and sname else _Pickled(sname)))
+            children["values"] = (_write_array(img, v), None)
+            built.append((key.strip("/"), children, gattrs))
+            continue
         for c, v in zip(names, cols):
             if v.ndim != 1 or len(v) != n:
                 raise ValueError(f"{key}: column {c!r} has shape {v.shape}, expected ({n},)")
