@@ -87,45 +87,46 @@ def frame_to_table(fr: h5.Frame, contig_names, is_mutect: bool = False, label_co
             raise KeyError(f"concordance frame has no {c!r} column (columns: {list(fr.keys())})")
     idx = {name: i for i, name in enumerate(contig_names)}
     chrom = np.asarray(fr["chrom"], dtype=object)
-    contig = np.array([idx.get(c, -1) for c in chrom], dtype=np.int64)
+    uniq, inv = np.unique(chrom.astype(str), return_inverse=True) if n else (np.zeros(0, str), np.zeros(0, np.int64))
+    contig = np.array([idx.get(c, -1) for c in uniq], dtype=np.int64)[inv] if n else np.zeros(0, np.int64)
     pos = _num(fr["pos"], n).astype(np.int64)
     ref, alleles = fr["ref"], fr["alleles"]
-    alt = np.empty(n, object)
-    ok = contig >= 0
-    for i in range(n):
-        a, r = alleles[i], ref[i]
-        if not ok[i]:
-            continue
-        if not isinstance(r, str) or not r or a is None or isinstance(a, float) or len(a) < 2 or not isinstance(a[1], str) or not a[1]:
-            ok[i] = False
-            continue
-        alt[i] = a[1]
+    # first ALT of every called row (None: no call - a missed truth variant - or a malformed row)
+    alt = [a[1] if isinstance(a, (tuple, list, np.ndarray)) and len(a) > 1 and isinstance(a[1], str) and a[1] else None for a in alleles]
+    ok = (contig >= 0) & np.fromiter((x is not None for x in alt), bool, n) & \
+        np.fromiter((isinstance(r, str) and len(r) > 0 for r in ref), bool, n)
     rows = np.flatnonzero(ok)
     rows = rows[np.lexsort((rows, pos[rows], contig[rows]))]
     m = rows.size
     refs = [ref[i].encode() for i in rows]
     alts = [alt[i].encode() for i in rows]
-    rl = np.array([len(x) for x in refs], np.uint16)
-    al = np.array([len(x) for x in alts], np.uint16)
+    rl = np.fromiter((len(x) for x in refs), np.int64, m).astype(np.uint16)
+    al = np.fromiter((len(x) for x in alts), np.int64, m).astype(np.uint16)
     off = np.concatenate([[0], np.cumsum(rl.astype(np.int64) + al)])
     pool = np.frombuffer(b"".join(r + a for r, a in zip(refs, alts)), dtype=np.uint8) if m else np.zeros(0, np.uint8)
-    ad = fr.get("ad")
-    adr, ada = np.zeros(m, np.int32), np.zeros(m, np.int32)
-    if ad is not None:
-        for k, i in enumerate(rows):
-            x = ad[i]
+
+    def first_two(col):
+        """(x[0], x[1]) of a tuple-valued column as two int arrays; missing / NaN -> 0."""
+        a0, a1 = np.zeros(m, np.int32), np.zeros(m, np.int32)
+        if col is None:
+            return a0, a1
+        for k, x in enumerate(col[rows] if isinstance(col, np.ndarray) else [col[i] for i in rows]):
             if isinstance(x, (tuple, list, np.ndarray)) and len(x):
-                adr[k] = int(x[0]) if x[0] is not None and x[0] == x[0] else 0
+                if x[0] is not None and x[0] == x[0]:
+                    a0[k] = int(x[0])
                 if len(x) > 1 and x[1] is not None and x[1] == x[1]:
-                    ada[k] = int(x[1])
+                    a1[k] = int(x[1])
+        return a0, a1
+
+    adr, ada = first_two(fr.get("ad"))
     gt = np.zeros(m, np.uint8)
     g = fr.get("gt_ultima", fr.get("gt"))
     if g is not None:
-        for k, i in enumerate(rows):
-            x = g[i]
+        code = {(1, 1): 2}
+        for k, x in enumerate(g[rows] if isinstance(g, np.ndarray) else [g[i] for i in rows]):
             if isinstance(x, (tuple, list, np.ndarray)):
                 x = tuple(x)
-                gt[k] = 2 if x == (1, 1) else (1 if 1 in x else 0)
+                gt[k] = code.get(x, 1 if 1 in x else 0)
     tlod = _num(fr.get("tlod"), n)[rows]
     qual = (10.0 * tlod) if is_mutect else _num(fr.get("qual"), n)[rows]
     vt = S.VariantTable(
@@ -145,17 +146,12 @@ def frame_to_table(fr: h5.Frame, contig_names, is_mutect: bool = False, label_co
 
 def filter_strings(res: S.FilterResult, n_tracks: int = 0) -> np.ndarray:
     """FILTER column text of a scored table: PASS | [HPOL_RUN;][COHORT_FP;][LOW_SCORE] (docs/howto-callset-filter.md:61-65)."""
-    out = np.empty(res.filter.size, object)
-    for i in range(res.filter.size):
-        tags = []
-        if res.flags[i] & S.FLAG_HPOL_RUN:
-            tags.append("HPOL_RUN")
-        if res.flags[i] & S.FLAG_COHORT_FP:
-            tags.append("COHORT_FP")
-        if res.filter[i] != S.FILTER_PASS:
-            tags.append("LOW_SCORE")
-        out[i] = ";".join(tags) if tags else "PASS"
-    return out
+    table = np.empty(8, object)
+    for code in range(8):
+        tags = [t for bit, t in ((S.FLAG_HPOL_RUN, "HPOL_RUN"), (S.FLAG_COHORT_FP, "COHORT_FP"), (4, "LOW_SCORE")) if code & bit]
+        table[code] = ";".join(tags) if tags else "PASS"
+    code = (res.flags & np.uint8(S.FLAG_HPOL_RUN | S.FLAG_COHORT_FP)).astype(np.int64) | ((res.filter != S.FILTER_PASS).astype(np.int64) << 2)
+    return table[code]
 
 
 def table_to_frame(vt: S.VariantTable, contig_names, label=None, res: S.FilterResult | None = None) -> h5.Frame:
