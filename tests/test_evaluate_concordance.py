@@ -177,3 +177,19 @@ def test_frame_table_round_trip(tmp_path):
     for i in range(vt.n):
         assert ("LOW_SCORE" in flt[i]) == bool(res.filter[i]) and ("HPOL_RUN" in flt[i]) == bool(res.flags[i] & 1)
         assert (flt[i] == "PASS") == (res.filter[i] == 0 and res.flags[i] & 3 == 0)
+
+
+def test_documented_example_table():
+    """docs/evaluate_concordance.md:45-56 prints an `optimal_recall_precision` table (tp, fp, fn -> precision, recall, f1);
+    precision / recall are shown there with 3 to 5 digits, f1 with 5."""
+    from variantcalling_amd import evaluate
+    doc = [("SNP", 747, 3, 6, 0.996, 0.992, 0.99401), ("Non-hmer INDEL", 36, 3, 3, 0.92308, 0.92308, 0.92308),
+           ("HMER indel <= 4", 14, 1, 1, 0.93333, 0.93333, 0.93333), ("HMER indel (4,8)", 5, 0, 0, 1, 1, 1),
+           ("HMER indel [8,10]", 9, 0, 0, 1, 1, 1), ("HMER indel 11,12", 7, 0, 3, 1, 0.7, 0.82353),
+           ("HMER indel > 12", 0, 2, 13, 0, 0, 0), ("INDELS", 71, 6, 20, 0.92208, 0.78022, 0.84524)]
+    # counts as accuracy_rows takes them: (true, false, true & passing, false & passing, missed) with nothing filtered
+    counts = [(tp, fp, tp, fp, fn) for _, tp, fp, fn, *_ in doc] + [(0, 0, 0, 0, 0)]
+    rows = evaluate.accuracy_rows(counts)
+    for row, (name, tp, fp, fn, p, r, f1) in zip(rows, doc):
+        assert (row["group"], row["tp"], row["fp"], row["fn"]) == (name, tp, fp, fn)
+        assert abs(row["precision"] - p) < 5e-4 and abs(row["recall"] - r) < 5e-4 and abs(row["f1"] - f1) < 1e-5, name
