@@ -313,3 +313,22 @@ def test_pandas_reads_what_we_write(tmp_path):
         if fr.index is None:                                          # pandas shows the stored 0..n-1 index
             fr = h5.Frame(fr, index=np.arange(fr.n_rows), index_names=[None])
         _check_against_json(fr, exp, k)
+
+
+def test_frame_pandas_bridge(tmp_path):
+    """Frame <-> pandas objects in this interpreter (pandas without PyTables): what a caller holding DataFrames uses."""
+    import pandas as pd
+    df = pd.DataFrame({"a": [1, 2, 3], "b": ["x", None, "z"], "t": [(1, 2), None, (3,)], "f": [0.5, np.nan, 2.0]},
+                      index=pd.MultiIndex.from_arrays([["c1", "c1", "c2"], [5, 6, 7]], names=["chrom", "pos"]))
+    ser = pd.Series([1.5, 2.5], index=["u", "v"], name="callable")
+    path = str(tmp_path / "b.h5")
+    h5.write_hdf(path, {"df": h5.Frame.from_pandas(df), "ser": h5.Frame.from_pandas(ser), "plain": h5.Frame.from_pandas(df.reset_index(drop=True))})
+    back = h5.read_hdf(path, "df").to_pandas()
+    assert list(back.columns) == list(df.columns) and back.index.names == ["chrom", "pos"]
+    assert back["a"].tolist() == [1, 2, 3] and back["b"].tolist() == ["x", None, "z"] and back["t"].tolist() == [(1, 2), None, (3,)]
+    assert np.array_equal(back["f"].to_numpy(), df["f"].to_numpy(), equal_nan=True)
+    assert back.index.tolist() == df.index.tolist()
+    s2 = h5.read_hdf(path, "ser").to_pandas()
+    assert isinstance(s2, pd.Series) and s2.name == "callable" and s2.tolist() == [1.5, 2.5] and s2.index.tolist() == ["u", "v"]
+    plain = h5.read_hdf(path, "plain").to_pandas()
+    assert plain.index.tolist() == [0, 1, 2]
