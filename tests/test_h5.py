@@ -332,3 +332,43 @@ def test_frame_pandas_bridge(tmp_path):
     assert isinstance(s2, pd.Series) and s2.name == "callable" and s2.tolist() == [1.5, 2.5] and s2.index.tolist() == ["u", "v"]
     plain = h5.read_hdf(path, "plain").to_pandas()
     assert plain.index.tolist() == [0, 1, 2]
+
+
+class _Evil:
+    def __init__(self, marker):
+        self.marker = marker
+
+    def __reduce__(self):
+        return (os.system, (f"echo run > {self.marker}",))
+
+
+def test_object_blocks_are_data_not_code(tmp_path):
+    """An object block is a pickle.  Ours is loaded with data constructors only: a file that names any other callable
+    is refused (pandas / PyTables would run it), and a damaged array state raises instead of crashing numpy."""
+    marker = str(tmp_path / "marker")
+    col = np.empty(2, object)
+    col[0], col[1] = "fine", _Evil(marker)
+    path = str(tmp_path / "evil.h5")
+    h5.write_hdf(path, {"k": h5.Frame([("x", col)])})
+    with pytest.raises(h5.H5Error, match="is not allowed in an HDF5 object block"):
+        h5.read_hdf(path, "k")
+    assert not os.path.exists(marker)
+    # the usual inhabitants of object columns pass
+    import datetime
+    import decimal
+    ok = np.empty(8, object)
+    ok[:] = ["s", None, float("nan"), (1, "a", (2.5, None)), np.int64(4), np.float32(1.5), datetime.date(2024, 1, 2), decimal.Decimal("1.25")]
+    h5.write_hdf(path, {"k": h5.Frame([("x", ok)])})
+    got = h5.read_hdf(path, "k")["x"]
+    assert got[0] == "s" and got[1] is None and got[2] != got[2] and got[3] == (1, "a", (2.5, None)) and got[4] == 4
+    assert got[5] == np.float32(1.5) and got[6] == datetime.date(2024, 1, 2) and got[7] == decimal.Decimal("1.25")
+    # an object list shorter than the array shape (what a dropped span of the file produces)
+    import pickle
+    arr = np.empty((3, 1), object)
+    arr[:, 0] = ["a", "b", "c"]
+    raw = pickle.dumps(arr, protocol=2)
+    bad = raw.replace(b"K\x03K\x01", b"K\x09K\x01", 1)                 # shape (3, 1) -> (9, 1), same three objects
+    assert bad != raw
+    with pytest.raises(pickle.UnpicklingError, match="does not match its shape"):
+        h5._loads(bad)
+    assert h5._loads(raw).tolist() == [["a"], ["b"], ["c"]] and type(h5._loads(raw)) is np.ndarray

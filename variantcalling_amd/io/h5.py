@@ -638,6 +638,79 @@ class Frame(OrderedDict):
         return pd.DataFrame({k: v for k, v in self.items()}, index=idx, columns=list(self.keys()))
 
 
+# ---- unpickling what PyTables / pandas pickled: only data constructors, and array states that add up -------------
+class _CheckedArray(np.ndarray):
+    """ndarray whose pickle state is validated before numpy installs it: a damaged object block must raise, not read
+    past the end of a too-short object list (which numpy does not check for object dtypes)."""
+
+    def __setstate__(self, state):
+        try:
+            _, shape, dtype, _, raw = state
+            n = 1
+            for d in shape:
+                n *= int(d)
+            ok = (isinstance(raw, list) and len(raw) == n) if dtype.hasobject else \
+                (isinstance(raw, (bytes, bytearray)) and len(raw) == n * dtype.itemsize)
+        except Exception:
+            ok = False
+        if not ok:
+            raise pickle.UnpicklingError("ndarray state does not match its shape (damaged object block)")
+        super().__setstate__(state)
+
+
+def _checked_reconstruct(subtype, shape, typecode):
+    return np.ndarray.__new__(_CheckedArray, shape, typecode)
+
+
+try:
+    from numpy._core.multiarray import scalar as _np_scalar
+except ImportError:                                               # numpy 1.x
+    from numpy.core.multiarray import scalar as _np_scalar
+
+_SAFE_GLOBALS = {
+    ("numpy", "ndarray"): np.ndarray, ("numpy", "dtype"): np.dtype,
+    ("builtins", "tuple"): tuple, ("builtins", "list"): list, ("builtins", "dict"): dict, ("builtins", "set"): set,
+    ("builtins", "frozenset"): frozenset, ("builtins", "complex"): complex, ("builtins", "bytearray"): bytearray,
+    ("builtins", "slice"): slice, ("builtins", "range"): range, ("__builtin__", "tuple"): tuple, ("__builtin__", "list"): list,
+    ("__builtin__", "dict"): dict, ("__builtin__", "set"): set, ("__builtin__", "frozenset"): frozenset,
+    ("__builtin__", "complex"): complex, ("__builtin__", "unicode"): str, ("__builtin__", "long"): int,
+    ("collections", "OrderedDict"): OrderedDict, ("_codecs", "encode"): __import__("_codecs").encode,
+}
+for _m in ("numpy.core.multiarray", "numpy._core.multiarray"):
+    _SAFE_GLOBALS[(_m, "_reconstruct")] = _checked_reconstruct
+    _SAFE_GLOBALS[(_m, "scalar")] = _np_scalar
+for _n in ("datetime", "date", "time", "timedelta", "timezone"):
+    _SAFE_GLOBALS[("datetime", _n)] = getattr(__import__("datetime"), _n)
+_SAFE_GLOBALS[("decimal", "Decimal")] = __import__("decimal").Decimal
+
+
+class _DataUnpickler(pickle.Unpickler):
+    """Unpickler for object blocks / PyTables attributes: data constructors only.  Reading a table must not run
+    whatever callable a file names - pandas itself offers no such guard."""
+
+    def find_class(self, module, name):
+        obj = _SAFE_GLOBALS.get((module, name))
+        if obj is None:
+            raise pickle.UnpicklingError(f"global {module}.{name} is not allowed in an HDF5 object block")
+        return obj
+
+
+def _loads(raw: bytes):
+    import io
+    out = _DataUnpickler(io.BytesIO(raw)).load()
+
+    def plain(x):
+        if isinstance(x, _CheckedArray):
+            x = x.view(np.ndarray)
+            if x.dtype == object:
+                flat = x.reshape(-1)
+                for i, y in enumerate(flat):
+                    if isinstance(y, _CheckedArray):
+                        flat[i] = plain(y)
+        return x
+    return plain(out)
+
+
 def _unpickle_attr(v):
     """PyTables keeps non-string Python attribute values as pickles inside string attributes."""
     if isinstance(v, str):
@@ -648,7 +721,7 @@ def _unpickle_attr(v):
         return v
     if raw.endswith(b"."):
         try:
-            return pickle.loads(raw)
+            return _loads(raw)
         except Exception:
             return v
     return v
@@ -664,7 +737,12 @@ def _read_array(group, key):
         if rows.size == 0:
             ret = np.empty(0, object)
         else:
-            ret = pickle.loads(rows.reshape(-1)[0].tobytes())
+            try:
+                ret = _loads(rows.reshape(-1)[0].tobytes())
+            except H5Error:
+                raise
+            except Exception as e:                                 # damaged or hostile pickle
+                raise H5Error(f"{ds.name}: object block cannot be unpickled ({type(e).__name__}: {e})")
     else:
         ret = ds.read()
         shape = _unpickle_attr(at.get("shape"))
