@@ -214,3 +214,115 @@ def write_vcf_from_table(path: str, vt: S.VariantTable, contig_names: list, samp
                               f"{gt}:{int(vt.ad_ref[i])},{int(vt.ad_alt[i])}:{int(vt.dp[i])}:{int(vt.gq[i])}"])
                    + "\n").encode())
     out.close()
+
+
+# ---------------------------------------------------------------------------------------------------- tabix index
+def _reg2bin(beg: int, end: int) -> int:
+    end -= 1
+    for shift, first in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+        if beg >> shift == end >> shift:
+            return first + (beg >> shift)
+    return 0
+
+
+def tabix_index(path: str) -> bool:
+    """`pysam.tabix_index(path, preset="vcf")` for a BGZF VCF that already exists
+    (/root/reference/ugvc/pipelines/vcfbed/calibrate_bridging_snvs.py:130): writes `path`.tbi (binning index + 16 kb linear
+    index over the BGZF virtual offsets, INFO/END honoured).  Returns False, writing nothing, when the records are not
+    grouped by contig and sorted by position (tabix refuses such files too).  The pure-Python statement of the native
+    codec's index writer (csrc_host/vcf_codec.cpp:write_tbi); tests demand byte-equal indices."""
+    raw = open(path, "rb").read()
+    # block table: compressed offset and uncompressed start of every BGZF member
+    blocks, text, off = [], [], 0
+    while off < len(raw):
+        if raw[off:off + 4] != b"\x1f\x8b\x08\x04" or raw[off + 12:off + 14] != b"BC":
+            raise ValueError(f"{path}: not a BGZF file (member at byte {off})")
+        bsize = int.from_bytes(raw[off + 16:off + 18], "little") + 1
+        data = zlib.decompress(raw[off + 18:off + bsize - 8], -15)
+        blocks.append((off, sum(len(t) for t in text) if not text else blocks[-1][1] + len(text[-1])))
+        text.append(data)
+        off += bsize
+    body = b"".join(text)
+    # virtual offset of uncompressed byte u: the non-empty member holding it; the end of the data is the end of the last
+    # member (its length as the in-block offset), as bgzf_tell reports it before the next member is loaded
+    import bisect
+    live = [(coff, ust) for (coff, ust), t in zip(blocks, text) if t]
+    ustart = [ust for _, ust in live]
+
+    def voff(u: int) -> int:
+        k = max(bisect.bisect_right(ustart, u) - 1, 0)
+        return (live[k][0] << 16) | (u - live[k][1])
+
+    refs, names, seen = [], [], set()
+    cur, last_beg, u = None, -1, 0
+    n = len(body)
+    while u < n:
+        e = body.find(b"\n", u)
+        e = n if e < 0 else e + 1
+        line = body[u:e]
+        if line[:1] != b"#" and line.strip():
+            f = line.rstrip(b"\r\n").split(b"\t")
+            if len(f) < 8:
+                raise ValueError(f"{path}: a record has {len(f)} columns")
+            beg = int(f[1]) - 1
+            end = beg + len(f[3])
+            for kv in f[7].split(b";"):
+                if kv.startswith(b"END="):
+                    digits = kv[4:]
+                    k = 0
+                    while k < len(digits) and 48 <= digits[k] <= 57:
+                        k += 1
+                    if k and int(digits[:k]) > beg:
+                        end = int(digits[:k])
+                    break
+            if beg < 0:
+                return False
+            if f[0] != cur:
+                if f[0] in seen:
+                    return False
+                seen.add(f[0])
+                names.append(f[0])
+                refs.append(([], []))
+                cur, last_beg = f[0], -1
+            if beg < last_beg:
+                return False
+            last_beg = beg
+            chunks, lin = refs[-1]
+            stop = end if end > beg else beg + 1
+            v0, v1 = voff(u), voff(e)
+            b = _reg2bin(beg, stop)
+            if chunks and chunks[-1][0] == b:
+                chunks[-1][2] = v1
+            else:
+                chunks.append([b, v0, v1])
+            w0, w1 = beg >> 14, (stop - 1) >> 14
+            if len(lin) <= w1:
+                lin.extend([None] * (w1 + 1 - len(lin)))
+            for w in range(w0, w1 + 1):
+                if lin[w] is None:
+                    lin[w] = v0
+        u = e
+    out = bytearray(b"TBI\x01")
+    out += struct.pack("<7i", len(refs), 2, 1, 2, 0, ord("#"), 0)
+    nm = b"".join(x + b"\0" for x in names)
+    out += struct.pack("<i", len(nm)) + nm
+    for chunks, lin in refs:
+        bins = {}
+        for b, v0, v1 in chunks:
+            bins.setdefault(b, []).append((v0, v1))
+        out += struct.pack("<i", len(bins))
+        for b in sorted(bins):
+            out += struct.pack("<Ii", b, len(bins[b]))
+            for v0, v1 in bins[b]:
+                out += struct.pack("<QQ", v0, v1)
+        if lin and lin[0] is None:
+            lin[0] = 0
+        for w in range(1, len(lin)):
+            if lin[w] is None:
+                lin[w] = lin[w - 1]
+        out += struct.pack("<i", len(lin)) + struct.pack(f"<{len(lin)}Q", *lin)
+    out += struct.pack("<Q", 0)
+    w = _BgzfWriter(path + ".tbi")
+    w.write(bytes(out))
+    w.close()
+    return True
