@@ -82,7 +82,8 @@ def test_train_then_filter(tmp_path):
     assert rc == 0
     models = pickle.load(open(prefix + ".pkl", "rb"))
     assert set(models) == {"rf_model_ignore_gt_incl_hpol_runs", "dt_model_ignore_gt_incl_hpol_runs",
-                           "rf_model_ignore_gt_excl_hpol_runs", "dt_model_ignore_gt_excl_hpol_runs"}
+                           "rf_model_ignore_gt_excl_hpol_runs", "dt_model_ignore_gt_excl_hpol_runs",
+                           "threshold_model_ignore_gt_incl_hpol_runs", "threshold_model_ignore_gt_excl_hpol_runs"}
     rows = [x.split(";") for x in open(prefix + ".stats.csv").read().splitlines()]
     assert rows[0][0] == "group" and rows[1][0] == "SNP" and float(rows[1][6]) > 0.7      # SNP f1 after filtering
     from variantcalling_amd.io import h5
@@ -108,16 +109,20 @@ def test_train_then_filter(tmp_path):
     assert np.array_equal(res2["label"], res["label"]) and np.array_equal(res2["pos"], res["pos"])
     for f in feat:
         assert np.array_equal(res2[f], res[f]), f
-    for name in ("dt_model_ignore_gt_excl_hpol_runs", "rf_model_ignore_gt_incl_hpol_runs"):
+    for name in ("dt_model_ignore_gt_excl_hpol_runs", "rf_model_ignore_gt_incl_hpol_runs", "threshold_model_ignore_gt_incl_hpol_runs"):
         out = str(tmp_path / f"{name}.vcf")
         filter_variants_pipeline.run(["filter_variants_pipeline", "--input_file", d["vcf"], "--model_file", prefix + ".pkl",
                                       "--model_name", name, "--runs_file", d["runs"], "--blacklist", d["bl"],
                                       "--reference_file", d["fa"], "--output_file", out] + d["ann"])
-        forests = [model_io.flatten_sklearn(models[name][g]) if g in models[name] else None for g in S.GROUP_NAMES]
+        forests = [(models[name][g] if isinstance(models[name][g], S.FlatForest) else model_io.flatten_sklearn(models[name][g]))
+                   if g in models[name] else None for g in S.GROUP_NAMES]
         exp = O.filter_variants(cs.variants, cs.ref, cs.runs, cs.tracks, bl, forests)
         score, tags = _parse_out(out, cs.variants.n)
         assert np.array_equal(score, exp.tree_score)
         assert np.array_equal(np.array(["LOW_SCORE" in t for t in tags]), exp.filter == 1)
-        # and against scikit-learn itself
         g0 = ft["group"] == 0
+        if name.startswith("threshold"):                       # the two-feature model: labels were drawn from QUAL, so it must separate
+            assert ((exp.tree_score[g0] > 0.5) == is_tp[g0]).mean() > 0.75
+            continue
+        # and against scikit-learn itself
         assert np.array_equal(exp.tree_score[g0], models[name]["snp"].predict_proba(ft["X"][g0])[:, 1].astype(np.float32))

@@ -232,3 +232,40 @@ def test_pipelines_help_and_fail_loudly_without_gpu(tmp_path, capsys, cs):
         filter_variants_pipeline.run(base + ann)
     with pytest.raises(RuntimeError):
         train_models_pipeline.run(["x", "--input_file", vc, "--reference", fa, "--output_file_prefix", str(tmp_path / "m")])
+
+
+def test_threshold_model_is_monotone_and_scores_like_its_cells():
+    """model_io.make_threshold_model (the documented two-feature "simple model"): evaluated by the oracle's tree walker it
+    returns the monotone closure of the per-cell true-call fractions; never falls with QUAL, never rises with SOR."""
+    from oracle import oracle as O
+    from variantcalling_amd import model_io
+    rng = np.random.default_rng(8)
+    n = 30_000
+    qual = (rng.random(n) * 60).astype(np.float32)
+    sor = (rng.random(n) * 4).astype(np.float32)
+    y = (qual / 60 - sor / 8 + rng.normal(0, 0.2, n)) > 0.25
+    w = rng.integers(1, 4, n).astype(np.float64)
+    F = 20
+    f = model_io.make_threshold_model(qual, sor, y, w, i_a=0, i_b=1, n_features=F, k=16)
+    assert f.kind == S.MODEL_RF and f.n_trees == 1 and f.max_depth == 8 and f.leaf_value.shape == (256, 2)
+    assert np.allclose(f.leaf_value.sum(axis=1), 1.0)
+    X = np.zeros((4000, F), np.float32)
+    X[:, 0], X[:, 1] = qual[:4000], sor[:4000]
+    score = O.forest_predict(f, X)[1]
+    assert ((score > 0.5) == y[:4000]).mean() > 0.8
+    # recompute the cells independently
+    ca = np.unique(np.quantile(qual, np.linspace(0, 1, 17)[1:-1], method="inverted_cdf")).astype(np.float32)
+    cb = np.unique(np.quantile(sor, np.linspace(0, 1, 17)[1:-1], method="inverted_cdf")).astype(np.float32)
+    ia, ib = np.searchsorted(ca, qual, side="left"), np.searchsorted(cb, sor, side="left")
+    tp, tot = np.zeros((16, 16)), np.zeros((16, 16))
+    np.add.at(tp, (ia, ib), w * y)
+    np.add.at(tot, (ia, ib), w)
+    cell = (tp + 1) / (tot + 2)
+    closed = np.array([[cell[:i + 1, j:].max() for j in range(16)] for i in range(16)])
+    assert np.allclose(score, closed[ia[:4000], ib[:4000]])
+    for fixed in (0.5, 2.0, 3.5):
+        g = np.zeros((200, F), np.float32)
+        g[:, 0], g[:, 1] = np.linspace(0, 60, 200), fixed
+        assert np.all(np.diff(O.forest_predict(f, g)[1]) >= 0)
+        g[:, 0], g[:, 1] = 30.0, np.linspace(0, 4, 200)
+        assert np.all(np.diff(O.forest_predict(f, g)[1]) <= 0)

@@ -138,6 +138,57 @@ def make_gbt(trees: list, n_features: int, base_margin: float = 0.0) -> S.FlatFo
     return flatten_xgb_json(doc)
 
 
+def make_threshold_model(a, b, label, weight=None, i_a: int = 0, i_b: int = 1, n_features: int = 2, k: int = 16) -> S.FlatForest:
+    """The "simple model" of docs/howto-callset-filter.md:129 (`threshold_model_*`, :139): a confidence score from two
+    features - QUAL (10 * max TLOD under --is_mutect) and SOR.  BUILDER-DEFINED (the reference's class lives in the
+    absent submodule): up to k bins per feature at quantiles of the labelled calls; a cell's score is its smoothed
+    true-call fraction (tp + 1) / (n + 2), closed monotonically (the maximum over the cells that are no better on either
+    axis), so the score never falls with QUAL nor rises with SOR; a call passes when its score exceeds one half.  Returned as a single-tree forest (search over the QUAL cuts, then over the
+    SOR cuts), so it runs on the same kernels as the forests and pickles as plain arrays."""
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    y = np.asarray(label).astype(bool)
+    w = np.ones(a.size) if weight is None else np.asarray(weight, np.float64)
+
+    def cuts(x):
+        q = np.unique(np.quantile(x, np.linspace(0, 1, k + 1)[1:-1], method="inverted_cdf")) if x.size else np.zeros(0)
+        return q.astype(np.float32)
+    ca, cb = cuts(a), cuts(b)                                      # bin i of x: number of cuts < x  (x <= cut goes left)
+    ia, ib = np.searchsorted(ca, a, side="left"), np.searchsorted(cb, b, side="left")
+    na, nb = ca.size + 1, cb.size + 1
+    tp = np.zeros((na, nb))
+    tot = np.zeros((na, nb))
+    np.add.at(tp, (ia, ib), w * y)
+    np.add.at(tot, (ia, ib), w)
+    # smoothed true-call fraction of every cell, then its monotone closure: a call scores at least what any cell that is
+    # no better on either axis (lower or equal QUAL bin, higher or equal SOR bin) scores
+    score = (tp + 1.0) / (tot + 2.0)
+    score = np.maximum.accumulate(score, axis=0)
+    score = np.maximum.accumulate(score[:, ::-1], axis=1)[:, ::-1]
+    feature, threshold, left, right, leaves = [], [], [], [], []
+
+    def leaf(i, j):
+        feature.append(-1); threshold.append(0.0); left.append(len(leaves)); right.append(0)
+        leaves.append((1.0 - score[i, j], score[i, j]))
+        return len(feature) - 1
+
+    def search(lo, hi, cut, feat, on_bin):
+        """bins lo..hi (inclusive) of one axis -> node index; `on_bin(i)` builds what hangs under bin i."""
+        if lo == hi:
+            return on_bin(lo)
+        mid = (lo + hi) // 2                                       # x <= cut[mid]  <=>  bin <= mid
+        me = len(feature)
+        feature.append(feat); threshold.append(float(cut[mid])); left.append(-1); right.append(-1)
+        left[me] = search(lo, mid, cut, feat, on_bin)
+        right[me] = search(mid + 1, hi, cut, feat, on_bin)
+        return me
+
+    root = search(0, na - 1, ca, i_a, lambda i: search(0, nb - 1, cb, i_b, lambda j: leaf(i, j)))
+    depth = int(np.ceil(np.log2(max(na, 1)))) + int(np.ceil(np.log2(max(nb, 1))))
+    return S.FlatForest(S.MODEL_RF, np.array(feature, np.int32), np.array(threshold, np.float32), np.array(left, np.int32),
+                        np.array(right, np.int32), np.array([root], np.int32), np.array(leaves, np.float64).reshape(-1, 2),
+                        n_features=n_features, max_depth=depth)
+
+
 # ---------------------------------------------------------------- persistence of flat models
 def save_models(path: str, models: dict, meta: dict | None = None) -> None:
     """{name: [FlatForest per group]} -> one .npz (the frozen synthetic model of SURVEY.md §8(d))."""

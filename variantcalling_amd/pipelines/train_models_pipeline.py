@@ -86,7 +86,8 @@ def fit_models(X, group, label, weights, hpol_flag):
     for incl in (True, False):
         use = (label >= 0) & (incl | ~hpol_flag)
         suffix = "ignore_gt_" + ("incl" if incl else "excl") + "_hpol_runs"
-        rf, dt = {}, {}
+        rf, dt, thr = {}, {}, {}
+        i_qual, i_sor = S.BASE_FEATURES.index("qual"), S.BASE_FEATURES.index("sor")
         for g, gname in enumerate(S.GROUP_NAMES):
             m = use & (group == g)
             if m.sum() < 2 or np.unique(label[m]).size < 2:
@@ -95,13 +96,17 @@ def fit_models(X, group, label, weights, hpol_flag):
             rf[gname] = RandomForestClassifier(n_estimators=N_TREES, max_depth=MAX_DEPTH, random_state=g, n_jobs=-1).fit(
                 X[m], label[m], sample_weight=weights[m])
             dt[gname] = DecisionTreeClassifier(max_depth=MAX_DEPTH, random_state=g).fit(X[m], label[m], sample_weight=weights[m])
+            # the two-feature "simple model" (docs/howto-callset-filter.md:129,139): QUAL (= 10 * TLOD with --mutect) and SOR
+            thr[gname] = model_io.make_threshold_model(X[m, i_qual], X[m, i_sor], label[m], weights[m], i_qual, i_sor, X.shape[1])
         models["rf_model_" + suffix] = rf
         models["dt_model_" + suffix] = dt
+        models["threshold_model_" + suffix] = thr
     return models
 
 
 def _flatten(model: dict):
-    return [model_io.flatten_sklearn(model[g]) if g in model else None for g in S.GROUP_NAMES]
+    return [(model[g] if isinstance(model[g], S.FlatForest) else model_io.flatten_sklearn(model[g])) if g in model else None
+            for g in S.GROUP_NAMES]
 
 
 def run(argv: list[str]):
