@@ -7,7 +7,7 @@ import logging
 import numpy as np
 
 from .. import schema as S
-from ..io import bed, fasta
+from ..io import bed
 
 logger = logging.getLogger("ugvc")
 
