@@ -492,3 +492,51 @@ def test_corrupted_inputs_never_crash(tmp_path, seed):
     assert r.returncode == 0, f"worker died with {r.returncode}:\n{r.stderr[-1500:]}"
     m = re.search(r"done ok=(\d+) err=(\d+)", r.stdout)
     assert m and int(m.group(1)) + int(m.group(2)) >= 240 and int(m.group(2)) > 20 and int(m.group(1)) > 20, r.stdout[-300:]
+
+
+REF_TREE = "/root/reference/test/resources"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_TREE), reason="reference tree not present")
+def test_real_fixtures_of_the_reference_tree(tmp_path):
+    """The two real host-format files the reference tree carries for this path: a bgzipped FASTA with its .fai
+    (unit/filtering/test_spandel/ref_fragment.fa.gz) and a production VCF header of 3 402 lines, 3 366 of them contigs
+    (unit/vcfbed/test_vcftools/header.txt - the field dictionary SURVEY.md 8(c) names)."""
+    fa = f"{REF_TREE}/unit/filtering/test_spandel/ref_fragment.fa.gz"
+    name, length, *_ = open(fa + ".fai").read().split("\t")
+    ref = nv.read_fasta(fa)
+    assert ref.names == [name] and ref.contig_len(0) == int(length) == 660000
+    seq = b"".join(gzip.open(fa, "rb").read().split(b"\n")[1:])
+    assert np.array_equal(ref.codes, S._ASCII_TO_CODE[np.frombuffer(seq, np.uint8)]) and int((ref.codes == 0).sum()) == 150000     # a 150 kb N run
+    from variantcalling_amd.io import fasta as pfa
+    pref = pfa.read_fasta(fa)
+    assert pref.names == ref.names and np.array_equal(pref.codes, ref.codes)
+
+    hdr = open(f"{REF_TREE}/unit/vcfbed/test_vcftools/header.txt").read().rstrip("\n").split("\n")
+    contigs = [h.split("ID=")[1].split(",")[0] for h in hdr if h.startswith("##contig")]
+    assert len(hdr) == 3402 and len(contigs) == 3366 and hdr[-1].startswith("#CHROM") and contigs[0] == "chr1"
+    names = contigs[:200]                                          # the contig column is u8
+    rng = np.random.default_rng(2)
+    cidx = np.sort(rng.integers(0, 200, 500))                      # records grouped by contig, positions rising
+    body = []
+    for k, c in enumerate(names[i] for i in cidx):
+        body.append(f"{c}\t{1000 + 7 * k}\t.\tA\tG\t{30 + k % 9}.5\tRefCall\tSOR=1.25;X_CSS=non-skip;VARIANT_TYPE=SNP\tGT:AD:DP:GQ:PL:VAF\t"
+                    f"0/1:10,{k % 13}:{10 + k % 13}:{k % 60}:30,0,40:0.5")
+    src = str(tmp_path / "real_header.vcf.gz")
+    w = pv._BgzfWriter(src)
+    w.write(("\n".join(hdr + body) + "\n").encode())
+    w.close()
+    a, b = nv.read_vcf(src, names), pv.read_vcf(src, names)
+    _same_file(a, b)
+    assert a.header == hdr and a.table.n == 500 and a.table.gq.max() == 59 and set(a.orig_filter) == {"RefCall"}
+    res = S.FilterResult((np.arange(500) / 500).astype(np.float32), (np.arange(500) % 2).astype(np.uint8), (np.arange(500) % 4).astype(np.uint8))
+    out_n, out_p = str(tmp_path / "n.vcf.gz"), str(tmp_path / "p.vcf.gz")
+    assert nv.write_filtered_vcf(out_n, a, res) is True
+    pv.write_filtered_vcf(out_p, b, res)
+    assert open(out_n, "rb").read() == open(out_p, "rb").read()
+    text = gzip.open(out_n, "rb").read().decode().split("\n")
+    new = [x for x in text if x.startswith("##") and x not in hdr]
+    assert len(new) == 5 and text[len(hdr) + 5 - 1].startswith("#CHROM")     # the five tags join the 3 401 meta lines
+    native_index = open(out_n + ".tbi", "rb").read()
+    os.remove(out_n + ".tbi")
+    assert pv.tabix_index(out_n) and open(out_n + ".tbi", "rb").read() == native_index
