@@ -330,8 +330,16 @@ class Engine:
         return out, ms.value
 
     # ---- pileup
+    @staticmethod
+    def _check_csr(off, ob):
+        if off.ndim != 1 or off.size < 1 or ob.ndim != 1:
+            raise ValueError("offsets must be a 1-D array of n_loci + 1 entries, obs 1-D")
+        if off[0] != 0 or off[-1] != ob.size or (off.size > 1 and np.any(np.diff(off) < 0)):
+            raise ValueError("offsets must rise from 0 to len(obs)")
+
     def pileup_tally(self, offsets: np.ndarray, obs: np.ndarray) -> dict:
         off, ob = _col(offsets, np.int64), _col(obs, np.uint16)
+        self._check_csr(off, ob)
         n = off.size - 1
         out = {k: np.zeros(n, np.int32) for k in ("ref_fwd", "ref_rev", "alt_fwd", "alt_rev", "other", "dp",
                                                   "bq_ref", "bq_alt")}
@@ -347,6 +355,7 @@ class Engine:
 
     def upload_pileup(self, offsets, obs):
         off, ob = _col(offsets, np.int64), _col(obs, np.uint16)
+        self._check_csr(off, ob)
         self._check(self.lib.ugvc_pileup_upload(self._h, _p(off, _i64p), _p(ob, _u16p), off.size - 1))
 
     def timed_pileup(self, iters: int) -> float:
@@ -401,6 +410,9 @@ class Engine:
         cv = self._cvariants(vt)
         ip, a, b, d = (_col(is_pass, np.uint8), _col(ad_alt_sum, np.int32), _col(bg_ad_alt_sum, np.int32),
                        _col(bg_dp, np.int32))
+        for name, x in (("is_pass", ip), ("ad_alt_sum", a), ("bg_ad_alt_sum", b), ("bg_dp", d)):
+            if x.shape != (vt.n,):                         # the C ABI takes bare pointers: sizes are checked here
+                raise ValueError(f"{name} must have one entry per variant ({vt.n}), got shape {x.shape}")
         prm = CBridgingParams(min_initial_qual, min_tumor_vaf, max_normal_vaf, min_query_hmer_size,
                               min_normal_depth, min_distance_from_edge)
         oh, op = np.zeros(vt.n, np.uint8), np.zeros(vt.n, np.uint8)
