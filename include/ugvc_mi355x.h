@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define UGVC_ABI_VERSION 1
+#define UGVC_ABI_VERSION 2          /* 2: contig column u16 (a WGS reference has 3 366 contigs:
+                                     test/resources/unit/vcfbed/test_vcftools/header.txt) */
 #define UGVC_MAX_TRACKS 5
 #define UGVC_N_GROUPS 3          /* snp, h-indel, non-h-indel */
 #define UGVC_N_BASE_FEATURES 17  /* + one per annotation track; order: schema.BASE_FEATURES */
@@ -51,7 +52,7 @@ typedef struct ugvc_ctx ugvc_ctx;
  * shape ugvc/reports/report_wo_gt.ipynb:1207-1210). */
 typedef struct ugvc_variants {
     int64_t n;
-    const uint8_t* contig;    /* contig index into the uploaded reference                  */
+    const uint16_t* contig;   /* contig index into the uploaded reference (<= 65535 contigs) */
     const int32_t* pos;       /* 1-based                                                   */
     const uint16_t* ref_len;
     const uint16_t* alt_len;
@@ -165,10 +166,10 @@ int ugvc_host_css_lut(const char* flow4, uint8_t out[256]);
  *   bits 0-4 section ablation of the featurize kernel (results are WRONG): 1 no forest kernel, 2 no joins,
  *            4 no quantisation, 8 no window features, 16 no record append
  *   32   featurize kernel without the one-tile-ahead column prefetch     64   phase clocks on (ugvc_debug_phase_clocks)
- *   128  v4 featurize kernel (single-contig tiles, sentinel joins)       256  v1 universal fused kernel
- *   512  v2 kernels                                                      1024 pair-sum forest kernel
- *   2048 16 trees in flight in the forest kernel
- *   bits 12-13 featurize workgroups per CU (1..3; 0 = 4)                 bits 14-15 forest waves (1: 12, 2: 8, 3: 4; 0 = 16) */
+ *   256  v1 universal fused kernel                                       1024 pair-sum forest kernel (v3)
+ *   2048 16 trees in flight in the forest kernel (v3)                    65536 v3 kernels instead of v5
+ *   bits 12-13 v3 featurize workgroups per CU (1..3; 0 = 4)              bits 14-15 v3 forest waves (1: 12, 2: 8, 3: 4; 0 = 16)
+ *   v5 profiling (results WRONG / partial): 131072 no SNP walk, 262144 no indel pass, 524288 no joins */
 int ugvc_set_kernel_variant(ugvc_ctx* ctx, int variant);
 /* Profiling aid: core-clock cycles wave 0 of every featurize workgroup spent between the kernel's phase
  * boundaries (kernel variant bit 6 turns the clocks on), summed over workgroups and launches since the

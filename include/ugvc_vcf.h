@@ -34,7 +34,7 @@ typedef struct ugvc_vcf_view {
     int64_t n;                 /* records == table rows                                               */
     int64_t pool_bytes;        /* length of `alleles`                                                  */
     /* ugvc_variants columns, rows sorted by (contig, pos) */
-    const uint8_t* contig;
+    const uint16_t* contig;
     const int32_t* pos;
     const uint16_t* ref_len;
     const uint16_t* alt_len;

@@ -14,7 +14,7 @@ def table_from_records(recs):
         ao.append(len(pool)); pool.extend(S.encode_bases(r[3]).tolist())
     col = lambda k, dt: np.array([r[k] for r in recs], dtype=dt)
     vt = S.VariantTable(
-        contig=col(0, np.uint8), pos=col(1, np.int32),
+        contig=col(0, np.uint16), pos=col(1, np.int32),
         ref_len=np.array([len(r[2]) for r in recs], np.uint16), alt_len=np.array([len(r[3]) for r in recs], np.uint16),
         ref_off=np.array(ro, np.uint32), alt_off=np.array(ao, np.uint32), alleles=np.array(pool, np.uint8),
         qual=col(4, np.float32), sor=col(5, np.float32), dp=col(6, np.int32), ad_ref=col(7, np.int32),

@@ -51,7 +51,7 @@ def test_random_configurations(engine, frozen_models, seed):
         tracks = list(cs.tracks)                              # the frozen models test all three track features
     configure(engine, cs.ref, runs, tracks, bl, forests, flow, hp_len, hp_dist, True)
     exp = O.filter_variants(vt, cs.ref, runs, tracks, bl, forests, hpol_len=hp_len, hpol_dist=hp_dist, flow_order=flow)
-    for path in (0, 128, 512, 256):
+    for path in (0, 65536, 256):
         engine.set_kernel_variant(path)
         res = engine.filter_variants(vt)
         what = f"seed {seed} path {path}"
@@ -164,7 +164,7 @@ def test_random_models(engine, small_callset, seed):
             f.max_depth = max(model_io._depth(f.left, f.right, f.feature, int(r)) for r in f.tree_root)
     configure(engine, cs.ref, cs.runs, cs.tracks, cs.blacklist, forests, "TGCA", 10, 10, True)
     exp = O.filter_variants(cs.variants, cs.ref, cs.runs, cs.tracks, cs.blacklist, forests)
-    for path in (0, 128, 1024, 512, 256):
+    for path in (0, 65536, 65536 | 1024, 256):
         engine.set_kernel_variant(path)
         res = engine.filter_variants(cs.variants)
         what = f"seed {seed} path {path} kind {kind}"
@@ -194,7 +194,7 @@ def test_random_side_tables_and_clustered_variants(engine, small_callset, frozen
     clen = np.diff(ref.contig_off).astype(np.int64)
     n = int(rng.choice([300, 5_000, 30_000]))
     vt = copy.deepcopy(cs.variants.slice(0, n))
-    contig = np.sort(rng.integers(0, nc, n)).astype(np.uint8) if rng.random() < 0.8 else np.full(n, int(rng.integers(0, nc)), np.uint8)
+    contig = np.sort(rng.integers(0, nc, n)).astype(np.uint16) if rng.random() < 0.8 else np.full(n, int(rng.integers(0, nc)), np.uint16)
     pos = np.zeros(n, np.int64)
     for c in range(nc):
         m = contig == c
@@ -248,7 +248,7 @@ def test_random_side_tables_and_clustered_variants(engine, small_callset, frozen
         if tracks[j] is not dense:
             tracks[j] = overlapping(random_track("ov", 3e-4, merge=False))
     if rng.random() < 0.15:
-        runs = overlapping(random_track("ovruns", 2e-4, merge=False))   # overlapping runs: the v2 kernels take over
+        runs = overlapping(random_track("ovruns", 2e-4, merge=False))   # overlapping runs: the universal kernel takes over
     keys = vt.keys()
     bl_parts = [keys[:: int(rng.integers(1, 7))], keys[255::256], keys[::256] + np.uint64(1), keys[::97] - np.uint64(1),
                 (rng.integers(0, nc, 2000).astype(np.uint64) << np.uint64(32)) | rng.integers(1, int(clen.min()), 2000).astype(np.uint64)]
@@ -257,7 +257,7 @@ def test_random_side_tables_and_clustered_variants(engine, small_callset, frozen
     forests = frozen_models[RF]
     configure(engine, ref, runs, tracks, bl, forests, "TGCA", hp_len, hp_dist, True)
     exp = O.filter_variants(vt, ref, runs, tracks, bl, forests, hpol_len=hp_len, hpol_dist=hp_dist)
-    for path in (0, 128, 512, 256):
+    for path in (0, 65536, 256):
         engine.set_kernel_variant(path)
         res = engine.filter_variants(vt)
         what = f"seed {seed} path {path}"
@@ -328,7 +328,7 @@ def test_random_alleles_on_a_homopolymer_rich_reference(engine, frozen_models, s
         ao.append(len(pool)); pool += alta
     m = len(rows)
     vt = S.VariantTable(
-        contig=np.array([r[0] for r in rows], np.uint8), pos=np.array([r[1] for r in rows], np.int32),
+        contig=np.array([r[0] for r in rows], np.uint16), pos=np.array([r[1] for r in rows], np.int32),
         ref_len=np.array([len(r[2]) for r in rows], np.uint16), alt_len=np.array([len(r[3]) for r in rows], np.uint16),
         ref_off=np.array(ro, np.uint32), alt_off=np.array(ao, np.uint32), alleles=np.array(pool, np.uint8),
         qual=rng.exponential(60, m).astype(np.float32), sor=rng.lognormal(0, 0.7, m).astype(np.float32),
@@ -342,7 +342,7 @@ def test_random_alleles_on_a_homopolymer_rich_reference(engine, frozen_models, s
     configure(engine, ref, None, empty, None, forests, flow, 10, 10, True)
     exp = O.filter_variants(vt, ref, None, empty, None, forests, flow_order=flow)
     X_exp = None
-    for path in (0, 128, 512, 256):
+    for path in (0, 65536, 256):
         engine.set_kernel_variant(path)
         res = engine.filter_variants(vt)
         what = f"seed {seed} path {path}"

@@ -40,7 +40,9 @@ def test_library_is_loaded_in_tree(engine):
         assert "libugvc_mi355x.so" in fh.read()
 
 
-PATHS = pytest.mark.parametrize("path", [0, 128, 512, 256], ids=["v3-lockstep", "v4-sentinel", "v2-lds-forest", "v1-universal"])
+# kernel paths (include/ugvc_mi355x.h, ugvc_set_kernel_variant): 0 = production (v5 when the models allow it),
+# 65536 = v3 kernels, 256 = v1 universal kernel
+PATHS = pytest.mark.parametrize("path", [0, 65536, 256], ids=["v5-fused", "v3-lockstep", "v1-universal"])
 
 
 @pytest.fixture(autouse=True)
@@ -117,11 +119,11 @@ def test_gbt_model(engine, small_callset, frozen_models, path):
     assert np.max(np.abs(res.tree_score - exp.tree_score)) <= 1e-6
 
 
-@pytest.mark.parametrize("path", [0, 128], ids=["v3-lockstep", "v4-sentinel"])
+@pytest.mark.parametrize("path", [0, 65536], ids=["v5-fused", "v3-lockstep"])
 def test_v3_fallbacks_and_dense_tiles(engine, frozen_models, path):
-    """v3 / v4 preconditions: (i) a tile whose side-table slices overflow the LDS pool takes the HBM
-    search path; (ii) overlapping intervals with sorted ends stay on v3; (iii) a track whose ends
-    are not sorted is rejected, overlapping runs silently select v2 - results equal the oracle."""
+    """v5 / v3 preconditions: (i) a tile whose side-table slices overflow the staged LDS slices takes the
+    HBM search path; (ii) overlapping intervals with sorted ends stay on the fast paths; (iii) a track whose
+    ends are not sorted is rejected, overlapping runs silently select the universal kernel - results equal the oracle."""
     from variantcalling_amd import schema as S, synth
     O = _oracle()
     cs = synth.make_callset(30_000, genome_len=3_000_000, n_contigs=2, seed=31)
@@ -150,7 +152,7 @@ def test_v3_fallbacks_and_dense_tiles(engine, frozen_models, path):
         exp = O.filter_variants(vt, ref, cs.runs, tracks, bl, frozen_models[RF])
         _assert_same(got, exp, "dense/overlapping tracks on v3")
         assert (got.flags >> 3).any()
-    # (iii) nested intervals (ends not sorted) are rejected at upload; overlapping runs select v2
+    # (iii) nested intervals (ends not sorted) are rejected at upload; overlapping runs select the universal kernel
     en3 = st2 + rng.integers(1, 3000, size=4000)
     nested = track(st2, en3, np.zeros(4000, np.int64))
     assert (np.diff(nested.ends) < 0).any()
@@ -191,7 +193,7 @@ def test_error_paths(engine, small_callset):
     with pytest.raises(RuntimeError, match="sorted"):
         engine.filter_variants(vt)
     vt = copy.copy(cs.variants.slice(0, 100))
-    vt.contig = np.full(100, 200, np.uint8)
+    vt.contig = np.full(100, 200, np.uint16)
     with pytest.raises(RuntimeError, match="contig index"):
         engine.filter_variants(vt)
     with pytest.raises(RuntimeError, match="permutation"):
@@ -353,7 +355,7 @@ def _stump_forest(specs, n_features=20):
                         n_features=n_features, max_depth=1)
 
 
-@pytest.mark.parametrize("path", [0, 1024, 128, 512, 256], ids=["v3-single-sum", "v3-pair-sums", "v4-single-sum", "v2", "v1"])
+@pytest.mark.parametrize("path", [0, 65536, 65536 | 1024, 256], ids=["v5", "v3-single-sum", "v3-pair-sums", "v1"])
 def test_rf_vote_ties_and_unnormalised_payloads(engine, small_callset, path):
     """The single-sum forest kernel decides PASS on the class-1 sum alone and must fall back to both
     sums where scikit-learn's argmax is decided by them: exact ties (pure leaves, even T), near ties

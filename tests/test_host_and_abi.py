@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol(lib):
         assert hasattr(lib, n), f"{n} declared in include/ugvc_mi355x.h but not exported"
     # the ctypes binding table covers exactly the header
     assert sorted(eng_mod.ABI) == names
-    assert lib.ugvc_abi_version() == 1
+    assert lib.ugvc_abi_version() == 2
     out = subprocess.run(["nm", "-D", "--defined-only", eng_mod.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (ugvc_\w+)", out))
     assert set(names) <= exported

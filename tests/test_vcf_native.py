@@ -46,7 +46,7 @@ def test_header_symbols_are_exported():
         assert hasattr(lib, n), n
     out = subprocess.run(["nm", "-D", "--defined-only", nv.LIB_PATH], capture_output=True, text=True).stdout
     assert set(names) <= set(re.findall(r" T (ugvc_\w+)", out))
-    assert lib.ugvc_vcf_abi_version() == 1
+    assert lib.ugvc_vcf_abi_version() == 2
     # host-only library: no HIP runtime dependency
     deps = subprocess.run(["ldd", nv.LIB_PATH], capture_output=True, text=True).stdout
     assert "amdhip" not in deps and "libz" in deps

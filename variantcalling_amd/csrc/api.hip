@@ -52,7 +52,7 @@ int build_args(ugvc_ctx* ctx, FilterArgs& a, bool want_x) {
     if (!ctx->ref.p) return fail("no reference uploaded (ugvc_ref_upload)");
     memset(&a, 0, sizeof(a));
     a.n = ctx->n;
-    a.contig = ctx->v_contig.as<uint8_t>();
+    a.contig = ctx->v_contig.as<uint16_t>();
     a.pos = ctx->v_pos.as<int32_t>();
     a.ref_len = ctx->v_rl.as<uint16_t>();
     a.alt_len = ctx->v_al.as<uint16_t>();
@@ -109,21 +109,17 @@ int build_args(ugvc_ctx* ctx, FilterArgs& a, bool want_x) {
     return 0;
 }
 
-// The scoring pass: v2 (K0 brackets + K1 featurize/quantise + K2 LDS forest) whenever every
-// uploaded model packs into the LDS layout (v3 when the side tables are sorted/disjoint and the
-// float thresholds fit its LDS budget, else v2), else the universal v1 fused kernel.
-// kernel_variant bit 8 (256) forces v1 (A/B measurements, parity cross-checks).
-// kernel_variant bit 9 (512) forces v2 over v3.
+// The scoring pass.  v5 (kernels_v5.hip: index lists by variant class, per-wave featurize fused with the
+// LDS-resident SNP forest walk, raw 16-bit codes) whenever every uploaded model is a random forest in the
+// single-sum layout and the side tables are sorted / disjoint; else v3 (K0 brackets + K1 featurize / quantise +
+// K2 LDS forest: pair-sum forests, XGBoost-style ensembles) when the models pack into its LDS layout; else the
+// universal v1 fused kernel (any depth / threshold count / overlapping runs).
+// kernel_variant bit 8 (256) forces v1, bit 16 (65536) forces v3 over v5 (A/B measurements, parity cross-checks).
 int launch_score(ugvc_ctx* ctx, const FilterArgs& a) {
     if (a.flags == ctx->r_flags.as<uint8_t>()) ctx->scored = 1;
     if (!(ctx->kernel_variant & 256) && v2_available(ctx)) {
-        if (!(ctx->kernel_variant & 512) && v3_available(ctx)) {
-            // kernel variant bit 7 (128): the v4 featurize kernel (single-contig tiles, sentinel-padded joins, packed
-            // window arithmetic: half v3's vector instructions, the same 420 us per 5 M pass - DESIGN.md 3.1)
-            if ((ctx->kernel_variant & 128) && v4_available(ctx)) return launch_filter_v4(ctx, a);
-            return launch_filter_v3(ctx, a);
-        }
-        return launch_filter_v2(ctx, a);
+        if (!(ctx->kernel_variant & 65536) && v5_available(ctx)) return launch_filter_v5(ctx, a);
+        if (v3_available(ctx)) return launch_filter_v3(ctx, a);
     }
     return launch_filter(ctx, a, true, false);
 }
@@ -164,7 +160,7 @@ int ugvc_ctx_destroy(ugvc_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     ugvc_comm_destroy(ctx);
     v2_destroy(ctx);
-    DeviceBuf* all[] = {&ctx->ref, &ctx->contig_off, &ctx->runs_s, &ctx->runs_e, &ctx->runs_p, &ctx->runs_c, &ctx->bl, &ctx->bl_ptr, &ctx->bl_c, &ctx->v_tiles,
+    DeviceBuf* all[] = {&ctx->ref, &ctx->contig_off, &ctx->runs_s, &ctx->runs_e, &ctx->runs_p, &ctx->runs_c, &ctx->bl, &ctx->bl_c,
                         &ctx->v_contig, &ctx->v_pos, &ctx->v_rl, &ctx->v_al, &ctx->v_ro, &ctx->v_ao,
                         &ctx->v_alleles, &ctx->v_qual, &ctx->v_sor, &ctx->v_dp, &ctx->v_adr, &ctx->v_ada,
                         &ctx->v_gq, &ctx->r_score, &ctx->r_filter, &ctx->r_flags, &ctx->x_mat, &ctx->x_group,
@@ -210,7 +206,7 @@ int ugvc_sync(ugvc_ctx* ctx) {
 int ugvc_ref_upload(ugvc_ctx* ctx, const uint8_t* codes, int64_t total_len, const int64_t* contig_off,
                     int n_contigs) {
     if (!ctx || !codes || !contig_off) return fail("NULL argument");
-    if (n_contigs < 1 || n_contigs > 255) return fail("n_contigs must be in 1..255 (contig column is u8)");
+    if (n_contigs < 1 || n_contigs > 65535) return fail("n_contigs must be in 1..65535 (contig column is u16)");
     if (contig_off[0] != 0 || contig_off[n_contigs] != total_len) return fail("contig_off must span [0, total_len]");
     for (int c = 0; c < n_contigs; ++c)
         if (contig_off[c + 1] < contig_off[c]) return fail("contig_off must be non-decreasing");
@@ -311,12 +307,6 @@ int ugvc_blacklist_upload(ugvc_ctx* ctx, const uint64_t* keys, int64_t n) {
         if (keys[i] <= keys[i - 1]) return fail("blacklist keys must be sorted and unique");
     UGVC_HIP(hipSetDevice(ctx->device));
     if (upload(ctx, ctx->bl, keys, (size_t)n * 8)) return -1;
-    // CSR by contig id (the contig column is u8): bl_ptr[c] = first key of contig >= c
-    std::vector<int32_t> bp(258, 0);
-    if (n <= std::numeric_limits<int32_t>::max())
-        for (int c = 0; c <= 257; ++c)
-            bp[c] = (int32_t)(std::lower_bound(keys, keys + n, (uint64_t)c << 32) - keys);
-    if (upload(ctx, ctx->bl_ptr, bp.data(), bp.size() * 4)) return -1;
     if (upload_coarse(ctx, ctx->bl_c, keys, n)) return -1;
     UGVC_HIP(hipStreamSynchronize(ctx->stream));
     ctx->n_bl = n;
@@ -429,17 +419,8 @@ int ugvc_variants_upload(ugvc_ctx* ctx, const ugvc_variants* v) {
     if (ctx->n_contigs == 0) return fail("upload the reference before variants");
     UGVC_HIP(hipSetDevice(ctx->device));
     const size_t n = (size_t)v->n;
-    // single-contig tiles of <= kBlock consecutive variants (v4 kernel): cut at every contig change
-    std::vector<int2> tiles;
-    tiles.reserve(n / kBlock + 260);
     // host-side validation the kernel relies on (sortedness, contig range, allele bounds)
     for (size_t i = 0; i < n; ++i) {
-        if (n < (size_t)1 << 31) {
-            if (i == 0 || v->contig[i] != v->contig[i - 1] || (tiles.back().y & 0xFFFF) == kBlock)
-                tiles.push_back(make_int2((int)i, 1 | ((int)v->contig[i] << 16)));
-            else
-                tiles.back().y += 1;
-        }
         if (v->contig[i] >= ctx->n_contigs) return fail("contig index out of range at row " + std::to_string(i));
         if (v->ref_len[i] == 0 || v->alt_len[i] == 0) return fail("empty allele at row " + std::to_string(i));
         if ((int64_t)v->ref_off[i] + v->ref_len[i] > v->alleles_len ||
@@ -450,18 +431,16 @@ int ugvc_variants_upload(ugvc_ctx* ctx, const ugvc_variants* v) {
                   (v->contig[i] == v->contig[i - 1] && v->pos[i] < v->pos[i - 1])))
             return fail("variants must be sorted by (contig, pos); row " + std::to_string(i));
     }
-    if (upload(ctx, ctx->v_contig, v->contig, n)) return -1;
+    if (upload(ctx, ctx->v_contig, v->contig, n * 2)) return -1;
     if (upload(ctx, ctx->v_pos, v->pos, n * 4)) return -1;
     if (upload(ctx, ctx->v_rl, v->ref_len, n * 2)) return -1;
     if (upload(ctx, ctx->v_al, v->alt_len, n * 2)) return -1;
     if (upload(ctx, ctx->v_ro, v->ref_off, n * 4)) return -1;
     if (upload(ctx, ctx->v_ao, v->alt_off, n * 4)) return -1;
-    // 16 zero bytes behind the allele pool: the v4 kernel fetches an allele's tail as one 8-byte load
+    // 16 zero bytes behind the allele pool: allele tails are fetched with fixed-width loads
     if (ensure(ctx->v_alleles, (size_t)v->alleles_len + 16)) return -1;
     UGVC_HIP(hipMemsetAsync(static_cast<uint8_t*>(ctx->v_alleles.p) + v->alleles_len, 0, 16, ctx->stream));
     if (upload(ctx, ctx->v_alleles, v->alleles, (size_t)v->alleles_len)) return -1;
-    if (upload(ctx, ctx->v_tiles, tiles.data(), tiles.size() * sizeof(int2))) return -1;
-    ctx->n_tiles4 = (int)tiles.size();
     if (upload(ctx, ctx->v_qual, v->qual, n * 4)) return -1;
     if (upload(ctx, ctx->v_sor, v->sor, n * 4)) return -1;
     if (upload(ctx, ctx->v_dp, v->dp, n * 4)) return -1;

@@ -200,7 +200,7 @@ int launch_sec(ugvc_ctx* ctx, const int32_t* d_actual, const int32_t* d_expected
 // (/root/reference/ugvc/pipelines/vcfbed/calibrate_bridging_snvs.py:9-66,110-126).
 struct BridgingArgs {
     int64_t n;
-    const uint8_t* contig; const int32_t* pos; const uint16_t* ref_len; const uint16_t* alt_len;
+    const uint16_t* contig; const int32_t* pos; const uint16_t* ref_len; const uint16_t* alt_len;
     const uint32_t* ref_off; const uint32_t* alt_off; const uint8_t* alleles;
     const float* qual; const int32_t* dp;
     const uint8_t* is_pass; const int32_t* ad_alt_sum; const int32_t* bg_ad_alt_sum; const int32_t* bg_dp;
@@ -354,7 +354,7 @@ int ugvc_bridging_snvs(ugvc_ctx* ctx, const ugvc_variants* v, const uint8_t* is_
     if (!rc) {
         BridgingArgs a;
         a.n = v->n;
-        a.contig = ctx->v_contig.as<uint8_t>(); a.pos = ctx->v_pos.as<int32_t>();
+        a.contig = ctx->v_contig.as<uint16_t>(); a.pos = ctx->v_pos.as<int32_t>();
         a.ref_len = ctx->v_rl.as<uint16_t>(); a.alt_len = ctx->v_al.as<uint16_t>();
         a.ref_off = ctx->v_ro.as<uint32_t>(); a.alt_off = ctx->v_ao.as<uint32_t>();
         a.alleles = ctx->v_alleles.as<uint8_t>(); a.qual = ctx->v_qual.as<float>(); a.dp = ctx->v_dp.as<int32_t>();

@@ -50,7 +50,7 @@ __device__ __forceinline__ void sec_log_pmf2(const int* x, const int* e, int k, 
     lp_x = g + sx;
 }
 
-__global__ __launch_bounds__(256) void sec_apply_kernel(const uint8_t* __restrict__ contig, const int32_t* __restrict__ pos,
+__global__ __launch_bounds__(256) void sec_apply_kernel(const uint16_t* __restrict__ contig, const int32_t* __restrict__ pos,
                                                         const int32_t* __restrict__ dp, const int32_t* __restrict__ adr,
                                                         const int32_t* __restrict__ ada, int64_t n,
                                                         const uint64_t* __restrict__ keys, const uint64_t* __restrict__ coarse,
@@ -227,7 +227,7 @@ int ugvc_sec_apply(ugvc_ctx* ctx, double min_ratio, int scale_expected, int mark
     int rc = 0;
     do {
         if ((ratio && (rc = ensure(d_r, (size_t)n * 8))) || (is_sec && (rc = ensure(d_s, (size_t)n)))) break;
-        hipLaunchKernelGGL(sec_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->v_contig.as<uint8_t>(),
+        hipLaunchKernelGGL(sec_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->v_contig.as<uint16_t>(),
                            ctx->v_pos.as<int32_t>(), ctx->v_dp.as<int32_t>(), ctx->v_adr.as<int32_t>(), ctx->v_ada.as<int32_t>(), n,
                            ctx->sec_keys.as<uint64_t>(), ctx->sec_coarse.as<uint64_t>(), ctx->sec_exp.as<int32_t>(), ctx->sec_lgtab.as<double>(), ctx->n_sec,
                            ctx->sec_k,

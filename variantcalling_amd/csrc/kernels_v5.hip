@@ -1,0 +1,1044 @@
+// v5 scoring pass (gfx950): featurize -> lookup -> score -> FILTER as four launches.
+//
+// What v3 measured (profiles/r01_*): its featurize kernel (K1, 378 us per 5 M variants) waits on a chain of
+// dependent memory round trips per 256-variant tile at 4 waves/SIMD, with the vector ALU mostly idle; its forest
+// kernel (K2, 321 us) is bound by the LDS pipeline and runs AFTER K1; the two exchange a 16-byte record per
+// variant through HBM (160 MB per pass) and K2 stores its results scattered.  v5 puts both on the same waves:
+//
+//   compact5_kernel   every 1024-variant block splits its rows by variant class (ref_len == alt_len: the SNP
+//                     forest; else an indel) into tiles of 64 row indices; a tile is one wave's work and is pure
+//                     in class, so every lane of a wave walks the SAME forest (no lane is idle in a walk).
+//   bracket5_kernel   per tile, the lower bound of its first (indel tiles: and last) variant in every searched
+//                     side table (two-level search, L2-resident 1/64 sample first).
+//   fused5_kernel     one 16-wave workgroup per CU holds the SNP forest in LDS (rank-coded complete trees,
+//                     single-sum layout) and the SNP group's float thresholds.  A wave is autonomous - no
+//                     workgroup barrier after the prologue: it loads its tile's columns, an 11-base reference
+//                     window per lane (one 16-byte load, realigned with v_alignbyte), stages the side-table slices
+//                     its tile can touch in wave-private LDS (sentinel padded, so the descents carry no bounds
+//                     test), derives the features, writes 16-bit codes straight into its code planes and walks
+//                     the forest; score / FILTER / flags leave in variant order (coalesced).  While one wave waits
+//                     for memory the other fifteen walk: the featurize latency that bounded K1 disappears under
+//                     the LDS-bound walk.  Indel tiles (18 % of a WGS callset) are featurised by the same waves
+//                     between SNP tiles (48-byte window, homopolymer logic, bracketed searches on the L2-resident
+//                     tables) and leave as 48-byte raw-code records in their variant-type group's list.
+//   forest5_kernel    walks the indel groups' forests over those records (the v3 forest kernel on raw records).
+//
+// Codes: floats (qual, sor, vaf, gc) are ranked against the group's sorted thresholds (exact, as v3); every
+// other feature is a non-negative integer and is used as it stands, clamped to one past the largest threshold
+// the forest tests (ugvc_v2.hpp) - no code tables, no gathers.
+// Semantics are those of the oracle (oracle/oracle.py); parity tests run v5, v3 and v1 against it.
+#include <algorithm>
+
+#include "ugvc_walk.hpp"
+
+namespace ugvc {
+
+#define UGVC_CONST __attribute__((address_space(4)))
+// Loads through the constant address space: data written by an EARLIER launch, wave-uniform address -> s_load.
+template <class T> __device__ __forceinline__ T cload(const T* p) {
+    return *(const UGVC_CONST T*)(uintptr_t)p;
+}
+
+__device__ __forceinline__ uint2 cload2(const uint2* p) {
+    const u32x2_t x = *(const UGVC_CONST u32x2_t*)(uintptr_t)p;
+    return make_uint2(x.x, x.y);
+}
+
+constexpr int kGcTab = 128;          // gc_content = gctab[len * 11 + count], len, count in 0..10
+constexpr int kWinRowB = kWinStride * 4;
+
+// ---- Kc: variant classes -> tiles of 64 row indices ---------------------------------------------------
+__global__ __launch_bounds__(kCBlock5) void compact5_kernel(const V5Args v) {
+    __shared__ unsigned ws[kCBlock5 / 64], wi[kCBlock5 / 64];
+    __shared__ unsigned base_s, base_i;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t i = (int64_t)blockIdx.x * kCBlock5 + tid;
+    if (i < UGVC_N_GROUPS * kShards) v.counters[i * kCounterStride] = 0;      // the record lists of this pass start empty
+    bool snp = false, ind = false;
+    if (i < v.f.n) {
+        snp = v.f.ref_len[i] == v.f.alt_len[i];
+        ind = !snp;
+    }
+    const unsigned long long ms = __ballot(snp), mi = __ballot(ind);
+    if (lane == 0) { ws[wave] = (unsigned)__popcll(ms); wi[wave] = (unsigned)__popcll(mi); }
+    __syncthreads();
+    unsigned ps = 0, pi = 0, ts = 0, ti = 0;
+#pragma unroll
+    for (int w = 0; w < kCBlock5 / 64; ++w) {
+        const unsigned a = ws[w], b = wi[w];
+        ps += w < wave ? a : 0u;
+        pi += w < wave ? b : 0u;
+        ts += a;
+        ti += b;
+    }
+    const unsigned nts = (ts + 63) >> 6, nti = (ti + 63) >> 6;
+    if (tid == 0) {
+        base_s = nts ? atomicAdd(&v.tile_cnt[0], nts) : 0u;
+        base_i = nti ? atomicAdd(&v.tile_cnt[1], nti) : 0u;
+    }
+    __syncthreads();
+    const unsigned bs = base_s, bi = base_i;
+    const unsigned long long below = (1ull << lane) - 1;
+    if (snp) v.snp_idx[(size_t)bs * 64 + ps + (unsigned)__popcll(ms & below)] = (uint32_t)i;
+    if (ind) v.indel_idx[(size_t)bi * 64 + pi + (unsigned)__popcll(mi & below)] = (uint32_t)i;
+    if ((unsigned)tid < nts * 64 - ts) v.snp_idx[(size_t)bs * 64 + ts + tid] = ~0u;          // padding of the last tile
+    if ((unsigned)tid < nti * 64 - ti) v.indel_idx[(size_t)bi * 64 + ti + tid] = ~0u;
+    if ((unsigned)tid < nts) v.tile_n[bs + tid] = (uint8_t)((unsigned)tid + 1 < nts ? 64u : ts - 64u * (nts - 1));
+    if ((unsigned)tid < nti) v.tile_n[(size_t)v.max_tiles + bi + tid] = (uint8_t)((unsigned)tid + 1 < nti ? 64u : ti - 64u * (nti - 1));
+}
+
+// ---- K0: per tile, lower bounds of its first (indel tiles: and last) variant in the searched tables ---
+__global__ void bracket5_kernel(const V5Args v) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t ns = v.tile_cnt[0], ni = v.tile_cnt[1];
+    const FilterArgs& f = v.f;
+    int64_t tile;
+    int a;
+    bool is_indel;
+    if (gid < ns * 8) { tile = gid >> 3; a = (int)(gid & 7); is_indel = false; }
+    else {
+        const int64_t g2 = gid - ns * 8;
+        if (g2 >= ni * 16) return;
+        tile = g2 >> 4; a = (int)(g2 & 15); is_indel = true;
+    }
+    const int t = a & 7;
+    if (t >= kJoin5) return;
+    const uint32_t* list = is_indel ? v.indel_idx : v.snp_idx;
+    const int slot = a >= 8 ? (int)v.tile_n[(size_t)v.max_tiles + tile] - 1 : 0;
+    const uint32_t i = list[tile * 64 + slot];
+    const int c = f.contig[i], pos = f.pos[i];
+    int out = 0;
+    if (t == kJoin5 - 1) {
+        if (f.n_bl > 0) out = lb_two_level_g<uint64_t>(f.bl, f.bl_coarse, 0, (int)f.n_bl, ((uint64_t)c << 32) | (uint32_t)pos);
+    } else if (table_present(f, t)) {
+        const TrackView& tv = table_view(f, t);
+        out = lb_two_level_g<int32_t>(tv.starts, tv.coarse, tv.ptr[c], tv.ptr[c + 1], pos);
+    }
+    if (is_indel) v.br_indel[tile * 16 + a] = out;
+    else v.br_snp[tile * 8 + a] = out;
+}
+
+// ---- joins ---------------------------------------------------------------------------------------
+struct JoinOut {
+    bool inside_run, close_run, cohort;
+    uint32_t trk;                    // bit t: inside an interval of annotation track t
+};
+
+// After the rank sg = #starts < pos of a table (global index): membership / proximity from a few reads of
+// the starts and ends around it.  S / E return starts[i] / ends[i] for any i the guards allow.
+template <class GetS, class GetE>
+__device__ __forceinline__ void interval_verdict(int t, int sg, int plo, int phi, int pos, int D, GetS S, GetE E, JoinOut& o) {
+    const bool valid = sg > plo;
+    const int e1v = E(sg - 1);
+    if (t == 0) {
+        // runs are disjoint: #ends < pos is sg-1 or sg
+        const bool ins_run = valid && e1v >= pos;
+        if (phi > plo) {
+            const int eg = valid ? sg - 1 + (e1v < pos ? 1 : 0) : sg;
+            auto near = [&](int x) { const int d = pos - x; return (d < 0 ? -d : d) < D; };
+            const int s1v = S(sg - 1), s0v = S(sg);
+            bool cd = (valid && near(s1v)) || (sg <= phi - 1 && near(s0v));
+            const int ee = E(eg), em = E(eg - 1);
+            cd = cd || (eg - 1 >= plo && near(em)) || (eg <= phi - 1 && near(ee));
+            o.inside_run = ins_run;
+            o.close_run = cd && !ins_run;
+        }
+    } else {
+        const int e2v = E(sg - 2);
+        const bool in = valid && e1v >= pos && (sg - 1 == plo || e2v < pos);
+        o.trk |= in ? 1u << (t - 1) : 0u;
+    }
+}
+
+// Searches on the resident tables themselves, all tables in lock-step: per lane the range [lo, hi) of every
+// table (a tile's brackets, or the whole contig).
+__device__ __forceinline__ void join_global(const FilterArgs& a, const int (&lo)[kJoin5], const int (&hi)[kJoin5],
+                                            const int (&plo)[kJoin5 - 1], const int (&phi)[kJoin5 - 1], int pos, uint64_t key, JoinOut& o) {
+    int base[kJoin5], len[kJoin5];
+#pragma unroll
+    for (int t = 0; t < kJoin5; ++t) {
+        base[t] = lo[t];
+        len[t] = hi[t] - lo[t];
+        const bool present = t == kJoin5 - 1 ? a.n_bl > 0 : table_present(a, t);
+        if (!present || len[t] < 0) len[t] = 0;
+    }
+    for (;;) {
+        bool more = false;
+        int x[kJoin5 - 1];
+        uint64_t xk = 0;
+#pragma unroll
+        for (int t = 0; t < kJoin5 - 1; ++t) {
+            x[t] = 0;
+            if (table_present(a, t) && len[t] > 0) x[t] = table_view(a, t).starts[base[t] + (len[t] >> 1)];
+        }
+        if (len[kJoin5 - 1] > 0) xk = a.bl[base[kJoin5 - 1] + (len[kJoin5 - 1] >> 1)];
+#pragma unroll
+        for (int t = 0; t < kJoin5; ++t) {
+            if (len[t] > 0) {
+                const int half = len[t] >> 1;
+                const bool lt = t == kJoin5 - 1 ? xk < key : x[t] < pos;
+                base[t] = lt ? base[t] + half + 1 : base[t];
+                len[t] = lt ? len[t] - half - 1 : half;
+                more |= len[t] > 0;
+            }
+        }
+        if (__ballot(more) == 0) break;
+    }
+#pragma unroll
+    for (int t = 0; t < kJoin5 - 1; ++t) {
+        if (!table_present(a, t)) continue;
+        const TrackView& tv = table_view(a, t);
+        const int top = phi[t] - 1;                           // reads are clamped into the contig's rows; the guards of
+        auto S = [&](int i) { return tv.starts[i < plo[t] ? plo[t] : (i > top ? (top > plo[t] ? top : plo[t]) : i)]; };   // interval_verdict
+        auto E = [&](int i) { return tv.ends[i < plo[t] ? plo[t] : (i > top ? (top > plo[t] ? top : plo[t]) : i)]; };     // discard them
+        if (phi[t] > plo[t]) interval_verdict(t, base[t], plo[t], phi[t], pos, a.hpol_dist, S, E, o);
+    }
+    if (a.n_bl > 0) {
+        const int r = base[kJoin5 - 1];
+        if (r < (int)a.n_bl && a.bl[r] == key) o.cohort = true;
+    }
+}
+
+// ---- float features: rank among a sorted LDS slice -----------------------------------------------------
+// q0 = LDS address of the element BEFORE the slice, qend = address of its last element, bits: 2^bits > length.
+__device__ __forceinline__ uint32_t rank_f32(float x, uint32_t q0, uint32_t qend, int bits) {
+    uint32_t q = q0;
+    for (int s = bits - 1; s >= 0; --s) {
+        const uint32_t cand = q + (4u << s);
+        const float t = lds_f32(cand);
+        q = ((int32_t)(qend - cand) >= 0 && t < x) ? cand : q;
+    }
+    return (q - q0) >> 2;
+}
+
+__device__ __forceinline__ uint32_t raw_code(int x, int cap) {          // x < 0 ? 0 : min(x, cap) + 1
+    return (uint32_t)(max(min(x, cap), -1) + 1);
+}
+
+__device__ __forceinline__ bool any_zero_byte(uint32_t x) { return ((x - 0x01010101u) & ~x & 0x80808080u) != 0; }
+// A or T bytes (codes 1, 4) of a packed base word -> 0x01 per byte
+__device__ __forceinline__ uint32_t at_bytes(uint32_t x) { return ((x & ~(x >> 1)) | (x >> 2)) & 0x01010101u; }
+
+struct Cols {                       // one variant's columns
+    int c, pos, rl, al;
+    uint32_t ro, ao;
+    float qual, sor;
+    int dp, adr, ada, gq;
+};
+
+struct Scratch {                    // wave-private LDS (byte addresses)
+    uint32_t base;                  // window rows / staged slices / code planes, one after the other in time
+    uint32_t thr_b;                 // float thresholds
+    uint32_t gctab_b;
+    uint32_t css_b;
+};
+
+// ---- SNP / MNP tile: features of 64 substitutions (ref_len == alt_len) ---------------------------------
+// Writes the flags column, leaves the 16-bit codes of the group-0 forest in the wave's code planes.
+__device__ __forceinline__ void featurize_snp_tile(const V5Args& v, const Scratch& sc, int64_t tile, int lane, uint32_t i, bool live,
+                                                   bool has_model) {
+    const FilterArgs& a = v.f;
+    Cols k;
+    k.c = a.contig[i]; k.pos = a.pos[i]; k.rl = a.ref_len[i];
+    k.ro = a.ref_off[i]; k.ao = a.alt_off[i];
+    const int64_t clo = a.contig_off[k.c], chi = a.contig_off[k.c + 1];
+    const uint32_t clen = (uint32_t)(chi - clo);
+    const uint32_t p0 = (uint32_t)(k.pos - 1);
+    const int64_t g0 = clo + p0;
+    // 11 bases pos-5 .. pos+5: one dword-aligned 16-byte load, realigned per lane (the buffer is padded by 64
+    // bytes at both ends)
+    const int64_t wa = (g0 - 5) & ~(int64_t)3;
+    const uint32_t sh = (uint32_t)(g0 - 5) & 3u;
+    const uint4 xw = *reinterpret_cast<const uint4*>(a.ref + wa);
+    const uint32_t rbase = a.alleles[k.ro], abase = a.alleles[k.ao];
+    k.qual = a.qual[i]; k.sor = a.sor[i];
+    k.dp = a.dp[i]; k.adr = a.ad_ref[i]; k.ada = a.ad_alt[i]; k.gq = a.gq[i];
+
+    // ---- side-table slices of this tile -> wave-private LDS (sentinel padded)
+    const int c0 = rfl(k.c);
+    const bool uni = __ballot(k.c != c0) == 0;                  // one contig (all but a handful of tiles)
+    const int n_live = (int)__popcll(__ballot(live));
+    const int pos_max = __builtin_amdgcn_readlane(k.pos, n_live - 1);
+    const uint64_t key = ((uint64_t)(uint32_t)k.c << 32) | (uint32_t)k.pos;
+    const uint64_t key_max = ((uint64_t)(uint32_t)c0 << 32) | (uint32_t)pos_max;
+    int L[kJoin5], plo[kJoin5 - 1], phi[kJoin5 - 1];
+    const bool joins_on = !(a.ablate & 524288);
+    if (uni && joins_on) {
+#pragma unroll
+        for (int t = 0; t < kJoin5 - 1; ++t) {
+            L[t] = plo[t] = phi[t] = 0;
+            if (!table_present(a, t)) continue;
+            const TrackView& tv = table_view(a, t);
+            const int cap = v.jcap[t];
+            L[t] = cload(v.br_snp + tile * 8 + t) - 2;
+            plo[t] = cload(tv.ptr + c0);
+            phi[t] = cload(tv.ptr + c0 + 1);
+            const int na = v.na[t];
+            const uint32_t dS = sc.base + 4u * (uint32_t)v.joff[t], dE = dS + 4u * (uint32_t)cap;
+            for (int e = lane; e < cap; e += 64) {
+                const int gi = L[t] + e;
+                const int gs = gi < 0 ? 0 : (gi >= na ? (na > 0 ? na - 1 : 0) : gi);
+                const int sv = tv.starts[gs], ev = tv.ends[gs];
+                *(UGVC_LDS int32_t*)(uintptr_t)(dS + 4u * e) = gi < plo[t] ? INT32_MIN : (gi >= phi[t] ? INT32_MAX : sv);
+                *(UGVC_LDS int32_t*)(uintptr_t)(dE + 4u * e) = ev;
+            }
+        }
+        {
+            const int t = kJoin5 - 1;
+            L[t] = 0;
+            if (a.n_bl > 0) {
+                const int cap = v.jcap[t];
+                L[t] = cload(v.br_snp + tile * 8 + t);
+                const uint32_t dK = sc.base + 4u * (uint32_t)v.joff[t];
+                for (int e = lane; e < cap; e += 64) {
+                    const int64_t gi = (int64_t)L[t] + e;
+                    const uint64_t kv = gi < a.n_bl ? a.bl[gi] : ~0ull;
+                    *(UGVC_LDS uint64_t*)(uintptr_t)(dK + 8u * e) = kv;
+                }
+            }
+        }
+    }
+
+    // ---- window: bases pos-5 .. pos+5 in bytes 0..10 of (w0, w1, w2)
+    uint32_t w0 = __builtin_amdgcn_alignbyte(xw.y, xw.x, sh);
+    uint32_t w1 = __builtin_amdgcn_alignbyte(xw.z, xw.y, sh);
+    uint32_t w2 = __builtin_amdgcn_alignbyte(xw.w, xw.z, sh) & 0x00FFFFFFu;
+    uint32_t gc_len = kGcWindow;
+    if (__ballot(p0 < 5u || p0 + 6u > clen) != 0) {             // a lane near a contig edge: bases outside read as N
+        uint32_t m[3] = {0, 0, 0};
+        gc_len = 0;
+#pragma unroll
+        for (int q = 0; q < 11; ++q) {
+            const bool inb = (uint32_t)(p0 - 5u + (uint32_t)q) < clen;        // wraps below 0 -> fails
+            m[q >> 2] |= inb ? 0xFFu << (8 * (q & 3)) : 0u;
+            if (q >= 1) gc_len += inb ? 1u : 0u;
+        }
+        w0 &= m[0]; w1 &= m[1]; w2 &= m[2];
+    }
+    // get_motif_around (5): left = pos-5 .. pos-1, right = pos+1 .. pos+5 (substitutions), base-5 codes
+    const uint32_t b4 = w1 & 0xFFu, b6 = (w1 >> 16) & 0xFFu;
+    const int lm = (int)(__builtin_amdgcn_udot4(w0, 0x00010519u, 0u, false) * 25u + __builtin_amdgcn_udot4(w0, 0x05000000u, b4, false));
+    const int rm = (int)(__builtin_amdgcn_udot4(w1, 0x05190000u, w2 & 0xFFu, false) * 25u + __builtin_amdgcn_udot4(w2, 0x00010500u, 0u, false));
+    const bool motif_n = any_zero_byte(w0) || any_zero_byte(w1 | 0x0000FF00u) || any_zero_byte(w2 | 0xFF000000u);
+    // gc_content (10): bases pos-4 .. pos+5; everything that is not A / T counts (N included, as the reference's string test)
+    const uint32_t n_at = (uint32_t)__popc(at_bytes(w0) & 0x01010100u) + (uint32_t)__popc(at_bytes(w1)) + (uint32_t)__popc(at_bytes(w2) & 0x00010101u);
+    const uint32_t gc_cnt = gc_len - n_at;
+    const float gc = lds_f32(sc.gctab_b + 4u * (gc_len * 11u + gc_cnt));
+    // cycle skip
+    int css;
+    if (motif_n || rbase == 0 || abase == 0) css = 0;
+    else css = *(UGVC_LDS const uint8_t*)(uintptr_t)(sc.css_b + (((b4 - 1) << 6) | ((rbase - 1) << 4) | ((abase - 1) << 2) | (b6 - 1)));
+    if (__ballot(k.rl > 1) != 0) {                               // MNPs: the full flow-space walk
+        if (k.rl > 1) {
+            const uint8_t* __restrict__ apool = a.alleles;
+            bool has_n = motif_n;
+            for (int q = 0; q < k.rl; ++q) has_n |= apool[k.ro + q] == 0 || apool[k.ao + q] == 0;
+            if (has_n) css = 0;
+            else {
+                auto wbyte = [&](int q) -> int { return (int)(((q < 4 ? w0 : (q < 8 ? w1 : w2)) >> (8 * (q & 3))) & 0xFFu); };
+                auto seq_r = [&](int q) -> int {
+                    if (q < kMotif) return wbyte(q);
+                    if (q < kMotif + k.rl) return apool[k.ro + q - kMotif];
+                    return wbyte(q - k.rl + 1);
+                };
+                auto seq_a = [&](int q) -> int {
+                    if (q < kMotif) return wbyte(q);
+                    if (q < kMotif + k.rl) return apool[k.ao + q - kMotif];
+                    return wbyte(q - k.rl + 1);
+                };
+                css = cycle_skip_walk(k.rl + 2 * kMotif, a.flow, seq_r, seq_a);
+            }
+        }
+    }
+
+    // ---- joins
+    JoinOut jo{false, false, false, 0u};
+    if (!joins_on) {
+    } else if (uni) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // rank among the staged starts of every table, all descents in lock-step; a table whose staged slice
+        // does not reach the tile's last variant is searched in HBM instead (dense stretches)
+        uint32_t p[kJoin5];
+        bool cov[kJoin5];
+        int maxcap = 0;
+#pragma unroll
+        for (int t = 0; t < kJoin5; ++t) {
+            const int cap = v.jcap[t];
+            const bool present = t == kJoin5 - 1 ? a.n_bl > 0 : table_present(a, t);
+            const uint32_t A = sc.base + 4u * (uint32_t)v.joff[t];
+            cov[t] = false;
+            p[t] = A - (t == kJoin5 - 1 ? 8u : 4u);
+            if (present && cap > 0) {
+                if (t == kJoin5 - 1) cov[t] = lds_u64(A + 8u * (uint32_t)(cap - 1)) >= key_max;
+                else cov[t] = lds_i32(A + 4u * (uint32_t)(cap - 1)) >= pos_max;
+                cov[t] = rfl((int)cov[t]) != 0;
+                if (cov[t]) maxcap = cap > maxcap ? cap : maxcap;
+            }
+        }
+        for (int s = maxcap >> 1; s >= 1; s >>= 1) {
+            uint32_t cand[kJoin5];
+            int x[kJoin5 - 1];
+            uint64_t xk = 0;
+#pragma unroll
+            for (int t = 0; t < kJoin5 - 1; ++t) {
+                cand[t] = p[t] + 4u * (uint32_t)s;
+                x[t] = INT32_MAX;
+                if (cov[t] && s < v.jcap[t]) x[t] = lds_i32(cand[t]);
+            }
+            cand[kJoin5 - 1] = p[kJoin5 - 1] + 8u * (uint32_t)s;
+            if (cov[kJoin5 - 1] && s < v.jcap[kJoin5 - 1]) xk = lds_u64(cand[kJoin5 - 1]);
+            else xk = ~0ull;
+#pragma unroll
+            for (int t = 0; t < kJoin5 - 1; ++t) p[t] = x[t] < k.pos ? cand[t] : p[t];
+            p[kJoin5 - 1] = xk < key ? cand[kJoin5 - 1] : p[kJoin5 - 1];
+        }
+        bool missed = false;
+#pragma unroll
+        for (int t = 0; t < kJoin5 - 1; ++t) {
+            if (!table_present(a, t)) continue;
+            if (!cov[t]) { missed = true; continue; }
+            const uint32_t A = sc.base + 4u * (uint32_t)v.joff[t];
+            const uint32_t dE = 4u * (uint32_t)v.jcap[t];
+            const int r = (int)((p[t] + 4u - A) >> 2);             // staged starts below pos
+            const int sg = L[t] + r;
+            auto S = [&](int gi) { return lds_i32(A + 4u * (uint32_t)(gi - L[t])); };
+            auto E = [&](int gi) { return lds_i32(A + dE + 4u * (uint32_t)(gi - L[t])); };
+            interval_verdict(t, sg, plo[t], phi[t], k.pos, a.hpol_dist, S, E, jo);
+        }
+        if (a.n_bl > 0) {
+            const int t = kJoin5 - 1;
+            if (!cov[t]) missed = true;
+            else if (lds_u64(p[t] + 8u) == key) jo.cohort = true;   // the staged key at the rank (sentinel beyond the table)
+        }
+        if (missed) {
+            int lo_[kJoin5], hi_[kJoin5];
+#pragma unroll
+            for (int t = 0; t < kJoin5 - 1; ++t) {
+                const bool need = table_present(a, t) && !cov[t];
+                lo_[t] = plo[t];
+                hi_[t] = need ? phi[t] : plo[t];
+            }
+            lo_[kJoin5 - 1] = 0;
+            hi_[kJoin5 - 1] = (a.n_bl > 0 && !cov[kJoin5 - 1]) ? (int)a.n_bl : 0;
+            JoinOut j2{false, false, false, 0u};
+            join_global(a, lo_, hi_, plo, phi, k.pos, key, j2);
+            // only the tables searched here report
+            if (table_present(a, 0) && !cov[0]) { jo.inside_run = j2.inside_run; jo.close_run = j2.close_run; }
+#pragma unroll
+            for (int t = 1; t < kJoin5 - 1; ++t)
+                if (table_present(a, t) && !cov[t]) jo.trk = (jo.trk & ~(1u << (t - 1))) | (j2.trk & (1u << (t - 1)));
+            if (a.n_bl > 0 && !cov[kJoin5 - 1]) jo.cohort = j2.cohort;
+        }
+    } else {
+        // a tile that spans contigs: every lane searches its own contig's rows
+        int lo_[kJoin5], hi_[kJoin5], pl[kJoin5 - 1], ph[kJoin5 - 1];
+#pragma unroll
+        for (int t = 0; t < kJoin5 - 1; ++t) {
+            pl[t] = ph[t] = 0;
+            if (table_present(a, t)) {
+                const TrackView& tv = table_view(a, t);
+                pl[t] = tv.ptr[k.c];
+                ph[t] = tv.ptr[k.c + 1];
+            }
+            lo_[t] = pl[t];
+            hi_[t] = ph[t];
+        }
+        lo_[kJoin5 - 1] = 0;
+        hi_[kJoin5 - 1] = (int)a.n_bl;
+        join_global(a, lo_, hi_, pl, ph, k.pos, key, jo);
+    }
+    uint8_t flags = (uint8_t)(jo.trk << UGVC_FLAG_TRACK0_SHIFT);
+    if (jo.cohort) flags |= UGVC_FLAG_COHORT_FP;
+    if (a.mark_hpol && (jo.inside_run || jo.close_run)) flags |= UGVC_FLAG_HPOL_RUN;
+    if (live) a.flags[i] = flags;
+    if (!has_model) return;
+
+    // ---- codes -> the wave's code planes (the staged slices are dead: LDS executes a wave's accesses in order)
+    const float vaf = k.dp > 0 ? __fdiv_rn((float)k.ada, (float)k.dp) : 0.0f;
+    const uint32_t used = v.used5[0];
+    const int hslot = ((lane & 31) << 1) | (lane >> 5);
+    const uint32_t pl_b = sc.base + 2u * (uint32_t)hslot;
+    auto put = [&](int f, uint32_t code) {
+        if (used & (1u << f)) *(UGVC_LDS uint16_t*)(uintptr_t)(pl_b + 128u * (uint32_t)f) = (uint16_t)code;
+    };
+    {
+        const float fx[4] = {k.qual, k.sor, vaf, gc};
+        const int fj[4] = {0, 1, 5, 13};
+        uint32_t cd[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            cd[q] = 0;
+            if (!(used & (1u << fj[q]))) continue;
+            const uint2 d = cload2(v.desc3 + fj[q]);                 // group 0
+            const uint32_t off = d.x & 0xFFFFFu, len = d.y & 0xFFFFu;
+            const uint32_t q0 = sc.thr_b + 4u * off - 4u;
+            cd[q] = rank_f32(fx[q], q0, q0 + 4u * len, v.thr0_bits4[q]);
+            if (fx[q] != fx[q]) cd[q] = len;                        // NaN compares false: always the right branch
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) put(fj[q], cd[q]);
+    }
+    put(2, raw_code(k.dp, v.cap5[0][2]));
+    put(3, raw_code(k.adr, v.cap5[0][3]));
+    put(4, raw_code(k.ada, v.cap5[0][4]));
+    put(6, raw_code(k.gq, v.cap5[0][6]));
+    put(7, 1u); put(8, 1u); put(9, 1u); put(10, 1u);                // classify, indel_length, hmer length / base: 0
+    put(11, raw_code(lm, v.cap5[0][11]));
+    put(12, raw_code(rm, v.cap5[0][12]));
+    put(14, raw_code(css, v.cap5[0][14]));
+    put(15, jo.inside_run ? 2u : 1u);
+    put(16, jo.close_run ? 2u : 1u);
+#pragma unroll
+    for (int t = 0; t < UGVC_MAX_TRACKS; ++t) put(17 + t, (jo.trk >> t) & 1u ? 2u : 1u);
+}
+
+// ---- indel tile: features of 64 length-changing variants -> raw-code records of groups 1 / 2 -------------
+__device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scratch& sc, int64_t tile, int lane, uint32_t i, bool live) {
+    const FilterArgs& a = v.f;
+    const uint8_t* __restrict__ apool = a.alleles;
+    const int c = a.contig[i], pos = a.pos[i], rl = a.ref_len[i], al = a.alt_len[i];
+    const uint32_t ro = a.ref_off[i], ao = a.alt_off[i];
+    const bool ins = rl < al;
+    const int classify = ins ? 1 : 2;
+    const int indel_length = ins ? al - rl : rl - al;
+    const int64_t clo = a.contig_off[c], chi = a.contig_off[c + 1];
+    const uint32_t clen = (uint32_t)(chi - clo);
+    const uint32_t p0 = (uint32_t)(pos - 1);
+    const int64_t g0 = clo + p0;
+    int64_t ws = (g0 - 6) & ~(int64_t)15;
+    if (ws < 0) ws = 0;
+    const int o0 = (int)(g0 - ws);                            // byte of the variant's first base, 6..21 (less at genome start)
+    const uint32_t wrow_b = sc.base + (uint32_t)(lane * kWinRowB);
+    UGVC_LDS uint32_t* wrow = (UGVC_LDS uint32_t*)(uintptr_t)wrow_b;
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(a.ref + ws);
+        const uint4 x0 = src[0], x1 = src[1], x2 = src[2];
+        uint32_t w[kWinDw] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w};
+        if (ws < clo || ws + kWinBytes > chi) {               // contig-edge lanes: bytes outside the contig read as N
+#pragma unroll
+            for (int q = 0; q < kWinDw; ++q) {
+                uint32_t m = 0;
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    const int64_t gi = ws + 4 * q + bb;
+                    m |= (gi >= clo && gi < chi) ? (0xFFu << (8 * bb)) : 0u;
+                }
+                w[q] &= m;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kWinDw; ++q) wrow[q] = w[q];
+    }
+    // allele bytes: the tail of the longer allele
+    const uint32_t lo_off = ins ? ao : ro;
+    const int ln = ins ? al : rl;
+    uint32_t ab[8];
+    ab[0] = apool[lo_off + 1];
+    ab[1] = apool[lo_off + (2 < ln ? 2 : ln - 1)];
+#pragma unroll
+    for (int q = 2; q < 8; ++q) ab[q] = apool[lo_off + (q + 1 < ln ? q + 1 : ln - 1)];
+    const float qual = a.qual[i], sor = a.sor[i];
+    const int dp = a.dp[i], adr = a.ad_ref[i], ada = a.ad_alt[i], gq = a.gq[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    auto wb = [&](int o) -> int { return (int)*(UGVC_LDS const uint8_t*)(uintptr_t)(wrow_b + (uint32_t)o); };
+    auto ref_at = [&](int d) -> int {                         // reference base at contig offset p0 + d (0 outside the contig)
+        const int o = o0 + d;
+        if (o >= 0 && o < kWinBytes) return wb(o);
+        const int64_t gi = g0 + d;
+        return (gi >= clo && gi < chi) ? (int)a.ref[gi] : 0;
+    };
+    // ---- is_hmer_indel: the run starts at the first base after the variant's alleles
+    const int d_so = ins ? 1 : rl;
+    const int so = o0 + d_so;
+    int hmer_len = 0, hmer_nuc = 0, run = 0;
+    {
+        const int bb = (int)ab[0];
+        bool mono = true;
+#pragma unroll
+        for (int q = 1; q < 8; ++q) mono &= ab[q] == (uint32_t)bb;   // clamped reads repeat the last byte
+        if (ln > 9)
+            for (int q = 9; q < ln; ++q) mono &= apool[lo_off + q] == bb;
+        const uint32_t pstart = p0 + (uint32_t)d_so;
+        if (mono && pstart < clen) {
+            if (so + 12 <= kWinBytes) {
+                int nrun = 0;
+                bool go = true;
+#pragma unroll
+                for (int q = 0; q < 12; ++q) {
+                    go = go && wb(so + q) == bb;
+                    nrun += go ? 1 : 0;
+                }
+                run = nrun;
+                if (nrun == 12)
+                    while (ref_at(d_so + run) == bb && pstart + (uint32_t)run < clen) ++run;
+            } else {
+                while (pstart + (uint32_t)run < clen && ref_at(d_so + run) == bb) ++run;
+            }
+            const uint32_t room = clen - pstart;               // an N run may not run past the contig end
+            if ((uint32_t)run > room) run = (int)room;
+            if (run > 0) {
+                hmer_len = run + (ins ? 0 : rl - 1);
+                hmer_nuc = bb;
+            }
+        }
+    }
+    const bool is_h = hmer_len > 0;
+    const int group = is_h ? 1 : 2;
+    // ---- get_motif_around (5), gc_content (10)
+    int W[11];
+#pragma unroll
+    for (int q = 0; q < 11; ++q) W[q] = wb(o0 - 5 + q);
+    if (o0 < 5) {                                              // genome start: the window begins at base 0
+#pragma unroll
+        for (int q = 0; q < 11; ++q) W[q] = ref_at(q - 5);
+    }
+    const int d_r = is_h ? d_so + run : rl;
+    int lm = 0, rm = 0;
+#pragma unroll
+    for (int q = 0; q < kMotif; ++q) {
+        const int rb = (o0 + d_r + kMotif <= kWinBytes) ? wb(o0 + d_r + q) : ref_at(d_r + q);
+        lm = lm * 5 + W[q + 1];
+        rm = rm * 5 + rb;
+    }
+    int gc_cnt = 0, gc_len = 0;
+#pragma unroll
+    for (int q = 0; q < kGcWindow; ++q) {
+        const uint32_t pw = p0 + 1 - kGcWindow / 2 + q;       // wraps below 0 -> fails the bound test
+        const bool inb = pw < clen;
+        const int bb = W[q + 1];
+        gc_len += inb;
+        gc_cnt += inb && bb != 1 && bb != 4;
+    }
+    const float gc = lds_f32(sc.gctab_b + 4u * (uint32_t)(gc_len * 11 + gc_cnt));
+
+    // ---- joins on the resident tables, inside the tile's brackets
+    const int c0 = rfl(c);
+    const bool uni = __ballot(c != c0) == 0;
+    const uint64_t key = ((uint64_t)(uint32_t)c << 32) | (uint32_t)pos;
+    JoinOut jo{false, false, false, 0u};
+    if (!(a.ablate & 524288)) {
+        int lo_[kJoin5], hi_[kJoin5], pl[kJoin5 - 1], ph[kJoin5 - 1];
+#pragma unroll
+        for (int t = 0; t < kJoin5 - 1; ++t) {
+            pl[t] = ph[t] = lo_[t] = hi_[t] = 0;
+            if (!table_present(a, t)) continue;
+            const TrackView& tv = table_view(a, t);
+            if (uni) {
+                pl[t] = cload(tv.ptr + c0);
+                ph[t] = cload(tv.ptr + c0 + 1);
+                lo_[t] = cload(v.br_indel + tile * 16 + t);
+                hi_[t] = cload(v.br_indel + tile * 16 + 8 + t);
+            } else {
+                pl[t] = tv.ptr[c];
+                ph[t] = tv.ptr[c + 1];
+                lo_[t] = pl[t];
+                hi_[t] = ph[t];
+            }
+        }
+        lo_[kJoin5 - 1] = uni ? cload(v.br_indel + tile * 16 + kJoin5 - 1) : 0;
+        hi_[kJoin5 - 1] = uni ? cload(v.br_indel + tile * 16 + 8 + kJoin5 - 1) : (int)a.n_bl;
+        join_global(a, lo_, hi_, pl, ph, pos, key, jo);
+    }
+    uint8_t flags = (uint8_t)(jo.trk << UGVC_FLAG_TRACK0_SHIFT);
+    if (jo.cohort) flags |= UGVC_FLAG_COHORT_FP;
+    if (a.mark_hpol && (jo.inside_run || jo.close_run)) flags |= UGVC_FLAG_HPOL_RUN;
+    if (live) a.flags[i] = flags;
+    const bool ok1 = v.pg[1].ok != 0, ok2 = v.pg[2].ok != 0;
+    const bool pg_ok = group == 1 ? ok1 : ok2;
+    if (live && !pg_ok) {                                      // no model for this variant type: score 0, PASS
+        a.score[i] = 0.f;
+        a.filter[i] = UGVC_FILTER_PASS;
+    }
+    // ---- record slots: one returning atomic per wave and group
+    const bool mine = live && pg_ok;
+    const unsigned long long m1 = __ballot(mine && group == 1), m2 = __ballot(mine && group == 2);
+    const int shard = (int)(tile & (kShards - 1));
+    unsigned got = 0;
+    if (lane == 1 && m1 != 0) got = atomicAdd(&v.counters[(1 * kShards + shard) * kCounterStride], (unsigned)__popcll(m1));
+    if (lane == 2 && m2 != 0) got = atomicAdd(&v.counters[(2 * kShards + shard) * kCounterStride], (unsigned)__popcll(m2));
+    const unsigned long long below = (1ull << lane) - 1;
+    const unsigned grank = (unsigned)__popcll((group == 1 ? m1 : m2) & below);
+
+    // ---- codes of the lane's own group
+    const float vaf = dp > 0 ? __fdiv_rn((float)ada, (float)dp) : 0.0f;
+    uint32_t cd[4] = {0, 0, 0, 0};
+    if (__ballot(mine) != 0) {
+        const float fx[4] = {qual, sor, vaf, gc};
+        const int fj[4] = {0, 1, 5, 13};
+        uint32_t q[4], q0[4], qend[4], len4[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const uint2 d1 = cload2(v.desc3 + 1 * kMaxFeatures + fj[s]), d2 = cload2(v.desc3 + 2 * kMaxFeatures + fj[s]);
+            const uint32_t off = (group == 1 ? d1.x : d2.x) & 0xFFFFFu;
+            len4[s] = (group == 1 ? d1.y : d2.y) & 0xFFFFu;
+            q0[s] = sc.thr_b + 4u * off - 4u;
+            q[s] = q0[s];
+            qend[s] = q0[s] + 4u * len4[s];
+        }
+        const int fbm = max(max(v.thr_bits4[0], v.thr_bits4[1]), max(v.thr_bits4[2], v.thr_bits4[3]));
+        for (int s = fbm - 1; s >= 0; --s) {
+            uint32_t cand[4];
+            float t[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                cand[e] = q[e] + (4u << s);
+                t[e] = lds_f32(cand[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q[e] = ((int32_t)(qend[e] - cand[e]) >= 0 && t[e] < fx[e]) ? cand[e] : q[e];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            cd[s] = (q[s] - q0[s]) >> 2;
+            if (fx[s] != fx[s]) cd[s] = len4[s];
+        }
+    }
+    const int* cap = group == 1 ? v.cap5[1] : v.cap5[2];
+    auto rc = [&](int f, int x) -> uint32_t { return raw_code(x, group == 1 ? v.cap5[1][f] : v.cap5[2][f]); };
+    (void)cap;
+    uint32_t r[kRec5Dwords];
+    r[0] = cd[0] | (cd[1] << 16);                                        // qual, sor
+    r[1] = rc(2, dp) | (rc(3, adr) << 16);
+    r[2] = rc(4, ada) | (cd[2] << 16);                                   // ad_alt, vaf
+    r[3] = rc(6, gq) | (rc(7, classify) << 16);
+    r[4] = rc(8, indel_length) | (rc(9, hmer_len) << 16);
+    r[5] = rc(10, hmer_nuc) | (rc(11, lm) << 16);
+    r[6] = rc(12, rm) | (cd[3] << 16);                                   // right motif, gc
+    r[7] = rc(14, 3) | ((jo.inside_run ? 2u : 1u) << 16);                // cycle skip: NA for indels
+    r[8] = (jo.close_run ? 2u : 1u) | (((jo.trk >> 0) & 1u ? 2u : 1u) << 16);
+    r[9] = ((jo.trk >> 1) & 1u ? 2u : 1u) | (((jo.trk >> 2) & 1u ? 2u : 1u) << 16);
+    r[10] = ((jo.trk >> 3) & 1u ? 2u : 1u) | (((jo.trk >> 4) & 1u ? 2u : 1u) << 16);
+    r[11] = i;
+    const unsigned b1 = __shfl(got, 1), b2 = __shfl(got, 2);
+    if (mine) {
+        uint4* dst = v.rec5[group] + ((size_t)shard * v.shard_cap5 + (group == 1 ? b1 : b2) + grank) * 3;
+        dst[0] = make_uint4(r[0], r[1], r[2], r[3]);
+        dst[1] = make_uint4(r[4], r[5], r[6], r[7]);
+        dst[2] = make_uint4(r[8], r[9], r[10], r[11]);
+    }
+}
+
+// ---- single-sum walk of one forest over the wave's code planes -> (tree_score, FILTER) -------------------
+__device__ __forceinline__ void walk_forest(const PackedGroupView& pg, uint32_t hi_b, uint32_t last_b, uint32_t p1_b,
+                                            uint32_t planes_lane_b, float& score, uint8_t& filt) {
+    const int T = pg.T, D = pg.D, H = (1 << D) >> 1;
+    double a1 = 0.0;
+    int t = 0;
+    for (; t + 8 <= T; t += 8) {
+        uint32_t pi[8];
+        walk4<8>(hi_b, last_b, planes_lane_b, t, D, H, pi);
+        double pv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pv[q] = lds_f64(p1_b + 8u * pi[q]);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a1 += pv[q];
+    }
+    for (; t < T; ++t) {
+        uint32_t pi[1];
+        walk4<1>(hi_b, last_b, planes_lane_b, t, D, H, pi);
+        a1 += lds_f64(p1_b + 8u * pi[0]);
+    }
+    const double half = 0.5 * (double)T, band = pg.band;
+    score = (float)(a1 / (double)T);
+    filt = a1 > half ? UGVC_FILTER_PASS : UGVC_FILTER_LOW_SCORE;
+    // inside the band around T/2 (rounding of the two class sums, model_pack.hip) the class-0 sum decides as
+    // scikit-learn's argmax does: redo the walk with both payload sums, in tree order (exact ties in practice)
+    if (__builtin_amdgcn_ballot_w64(fabs(a1 - half) <= band) != 0) {
+        double b0 = 0.0, b1 = 0.0;
+        for (int tt = 0; tt < T; ++tt) {
+            uint32_t pi[1];
+            walk4<1>(hi_b, last_b, planes_lane_b, tt, D, H, pi);
+            const double2 pv = pg.pairs[pi[0]];
+            b0 += pv.x; b1 += pv.y;
+        }
+        const double q0 = b0 / (double)T, q1 = b1 / (double)T;
+        if (fabs(a1 - half) <= band) filt = q1 > q0 ? UGVC_FILTER_PASS : UGVC_FILTER_LOW_SCORE;
+    }
+}
+
+// LDS of a workgroup: group forest (hi | last | p1, 16-byte padded) | thresholds | gctab | css | wave scratch
+struct Lds5 {
+    uint32_t hi_b, last_b, p1_b, thr_b, gctab_b, css_b, scratch_b;
+};
+
+__device__ __forceinline__ Lds5 lds5_fill(unsigned char* smem, const PackedGroupView& pg, bool with_forest, const float* thr, int n_thr,
+                                          const uint8_t* css_lut, int tid, int nthreads) {
+    Lds5 L;
+    size_t off = 0;
+    const size_t n_hi = with_forest ? ((size_t)pg.T << pg.D) / 2 : 0;
+    const size_t b_hi = (n_hi * 4 + 15) & ~(size_t)15, b_last = (n_hi * 8 + 15) & ~(size_t)15;
+    const size_t b_p1 = with_forest ? (((size_t)pg.n_pairs * 8 + 15) & ~(size_t)15) : 0;
+    L.hi_b = lds_addr(smem);
+    L.last_b = lds_addr(smem + b_hi);
+    L.p1_b = lds_addr(smem + b_hi + b_last);
+    off = b_hi + b_last + b_p1;
+    if (with_forest) {
+        const uint4* s0 = reinterpret_cast<const uint4*>(pg.hi4);
+        const uint4* s1 = reinterpret_cast<const uint4*>(pg.last4);
+        const uint4* s2 = reinterpret_cast<const uint4*>(pg.p1);
+        uint4* d0 = reinterpret_cast<uint4*>(smem);
+        uint4* d1 = reinterpret_cast<uint4*>(smem + b_hi);
+        uint4* d2 = reinterpret_cast<uint4*>(smem + b_hi + b_last);
+        const size_t n0 = b_hi / 16, n1 = b_last / 16, n2 = b_p1 / 16;
+        for (size_t q = tid; q < n0 + n1 + n2; q += nthreads) {
+            if (q < n0) d0[q] = s0[q];
+            else if (q < n0 + n1) d1[q - n0] = s1[q - n0];
+            else d2[q - n0 - n1] = s2[q - n0 - n1];
+        }
+    }
+    float* thr_l = reinterpret_cast<float*>(smem + off);
+    const size_t b_thr = ((size_t)n_thr * 4 + 15) & ~(size_t)15;
+    for (int q = tid; q < (n_thr + 3) / 4; q += nthreads) reinterpret_cast<float4*>(thr_l)[q] = reinterpret_cast<const float4*>(thr)[q];
+    L.thr_b = lds_addr(thr_l);
+    off += b_thr;
+    float* gct = reinterpret_cast<float*>(smem + off);
+    for (int q = tid; q < kGcTab; q += nthreads) {
+        const int len = q / 11, cnt = q % 11;
+        gct[q] = (len > 0 && len <= 10 && cnt <= len) ? (float)((double)cnt / (double)len) : 0.0f;
+    }
+    L.gctab_b = lds_addr(gct);
+    off += kGcTab * 4;
+    uint8_t* css = smem + off;
+    for (int q = tid; q < 256; q += nthreads) css[q] = css_lut[q];
+    L.css_b = lds_addr(css);
+    off += 256;
+    L.scratch_b = lds_addr(smem + off);
+    return L;
+}
+
+static size_t lds5_bytes(const PackedGroupView& pg, bool with_forest, int n_thr, int n_waves, int scratch_bytes) {
+    const size_t n_hi = with_forest ? ((size_t)pg.T << pg.D) / 2 : 0;
+    size_t b = ((n_hi * 4 + 15) & ~(size_t)15) + ((n_hi * 8 + 15) & ~(size_t)15);
+    if (with_forest) b += ((size_t)pg.n_pairs * 8 + 15) & ~(size_t)15;
+    b += ((size_t)n_thr * 4 + 15) & ~(size_t)15;
+    b += kGcTab * 4 + 256;
+    return b + (size_t)n_waves * scratch_bytes;
+}
+
+// ---- Kf: persistent, one workgroup per CU; every wave works through tiles on its own --------------------
+__global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = rfl(tid >> 6);
+    const int n_waves = blockDim.x >> 6;
+    const PackedGroupView& pg0 = v.pg[0];
+    const bool has0 = pg0.ok != 0;
+    // the thresholds of every group: SNP tiles rank against group 0's slices (the head of the table), indel
+    // tiles against their own group's
+    const Lds5 L = lds5_fill(smem, pg0, has0, v.thr, v.thr_lds_len, v.css_lut, tid, blockDim.x);
+    __syncthreads();
+    Scratch sc;
+    sc.base = L.scratch_b + (uint32_t)(wave * v.scratch_bytes);
+    sc.thr_b = L.thr_b; sc.gctab_b = L.gctab_b; sc.css_b = L.css_b;
+    const int hslot = ((lane & 31) << 1) | (lane >> 5);
+    const uint32_t planes_lane_b = sc.base + 2u * (uint32_t)hslot;
+    const int64_t ns = cload(v.tile_cnt), ni = (v.f.ablate & 262144) ? 0 : cload(v.tile_cnt + 1);
+    const int64_t stride = (int64_t)gridDim.x * n_waves;
+    // tile slots are wave-major over the workgroups: a short last round leaves a few waves busy on every CU
+    int64_t ts = (int64_t)wave * gridDim.x + blockIdx.x, ti = ts;
+    for (int it = 0; ts < ns || ti < ni; ++it) {
+        const bool do_indel = ti < ni && ((it & 3) == 3 || ts >= ns);
+        if (do_indel) {
+            const uint32_t id = v.indel_idx[ti * 64 + lane];
+            const bool live = id != ~0u;
+            const uint32_t i = live ? id : (uint32_t)rfl((int)id);
+            featurize_indel_tile(v, sc, ti, lane, i, live);
+            ti += stride;
+        } else {
+            const uint32_t id = v.snp_idx[ts * 64 + lane];
+            const bool live = id != ~0u;
+            const uint32_t i = live ? id : (uint32_t)rfl((int)id);
+            featurize_snp_tile(v, sc, ts, lane, i, live, has0);
+            if (has0) {
+                float score = 0.f;
+                uint8_t filt = UGVC_FILTER_PASS;
+                if (!(v.f.ablate & 131072)) walk_forest(pg0, L.hi_b, L.last_b, L.p1_b, planes_lane_b, score, filt);
+                if (live) {
+                    v.f.score[i] = score;
+                    v.f.filter[i] = filt;
+                }
+            } else if (live) {                                 // no model for substitutions: score 0, PASS
+                v.f.score[i] = 0.f;
+                v.f.filter[i] = UGVC_FILTER_PASS;
+            }
+            ts += stride;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- K2: the indel groups' forests over the raw-code records ---------------------------------------------
+__global__ __launch_bounds__(kK2Threads) void forest5_kernel(const V5Args v) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned shard_off[kShards + 1];
+    __shared__ unsigned totals[UGVC_N_GROUPS];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int n_waves = blockDim.x >> 6;
+    if (tid < UGVC_N_GROUPS) totals[tid] = 0;
+    __syncthreads();
+    for (int q = tid; q < UGVC_N_GROUPS * kShards; q += blockDim.x) {
+        const unsigned cshard = v.counters[q * kCounterStride];
+        if (cshard && q >= kShards) atomicAdd(&totals[q / kShards], cshard);
+    }
+    __syncthreads();
+    // workgroups are split over the two indel groups in proportion to count x trees x depth
+    const int B = gridDim.x;
+    unsigned cnt[UGVC_N_GROUPS];
+    double work[UGVC_N_GROUPS], tot = 0.0;
+    cnt[0] = 0; work[0] = 0.0;
+    for (int g = 1; g < UGVC_N_GROUPS; ++g) {
+        cnt[g] = v.pg[g].ok ? totals[g] : 0u;
+        work[g] = (double)cnt[g] * v.pg[g].T * v.pg[g].D;
+        tot += work[g];
+    }
+    if (tot == 0.0) return;
+    int nb[UGVC_N_GROUPS] = {0, 0, 0}, used = 0, big = 1;
+    for (int g = 1; g < UGVC_N_GROUPS; ++g) {
+        nb[g] = cnt[g] ? (int)(B * (work[g] / tot) + 0.5) : 0;
+        if (cnt[g] && nb[g] < 1) nb[g] = 1;
+        used += nb[g];
+        if (work[g] > work[big]) big = g;
+    }
+    nb[big] += B - used;
+    if (nb[big] < 1) return;
+    int g = 1, lb = blockIdx.x;
+    while (g < UGVC_N_GROUPS - 1 && lb >= nb[g]) { lb -= nb[g]; ++g; }
+    g = rfl(g);
+    lb = rfl(lb);
+    const int nbg = rfl(nb[g]);
+    const PackedGroupView pg = v.pg[g];
+    const unsigned n = (unsigned)rfl((int)cnt[g]);
+    if (n == 0 || nbg == 0) return;
+    if (wave == 0) {                                             // exclusive scan of the group's shard counts
+        unsigned x[4], s = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { x[q] = v.counters[(g * kShards + lane * 4 + q) * kCounterStride]; s += x[q]; }
+        unsigned incl = s;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned y = __shfl_up(incl, d);
+            if (lane >= d) incl += y;
+        }
+        unsigned runv = incl - s;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { shard_off[lane * 4 + q] = runv; runv += x[q]; }
+        if (lane == 63) shard_off[kShards] = runv;
+    }
+    const int D = pg.D, H = (1 << D) >> 1;
+    const size_t n_hi = (size_t)pg.T * H;
+    const size_t b_hi = (n_hi * 4 + 15) & ~(size_t)15, b_last = (n_hi * 8 + 15) & ~(size_t)15;
+    const size_t b_p1 = ((size_t)pg.n_pairs * 8 + 15) & ~(size_t)15;
+    {
+        const uint4* s0 = reinterpret_cast<const uint4*>(pg.hi4);
+        const uint4* s1 = reinterpret_cast<const uint4*>(pg.last4);
+        const uint4* s2 = reinterpret_cast<const uint4*>(pg.p1);
+        uint4* d0 = reinterpret_cast<uint4*>(smem);
+        uint4* d1 = reinterpret_cast<uint4*>(smem + b_hi);
+        uint4* d2 = reinterpret_cast<uint4*>(smem + b_hi + b_last);
+        const size_t n0 = b_hi / 16, n1 = b_last / 16, n2 = b_p1 / 16;
+        for (size_t q = tid; q < n0 + n1 + n2; q += blockDim.x) {
+            if (q < n0) d0[q] = s0[q];
+            else if (q < n0 + n1) d1[q - n0] = s1[q - n0];
+            else d2[q - n0 - n1] = s2[q - n0 - n1];
+        }
+    }
+    __syncthreads();
+    const uint32_t hi_b = lds_addr(smem), last_b = lds_addr(smem + b_hi), p1_b = lds_addr(smem + b_hi + b_last);
+    const int hslot = ((lane & 31) << 1) | (lane >> 5);
+    const uint32_t planes_b = lds_addr(smem + b_hi + b_last + b_p1) + (uint32_t)(wave * kMaxFeatures * 128);
+    const uint32_t planes_lane_b = planes_b + 2u * (uint32_t)hslot;
+    const unsigned waves = (unsigned)nbg * n_waves;
+    const uint4* __restrict__ rec = v.rec5[g];
+    auto fetch = [&](unsigned chunk, bool& live, uint4& r0, uint4& r1, uint4& r2) {
+        const unsigned r = chunk * 64 + lane;
+        live = r < n;
+        const unsigned rr = live ? r : n - 1;
+        int lo = 0, len = kShards;
+        while (len > 1) {                                        // shard of record rr
+            const int half = len >> 1;
+            const bool ge = shard_off[lo + half] <= rr;
+            lo = ge ? lo + half : lo;
+            len = ge ? len - half : half;
+        }
+        const uint4* src = rec + ((size_t)lo * v.shard_cap5 + (rr - shard_off[lo])) * 3;
+        r0 = src[0]; r1 = src[1]; r2 = src[2];
+    };
+    unsigned chunk = (unsigned)rfl(wave) * (unsigned)nbg + (unsigned)lb;
+    bool live_next = false;
+    uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0, n2 = n0;
+    if ((uint64_t)chunk * 64 < n) fetch(chunk, live_next, n0, n1, n2);
+    for (; (uint64_t)chunk * 64 < n; chunk += waves) {
+        const uint4 q0 = n0, q1 = n1, q2 = n2;
+        const bool live = live_next;
+        if ((uint64_t)(chunk + waves) * 64 < n) fetch(chunk + waves, live_next, n0, n1, n2);
+        const uint32_t w[11] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z};
+        // record dword d holds the codes of two features (kRecFeat); one 16-bit store per plane
+        const int feat_lo[11] = {0, 2, 4, 6, 8, 10, 12, 14, 16, 18, 20};
+        const int feat_hi[11] = {1, 3, 5, 7, 9, 11, 13, 15, 17, 19, 21};
+#pragma unroll
+        for (int d = 0; d < 11; ++d) {
+            if (feat_lo[d] < kMaxFeatures) *(UGVC_LDS uint16_t*)(uintptr_t)(planes_lane_b + 128u * feat_lo[d]) = (uint16_t)(w[d] & 0xFFFFu);
+            if (feat_hi[d] < kMaxFeatures) *(UGVC_LDS uint16_t*)(uintptr_t)(planes_lane_b + 128u * feat_hi[d]) = (uint16_t)(w[d] >> 16);
+        }
+        float score;
+        uint8_t filt;
+        walk_forest(pg, hi_b, last_b, p1_b, planes_lane_b, score, filt);
+        if (live) {
+            v.f.score[q2.w] = score;
+            v.f.filter[q2.w] = filt;
+        }
+    }
+}
+
+static size_t k5_forest_lds(const PackedGroupView& pg, int n_waves) {
+    const size_t n_hi = ((size_t)pg.T << pg.D) / 2;
+    return ((n_hi * 4 + 15) & ~(size_t)15) + ((n_hi * 8 + 15) & ~(size_t)15) + (((size_t)pg.n_pairs * 8 + 15) & ~(size_t)15) +
+           (size_t)n_waves * kMaxFeatures * 128;
+}
+
+// LDS budget of the fused kernel for this configuration: 16, 12 or 8 waves of scratch beside the SNP forest
+int v5_fused_waves(const V5Args& v) {
+    for (int w : {16, 12, 8}) {
+        if (lds5_bytes(v.pg[0], v.pg[0].ok != 0, v.thr_lds_len, w, v.scratch_bytes) + 1024 <= 160 * 1024) return w;
+    }
+    return 0;
+}
+
+int launch_filter_v5(ugvc_ctx* ctx, const FilterArgs& a) {
+    if (a.n == 0) return 0;
+    V5Args v;
+    if (v5_fill_args(ctx, v, a)) return -1;
+    using K = void (*)(const V5Args);
+    static bool attr_set = false;
+    if (!attr_set) {
+        for (K f : {(K)fused5_kernel, (K)forest5_kernel})
+            UGVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+        attr_set = true;
+    }
+    UGVC_HIP(hipMemsetAsync(v.tile_cnt, 0, 16, ctx->stream));
+    hipLaunchKernelGGL(compact5_kernel, dim3((unsigned)v.n_cblocks), dim3(kCBlock5), 0, ctx->stream, v);
+    const int64_t nbr = ((int64_t)v.max_tiles + 1) * 16;        // >= 8 x SNP tiles + 16 x indel tiles
+    hipLaunchKernelGGL(bracket5_kernel, dim3((unsigned)((nbr + 255) / 256)), dim3(256), 0, ctx->stream, v);
+    const size_t lds_f = lds5_bytes(v.pg[0], v.pg[0].ok != 0, v.thr_lds_len, v.n_waves, v.scratch_bytes);
+    hipLaunchKernelGGL(fused5_kernel, dim3((unsigned)ctx->n_cus), dim3(v.n_waves * 64), lds_f, ctx->stream, v);
+    if (!(a.ablate & 262144) && (v.pg[1].ok || v.pg[2].ok)) {
+        int n_waves = 0;
+        size_t lds = 0;
+        for (int w : {16, 12, 8, 4}) {
+            size_t need = 0;
+            for (int g = 1; g < UGVC_N_GROUPS; ++g)
+                if (v.pg[g].ok) need = std::max(need, k5_forest_lds(v.pg[g], w));
+            if (need + 2048 <= 160 * 1024) { n_waves = w; lds = need; break; }
+        }
+        if (n_waves == 0) return fail("internal: packed forest does not fit LDS");
+        hipLaunchKernelGGL(forest5_kernel, dim3((unsigned)ctx->n_cus), dim3(n_waves * 64), lds, ctx->stream, v);
+    }
+    UGVC_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace ugvc

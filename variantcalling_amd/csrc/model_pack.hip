@@ -18,6 +18,11 @@ struct V2Group {
     std::vector<uint16_t> leaf_idx;
     std::vector<double> pairs;
     std::vector<float> leaf_f32;
+    std::vector<uint32_t> hi5, last5;   // v5: raw-code node tables in the single-sum layout
+    int cap5[kMaxFeatures];
+    uint32_t used5 = 0;
+    bool ok5 = false;
+    DeviceBuf d_hi5, d_last5;
     std::vector<uint32_t> hi4;          // single-sum layout (ugvc_v2.hpp)
     std::vector<uint32_t> last4;        // 2 dwords per entry
     std::vector<double> p1;
@@ -39,6 +44,9 @@ struct V2Group {
 struct V2State {
     V2Group g[UGVC_N_GROUPS];
     DeviceBuf desc, desc3, lut, thr, css, brackets, brackets3, counters, prof;
+    DeviceBuf snp_idx, indel_idx, tile_cnt, tile_n, br_snp, br_indel, rec5[UGVC_N_GROUPS];   // v5
+    int thr0_len = 0, thr0_bits4[4] = {0, 0, 0, 0};
+    std::vector<uint2> h_desc3;
     int thr_bits4[4] = {0, 0, 0, 0};        // descent depth per float feature (qual, sor, vaf, gc), max over groups
     bool uniform_layout = false;            // every group uses the same dword per feature; booleans in fixed slots
     int dw3[kMaxFeatures];                  // that dword
@@ -57,17 +65,19 @@ static V2State* state(ugvc_ctx* ctx) {
 void v2_destroy(ugvc_ctx* ctx) {
     if (!ctx->v2) return;
     V2State* s = static_cast<V2State*>(ctx->v2);
-    DeviceBuf* bufs[] = {&s->desc, &s->desc3, &s->lut, &s->thr, &s->css, &s->brackets, &s->brackets3, &s->counters, &s->prof};
+    DeviceBuf* bufs[] = {&s->desc, &s->desc3, &s->lut, &s->thr, &s->css, &s->brackets, &s->brackets3, &s->counters, &s->prof,
+                         &s->snp_idx, &s->indel_idx, &s->tile_cnt, &s->tile_n, &s->br_snp, &s->br_indel};
     for (auto* b : bufs) if (b->p) (void)hipFree(b->p);
     for (auto& r : s->rec) if (r.p) (void)hipFree(r.p);
+    for (auto& r : s->rec5) if (r.p) (void)hipFree(r.p);
     for (auto& g : s->g)
-        for (DeviceBuf* b : {&g.d_nodes, &g.d_leaf_idx, &g.d_pairs, &g.d_leaf_f32, &g.d_plane_desc, &g.d_hi4, &g.d_last4, &g.d_p1}) if (b->p) (void)hipFree(b->p);
+        for (DeviceBuf* b : {&g.d_nodes, &g.d_leaf_idx, &g.d_pairs, &g.d_leaf_f32, &g.d_plane_desc, &g.d_hi4, &g.d_last4, &g.d_p1, &g.d_hi5, &g.d_last5}) if (b->p) (void)hipFree(b->p);
     delete s;
     ctx->v2 = nullptr;
 }
 
 static void release_group(V2Group& g) {          // device tables of the previous model of this group, then a clean slate
-    for (DeviceBuf* b : {&g.d_nodes, &g.d_leaf_idx, &g.d_pairs, &g.d_leaf_f32, &g.d_plane_desc, &g.d_hi4, &g.d_last4, &g.d_p1})
+    for (DeviceBuf* b : {&g.d_nodes, &g.d_leaf_idx, &g.d_pairs, &g.d_leaf_f32, &g.d_plane_desc, &g.d_hi4, &g.d_last4, &g.d_p1, &g.d_hi5, &g.d_last5})
         if (b->p) (void)hipFree(b->p);
     g = V2Group();
 }
@@ -215,6 +225,55 @@ static bool pack_group(V2Group& g) {
     return true;
 }
 
+// ---- v5 node tables: raw 16-bit codes for the integer-valued features (ugvc_v2.hpp) -----------
+static void fill_dense5(const V2Group& g, std::vector<uint32_t>& nodes5, int t, int src, int idx) {
+    if (g.feature[src] < 0) return;
+    const int f = g.feature[src];
+    uint32_t rank;
+    if (search_only_feature(f)) {
+        const auto& u = g.uthr[f];
+        rank = (uint32_t)(std::lower_bound(u.begin(), u.end(), g.threshold[src]) - u.begin());
+    } else {
+        rank = (uint32_t)std::floor((double)g.threshold[src]) + 1u;      // code > rank <=> x > thr for integer x >= 0
+    }
+    nodes5[((size_t)t << g.D) + idx] = rank | ((uint32_t)(f * 128) << 16);
+    fill_dense5(g, nodes5, t, g.left[src], 2 * idx);
+    fill_dense5(g, nodes5, t, g.right[src], 2 * idx + 1);
+}
+
+static bool pack_group5(V2Group& g) {
+    g.ok5 = false;
+    g.used5 = 0;
+    for (int f = 0; f < kMaxFeatures; ++f) g.cap5[f] = 0;
+    if (!g.ok || g.kind != UGVC_MODEL_RF || !g.fast4) return false;
+    for (int f = 0; f < kMaxFeatures; ++f) {
+        if (g.uthr[f].empty()) continue;
+        g.used5 |= 1u << f;
+        if (search_only_feature(f)) continue;
+        const double lo = g.uthr[f].front(), hi = g.uthr[f].back();
+        if (!(lo >= 0.0) || !(hi < 65533.0)) return false;      // negative / huge / NaN thresholds: the rank-table paths
+        g.cap5[f] = (int)std::floor(hi) + 1;
+    }
+    const int D = g.D, T = g.T;
+    const size_t H = (size_t)1 << (D - 1);
+    std::vector<uint32_t> nodes5((size_t)T << D, 0xFFFFu);      // padded node: rank 65535 on plane 0 -> always left
+    for (int t = 0; t < T; ++t) fill_dense5(g, nodes5, t, g.roots[t], 1);
+    g.hi5.assign((size_t)T * H, 0xFFFFu);
+    g.last5.assign((size_t)T * H * 2, 0u);
+    for (int t = 0; t < T; ++t) {
+        for (size_t i = 1; i < H; ++i) g.hi5[(size_t)t * H + i] = nodes5[((size_t)t << D) + i];
+        for (size_t e = 0; e < H; ++e) {
+            g.last5[2 * ((size_t)t * H + e)] = nodes5[((size_t)t << D) + H + e];
+            g.last5[2 * ((size_t)t * H + e) + 1] = (uint32_t)g.leaf_idx[((size_t)t << D) + 2 * e] |
+                                                  ((uint32_t)g.leaf_idx[((size_t)t << D) + 2 * e + 1] << 16);
+        }
+    }
+    g.hi5.resize((g.hi5.size() + 3) & ~(size_t)3, 0xFFFFu);
+    g.last5.resize((g.last5.size() + 3) & ~(size_t)3, 0u);
+    g.ok5 = true;
+    return true;
+}
+
 static int count_code(const V2Group& g, int f, float v) {   // rank code of value v for feature f
     const auto& u = g.uthr[f];
     if (g.kind == UGVC_MODEL_RF) return (int)(std::lower_bound(u.begin(), u.end(), v) - u.begin());
@@ -296,11 +355,15 @@ int finalize_pack(ugvc_ctx* ctx) {
             if (search_only_feature(f)) desc3[(size_t)gi * kMaxFeatures + f] = make_uint2(0u, 0u);   // empty threshold slice
     for (auto& g : s->g)
         if (g.set && !pack_group(g)) { all_ok = false; s->why = g.why; }
+    for (auto& g : s->g)
+        if (g.set) pack_group5(g);
     if (all_ok) {
         // threshold table: search-only features of every group first (that prefix is staged in LDS)
-        for (int pass = 0; pass < 2; ++pass)
+        s->thr0_len = s->thr_lds_len = 0;
+        for (int pass = 0; pass < 2; ++pass) {
             for (int gi = 0; gi < UGVC_N_GROUPS; ++gi) {
                 V2Group& g = s->g[gi];
+                if (pass == 0 && gi == 1) s->thr0_len = (int)thr.size();      // group 0's float slices lead the table
                 if (!g.set) continue;
                 for (int f = 0; f < kMaxFeatures; ++f) {
                     if (g.uthr[f].empty() || search_only_feature(f) != (pass == 0)) continue;
@@ -327,8 +390,10 @@ int finalize_pack(ugvc_ctx* ctx) {
                         d3 = make_uint2((d.lut & 0xFFFFFu) | ((top + 2.0 <= 8192.0 ? 3u : 1u) << 30), (uint32_t)len | pk3);
                     }
                 }
-                if (pass == 0 && gi == UGVC_N_GROUPS - 1) s->thr_lds_len = (int)thr.size();
             }
+            // (a group without a model must not leave the previous configuration's length behind)
+            if (pass == 0) s->thr_lds_len = (int)thr.size();
+        }
         if (thr.size() >= (1u << 20) || lut.size() >= (1u << 20)) { all_ok = false; s->why = "code tables too large"; }
     }
     if (all_ok) {
@@ -336,6 +401,12 @@ int finalize_pack(ugvc_ctx* ctx) {
         if (upload(ctx, s->desc, desc.data(), desc.size() * sizeof(FeatDesc))) return -1;
         if (upload(ctx, s->desc3, desc3.data(), desc3.size() * sizeof(uint2))) return -1;
         for (int k = 0; k < 4; ++k) s->thr_bits4[k] = thr_bits4[k];
+        s->h_desc3 = desc3;
+        for (int k = 0; k < 4; ++k) {
+            const int f = k == 0 ? 0 : (k == 1 ? 1 : (k == 2 ? 5 : 13));
+            const int m = s->g[0].set ? (int)s->g[0].uthr[f].size() : 0;
+            s->thr0_bits4[k] = m > 0 ? 32 - __builtin_clz((unsigned)m) : 0;
+        }
         if (upload(ctx, s->lut, lut.data(), lut.size() * 2)) return -1;
         thr.resize((thr.size() + 3) & ~(size_t)3, 0.f);          // K1 copies the LDS-resident prefix as float4
         if (upload(ctx, s->thr, thr.data(), thr.size() * 4)) return -1;
@@ -353,6 +424,10 @@ int finalize_pack(ugvc_ctx* ctx) {
                 if (upload(ctx, g.d_hi4, g.hi4.data(), g.hi4.size() * 4)) return -1;
                 if (upload(ctx, g.d_last4, g.last4.data(), g.last4.size() * 4)) return -1;
                 if (upload(ctx, g.d_p1, g.p1.data(), g.p1.size() * 8)) return -1;
+                if (g.ok5) {
+                    if (upload(ctx, g.d_hi5, g.hi5.data(), g.hi5.size() * 4)) return -1;
+                    if (upload(ctx, g.d_last5, g.last5.data(), g.last5.size() * 4)) return -1;
+                }
             } else if (upload(ctx, g.d_leaf_f32, g.leaf_f32.data(), g.leaf_f32.size() * 4)) return -1;
         }
         UGVC_HIP(hipStreamSynchronize(ctx->stream));
@@ -472,8 +547,6 @@ int v2_fill_args(ugvc_ctx* ctx, V2Args& v, int64_t n, int n_tiles) {
     v.na3[kJoin3 - 1] = (int)ctx->n_bl;
     if (ensure(s->prof, 64)) return -1;
     v.prof = s->prof.as<unsigned long long>();
-    v.tiles4 = ctx->v_tiles.as<int2>();
-    v.bl_ptr = ctx->bl_ptr.as<int32_t>();
     return 0;
 }
 
@@ -511,9 +584,115 @@ int gemm_model(ugvc_ctx* ctx, int group, std::vector<float2>& nodes, std::vector
     return 0;
 }
 
-bool v4_available(ugvc_ctx* ctx) {
-    return ctx->n_tiles4 > 0 && ctx->n < ((int64_t)1 << 31) && (ctx->n_bl == 0 || ctx->bl_ptr.p != nullptr) &&
-           ctx->n_bl <= std::numeric_limits<int32_t>::max();
+int v5_fused_waves(const V5Args& v);
+
+// Everything the v5 launches need for the resident variants: node tables, index lists, brackets, record lists,
+// and the LDS layout of a wave's staged side-table slices (capacities follow the tables' densities).
+int v5_fill_args(ugvc_ctx* ctx, V5Args& v, const FilterArgs& a) {
+    V2State* s = state(ctx);
+    if (!s->css.p && build_css_lut(ctx)) return -1;
+    v = V5Args{};
+    v.f = a;
+    const int64_t n = a.n;
+    for (int gi = 0; gi < UGVC_N_GROUPS; ++gi) {
+        const V2Group& g = s->g[gi];
+        PackedGroupView& p = v.pg[gi];
+        p = PackedGroupView{};
+        v.used5[gi] = 0;
+        for (int f = 0; f < kMaxFeatures; ++f) v.cap5[gi][f] = 0;
+        if (!g.set || !g.ok5) continue;
+        p.ok = 1; p.kind = g.kind; p.T = g.T; p.D = g.D; p.base = g.base; p.n_pairs = g.n_pairs;
+        p.n_planes = kMaxFeatures;
+        p.pairs = g.d_pairs.as<double2>();
+        p.fast4 = 1;
+        p.band = g.band4;
+        p.hi4 = g.d_hi5.as<uint32_t>();
+        p.last4 = g.d_last5.as<uint2>();
+        p.p1 = g.d_p1.as<double>();
+        v.used5[gi] = g.used5;
+        for (int f = 0; f < kMaxFeatures; ++f) v.cap5[gi][f] = g.cap5[f];
+    }
+    v.thr = s->thr.as<float>();
+    v.desc3 = s->desc3.as<uint2>();
+    v.thr_lds_len = s->thr_lds_len;
+    v.thr0_len = s->thr0_len;
+    for (int k = 0; k < 4; ++k) { v.thr_bits4[k] = s->thr_bits4[k]; v.thr0_bits4[k] = s->thr0_bits4[k]; }
+    v.css_lut = s->css.as<uint8_t>();
+    v.n_cblocks = (int)((n + kCBlock5 - 1) / kCBlock5);
+    v.max_tiles = (int)((n + kTile5 - 1) / kTile5) + v.n_cblocks + 1;
+    v.shard_cap5 = ((v.max_tiles + kShards - 1) / kShards) * kTile5;
+    if (ensure(s->snp_idx, (size_t)v.max_tiles * kTile5 * 4) || ensure(s->indel_idx, (size_t)v.max_tiles * kTile5 * 4)) return -1;
+    if (ensure(s->tile_cnt, 64) || ensure(s->tile_n, (size_t)v.max_tiles * 2 + 64)) return -1;
+    if (ensure(s->br_snp, (size_t)v.max_tiles * 8 * 4) || ensure(s->br_indel, (size_t)v.max_tiles * 16 * 4)) return -1;
+    if (ensure(s->counters, (size_t)UGVC_N_GROUPS * kShards * kCounterStride * 4)) return -1;
+    v.snp_idx = s->snp_idx.as<uint32_t>();
+    v.indel_idx = s->indel_idx.as<uint32_t>();
+    v.tile_cnt = s->tile_cnt.as<uint32_t>();
+    v.tile_n = s->tile_n.as<uint8_t>();
+    v.br_snp = s->br_snp.as<int32_t>();
+    v.br_indel = s->br_indel.as<int32_t>();
+    v.counters = s->counters.as<uint32_t>();
+    for (int gi = 1; gi < UGVC_N_GROUPS; ++gi) {
+        v.rec5[gi] = nullptr;
+        if (!v.pg[gi].ok) continue;
+        if (ensure(s->rec5[gi], (size_t)kShards * v.shard_cap5 * kRec5Dwords * 4)) return -1;
+        v.rec5[gi] = s->rec5[gi].as<uint4>();
+    }
+    // staged slice of table t in the SNP path: the rows a tile of 64 substitutions can touch - about 96 consecutive
+    // variants' worth at a WGS class mix - twice over, as a power of two; a tile that needs more searches HBM
+    for (int t = 0; t < kJoin5; ++t) v.na[t] = v.jcap[t] = v.joff[t] = 0;
+    v.na[0] = ctx->has_runs ? (int)ctx->runs_n : 0;
+    for (int t = 0; t < ctx->n_tracks; ++t) v.na[1 + t] = (int)ctx->trk_n[t];
+    v.na[kJoin5 - 1] = (int)ctx->n_bl;
+    const int budget = 1024;                                  // dwords of a wave's scratch for the slices
+    for (int shrink = 0;; ++shrink) {
+        int used = 0;
+        for (int t = 0; t < kJoin5; ++t) {
+            const bool present = t == kJoin5 - 1 ? ctx->n_bl > 0 : (t == 0 ? ctx->has_runs != 0 : t - 1 < ctx->n_tracks);
+            v.jcap[t] = 0;
+            if (!present) continue;
+            const double per_tile = (double)v.na[t] / (double)std::max<int64_t>(n, 1) * 96.0;
+            int cap = 16;
+            while (cap < 512 && cap < 2.0 * per_tile + 8.0) cap <<= 1;
+            cap = std::max(16, cap >> shrink);
+            v.jcap[t] = cap;
+            v.joff[t] = used;
+            used += 2 * cap;                                  // starts + ends, or 8-byte keys
+        }
+        if (used <= budget || shrink >= 5) break;
+    }
+    {
+        int used = 0;
+        for (int t = 0; t < kJoin5; ++t) used = std::max(used, v.joff[t] + 2 * v.jcap[t]);
+        v.scratch_bytes = std::max({used * 4, kTile5 * 13 * 4 /* 48-byte window rows, stride 13 dwords */, kMaxFeatures * 128});
+        v.scratch_bytes = (v.scratch_bytes + 63) & ~63;
+    }
+    v.n_waves = v5_fused_waves(v);
+    if (v.n_waves == 0) return fail("internal: the SNP forest does not fit the fused kernel's LDS");
+    return 0;
+}
+
+bool v5_available(ugvc_ctx* ctx) {
+    V2State* s = state(ctx);
+    if (!v2_available(ctx)) return false;
+    bool any = false;
+    for (auto& g : s->g) {
+        if (!g.set) continue;
+        if (!g.ok5) return false;                             // pair-sum forests, XGBoost-style ensembles, odd thresholds: v3
+        any = true;
+    }
+    if (!any) return false;
+    if (s->thr_lds_len > kThr3) return false;
+    if (ctx->has_runs && !ctx->runs_fast) return false;
+    for (int t = 0; t < ctx->n_tracks; ++t)
+        if (!ctx->trk_fast[t]) return false;
+    if (ctx->n >= ((int64_t)1 << 31) - 4 * kCBlock5 || ctx->n_bl >= ((int64_t)1 << 31)) return false;
+    // LDS: group 0's forest + the thresholds + at least 8 waves of scratch
+    const V2Group& g0 = s->g[0];
+    size_t forest = 0;
+    if (g0.set) forest = ((size_t)g0.T << g0.D) / 2 * 12 + (size_t)g0.n_pairs * 8 + 64;
+    if (forest + (size_t)s->thr_lds_len * 4 + 1024 + 8 * 4160 + 1024 > 160 * 1024) return false;
+    return true;
 }
 
 bool v3_available(ugvc_ctx* ctx) {

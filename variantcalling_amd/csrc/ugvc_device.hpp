@@ -47,7 +47,7 @@ struct TrackView {
 
 struct FilterArgs {
     int64_t n;
-    const uint8_t* contig;
+    const uint16_t* contig;
     const int32_t* pos;
     const uint16_t* ref_len;
     const uint16_t* alt_len;
@@ -109,7 +109,7 @@ struct ugvc_ctx {
     int64_t runs_n = 0, trk_n[UGVC_MAX_TRACKS] = {0, 0, 0, 0, 0};
     // v3 needs: runs disjoint and sorted; tracks with non-decreasing starts AND ends per contig
     int runs_fast = 1, trk_fast[UGVC_MAX_TRACKS] = {1, 1, 1, 1, 1};
-    ugvc::DeviceBuf bl, bl_ptr, bl_c;  // bl_ptr: first key of every contig id 0..256 (v4 kernel); bl_c: every 64th key
+    ugvc::DeviceBuf bl, bl_c;          // bl_c: every 64th key
     int64_t n_bl = 0;
     uint8_t flow[4] = {4, 3, 2, 1};   // TGCA
     struct Model {
@@ -123,8 +123,6 @@ struct ugvc_ctx {
         v_adr, v_ada, v_gq;
     ugvc::DeviceBuf r_score, r_filter, r_flags, x_mat, x_group;
     int scored = 0;                    // the resident result columns hold a scoring pass over the resident variants
-    ugvc::DeviceBuf v_tiles;           // v4 kernel: int2 {first variant, count | contig << 16} per single-contig tile
-    int n_tiles4 = 0;
     // pileup
     int64_t pl_n = 0, pl_obs = 0;
     ugvc::DeviceBuf pl_off, pl_obsb, pl_out;

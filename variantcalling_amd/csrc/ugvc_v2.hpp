@@ -79,10 +79,51 @@ struct V2Args {
     int32_t* brackets3;           // [(n_blocks + 1)][8]
     int na3[8];                   // lengths of the searched arrays
     unsigned long long* prof;     // 8 phase-clock accumulators (profiling aid), or null
-    // v4
-    const int2* tiles4;           // {first variant, count | contig << 16}
-    const int32_t* bl_ptr;        // blacklist CSR by contig id
 };
+
+// ---- v5 (kernels_v5.hip) ---------------------------------------------------------------------
+// Codes are 16-bit values addressed by FEATURE index (plane f = feature f, 128 bytes per wave):
+//   * float features (qual, sor, vaf, gc): rank among the group's sorted thresholds, as above;
+//   * every other feature is a non-negative integer: code(x) = x < 0 ? 0 : min(x, cap) + 1 with
+//     cap = floor(largest threshold) + 1, node rank = floor(thr) + 1, so code > rank <=> x > thr (exact) and
+//     no code table is needed - one clamp per feature.
+// Node word = rank[0:16) | (f * 128)[16:32); forests in the single-sum layout (hi / last / p1).
+constexpr int kRec5Dwords = 12;               // raw record: 20 codes (u16, by feature) | pad | variant index (dword 11)
+constexpr int kTile5 = 64;                    // variants per tile = one wave
+constexpr int kCBlock5 = 1024;                // variants per compaction workgroup
+constexpr int kJoin5 = UGVC_MAX_TRACKS + 2;   // runs, tracks, blacklist
+
+struct V5Args {
+    FilterArgs f;
+    PackedGroupView pg[UGVC_N_GROUPS];   // hi4 / last4 hold the raw-code node tables; n_planes = kMaxFeatures
+    const float* thr;                    // float-feature thresholds, group 0's four slices first
+    const uint2* desc3;                  // [3][kMaxFeatures] {off, len | ...} of the float slices
+    int thr_lds_len;                     // floats staged by the indel path (all groups)
+    int thr0_len;                        // floats of group 0 (prefix of thr)
+    int thr_bits4[4];                    // descent depth over all groups
+    int thr0_bits4[4];                   // descent depth, group 0
+    int cap5[UGVC_N_GROUPS][kMaxFeatures];
+    uint32_t used5[UGVC_N_GROUPS];       // features a group's forest tests
+    const uint8_t* css_lut;
+    uint32_t* snp_idx;                   // tiles of 64 variant indices, ~0u = padding
+    uint32_t* indel_idx;
+    uint32_t* tile_cnt;                  // [0] SNP tiles, [1] indel tiles (zeroed before every pass)
+    uint8_t* tile_n;                     // real entries per tile: [0, max_tiles) SNP, [max_tiles, 2 max_tiles) indel
+    int32_t* br_snp;                     // [max_tiles][8]  lower bounds of the tile's first variant
+    int32_t* br_indel;                   // [max_tiles][16] + lower bounds of its last variant
+    uint4* rec5[UGVC_N_GROUPS];
+    uint32_t* counters;                  // [UGVC_N_GROUPS][kShards] x kCounterStride
+    int shard_cap5;
+    int jcap[kJoin5];                    // staged elements per table in the SNP path (power of two; 0 = absent)
+    int joff[kJoin5];                    // dword offset of the staged starts (ends follow at + jcap); keys: 2 dwords each
+    int na[kJoin5];                      // table lengths
+    int max_tiles;
+    int n_cblocks;
+    int scratch_bytes;                   // per-wave LDS scratch of the fused kernel
+    int n_waves;
+};
+
+int v5_fill_args(ugvc_ctx* ctx, V5Args& v, const FilterArgs& a);
 
 int pack_model_group(ugvc_ctx* ctx, int g, const int32_t* feature, const float* threshold,
                      const int32_t* left, const int32_t* right, int n_nodes, const int32_t* tree_root,
@@ -92,11 +133,10 @@ int clear_model_group(ugvc_ctx* ctx, int g);
 int finalize_pack(ugvc_ctx* ctx);
 int build_css_lut(ugvc_ctx* ctx);
 bool v2_available(ugvc_ctx* ctx);
-int launch_filter_v2(ugvc_ctx* ctx, const FilterArgs& a);
 int launch_filter_v3(ugvc_ctx* ctx, const FilterArgs& a);
-int launch_filter_v4(ugvc_ctx* ctx, const FilterArgs& a);
+int launch_filter_v5(ugvc_ctx* ctx, const FilterArgs& a);
+bool v5_available(ugvc_ctx* ctx);
 int launch_forest3(ugvc_ctx* ctx, const V2Args& v, const FilterArgs& a);
-bool v4_available(ugvc_ctx* ctx);
 int v2_fill_args(ugvc_ctx* ctx, V2Args& v, int64_t n, int n_tiles = 0);
 bool v3_available(ugvc_ctx* ctx);
 void v2_destroy(ugvc_ctx* ctx);

@@ -325,7 +325,8 @@ struct ugvc_vcf {
     std::string header_joined;
     int64_t n = 0;
     // table order
-    std::vector<uint8_t> contig, gq, gt, has_id, alleles;
+    std::vector<uint16_t> contig;
+    std::vector<uint8_t> gq, gt, has_id, alleles;
     std::vector<int32_t> pos, dp, ad_ref, ad_alt, filter_len;
     std::vector<uint16_t> ref_len, alt_len;
     std::vector<uint32_t> ref_off, alt_off;
@@ -337,7 +338,8 @@ struct ugvc_vcf {
 namespace {
 
 struct Parsed {                              // file order
-    std::vector<uint8_t> contig, gq, gt, has_id;
+    std::vector<uint16_t> contig;
+    std::vector<uint8_t> gq, gt, has_id;
     std::vector<int32_t> pos, dp, adr, ada;
     std::vector<float> qual, sor, tlod;
     std::vector<Span> ref, alt, filt;
@@ -379,7 +381,7 @@ bool parse_record(const char* base, Span line, int64_t k, const std::unordered_m
         err = path + ": contig '" + std::string(base + f[0].off, (size_t)f[0].len) + "' is not in the reference";
         return false;
     }
-    P.contig[k] = (uint8_t)it->second;
+    P.contig[k] = (uint16_t)it->second;
     int64_t pv;
     if (!parse_int(base + f[1].off, f[1].len, pv) || pv < INT32_MIN || pv > INT32_MAX) {
         err = path + ": record " + std::to_string(k + 1) + ": POS '" + std::string(base + f[1].off, (size_t)f[1].len) + "' is not an integer";
@@ -643,7 +645,7 @@ int write_tbi(const ugvc_vcf* h, const char* out_path, const std::vector<int64_t
 extern "C" {
 
 const char* ugvc_vcf_last_error(void) { return g_err.c_str(); }
-int ugvc_vcf_abi_version(void) { return 1; }
+int ugvc_vcf_abi_version(void) { return 2; }   // 2: contig column u16
 int ugvc_vcf_format_f32(float x, char* buf, int cap) { return buf ? format_f32(x, buf, cap) : -1; }
 
 void ugvc_vcf_free(ugvc_vcf* h) { delete h; }
@@ -651,7 +653,7 @@ void ugvc_vcf_free(ugvc_vcf* h) { delete h; }
 int ugvc_vcf_read(const char* path, const char* const* contig_names, int n_contigs, int is_mutect, int sample,
                   int n_threads, ugvc_vcf** out) {
     if (!path || !out || (n_contigs > 0 && !contig_names)) return fail("NULL argument");
-    if (n_contigs < 0 || n_contigs > 256) return fail("the contig column is u8: at most 256 contigs");
+    if (n_contigs < 0 || n_contigs > 65535) return fail("the contig column is u16: at most 65535 contigs");
     if (sample < 0 || sample > 1000000) return fail("bad sample index");
     *out = nullptr;
     const int threads = pick_threads(n_threads);

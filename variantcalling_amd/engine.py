@@ -22,7 +22,7 @@ _i32p, _i64p, _f32p, _f64p = (C.POINTER(t) for t in (C.c_int32, C.c_int64, C.c_f
 
 
 class CVariants(C.Structure):
-    _fields_ = [("n", C.c_int64), ("contig", _u8p), ("pos", _i32p), ("ref_len", _u16p), ("alt_len", _u16p),
+    _fields_ = [("n", C.c_int64), ("contig", _u16p), ("pos", _i32p), ("ref_len", _u16p), ("alt_len", _u16p),
                 ("ref_off", _u32p), ("alt_off", _u32p), ("alleles", _u8p), ("alleles_len", C.c_int64),
                 ("qual", _f32p), ("sor", _f32p), ("dp", _i32p), ("ad_ref", _i32p), ("ad_alt", _i32p),
                 ("gq", _u8p)]
@@ -113,7 +113,7 @@ def load_library(path: str = LIB_PATH):
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.ugvc_abi_version() != 1:
+    if lib.ugvc_abi_version() != 2:
         raise RuntimeError("libugvc_mi355x.so ABI version mismatch")
     _lib = lib
     return lib
@@ -258,7 +258,7 @@ class Engine:
         cols = {c: _col(getattr(vt, c), S.VariantTable.DTYPES[c]) for c in S.VariantTable.COLS if c != "gt"}
         alle = _col(vt.alleles, np.uint8)
         self._keep = [cols, alle]
-        return CVariants(vt.n, _p(cols["contig"], _u8p), _p(cols["pos"], _i32p), _p(cols["ref_len"], _u16p),
+        return CVariants(vt.n, _p(cols["contig"], _u16p), _p(cols["pos"], _i32p), _p(cols["ref_len"], _u16p),
                          _p(cols["alt_len"], _u16p), _p(cols["ref_off"], _u32p), _p(cols["alt_off"], _u32p),
                          _p(alle, _u8p), alle.size, _p(cols["qual"], _f32p), _p(cols["sor"], _f32p),
                          _p(cols["dp"], _i32p), _p(cols["ad_ref"], _i32p), _p(cols["ad_alt"], _i32p),

@@ -130,7 +130,7 @@ def frame_to_table(fr: h5.Frame, contig_names, is_mutect: bool = False, label_co
     tlod = _num(fr.get("tlod"), n)[rows]
     qual = (10.0 * tlod) if is_mutect else _num(fr.get("qual"), n)[rows]
     vt = S.VariantTable(
-        contig=contig[rows].astype(np.uint8), pos=pos[rows].astype(np.int32), ref_len=rl, alt_len=al,
+        contig=contig[rows].astype(np.uint16), pos=pos[rows].astype(np.int32), ref_len=rl, alt_len=al,
         ref_off=off[:-1].astype(np.uint32), alt_off=(off[:-1] + rl).astype(np.uint32), alleles=S._ASCII_TO_CODE[pool],
         qual=qual.astype(np.float32), sor=_num(fr.get("sor"), n)[rows].astype(np.float32),
         dp=_num(fr.get("dp"), n)[rows].astype(np.int32), ad_ref=adr, ad_alt=ada,

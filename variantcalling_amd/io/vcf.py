@@ -66,7 +66,7 @@ def read_vcf(path: str, contig_names: list, is_mutect: bool = False, sample: int
             elif line.strip():
                 records.append(line.rstrip(b"\r\n"))
     n = len(records)
-    contig = np.zeros(n, np.uint8); pos = np.zeros(n, np.int32)
+    contig = np.zeros(n, np.uint16); pos = np.zeros(n, np.int32)
     qual = np.zeros(n, np.float32); sor = np.zeros(n, np.float32)
     dp = np.zeros(n, np.int32); adr = np.zeros(n, np.int32); ada = np.zeros(n, np.int32)
     gq = np.zeros(n, np.uint8); gt = np.zeros(n, np.uint8)

@@ -102,7 +102,7 @@ class NativeVcfFile:
         tl = _arr(v.tlod, n, np.float32)
         self.tlod = tl if is_mutect else None
         self.table = S.VariantTable(
-            contig=_arr(v.contig, n, np.uint8), pos=_arr(v.pos, n, np.int32),
+            contig=_arr(v.contig, n, np.uint16), pos=_arr(v.pos, n, np.int32),
             ref_len=_arr(v.ref_len, n, np.uint16), alt_len=_arr(v.alt_len, n, np.uint16),
             ref_off=_arr(v.ref_off, n, np.uint32), alt_off=_arr(v.alt_off, n, np.uint32),
             alleles=_arr(v.alleles, int(v.pool_bytes), np.uint8), qual=_arr(v.qual, n, np.float32),

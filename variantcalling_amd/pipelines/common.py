@@ -15,12 +15,10 @@ logger = logging.getLogger("ugvc")
 def load_side_tables(reference_file, runs_file, annotate_intervals, blacklist_file):
     from ..io import vcf_native                        # threaded native readers (libugvc_vcf.so); io.fasta / io.bed are their references
     ref = vcf_native.read_fasta(reference_file)
-    if ref.n_contigs > 255:
-        # the contig column is u8: keep the primary contigs, as the reference's own
-        # per-contig keys do (HDF5 keyed per chromosome, docs/train_models_pipeline.md:58-59)
-        keep = ref.names[:255]
-        logger.warning("reference has %d contigs; using the first 255", ref.n_contigs)
-        ref = vcf_native.read_fasta(reference_file, contigs=keep)
+    if ref.n_contigs > 65535:
+        # the contig column is u16; production hg38 has 3 366 contigs
+        # (test/resources/unit/vcfbed/test_vcftools/header.txt), nothing is dropped below this bound
+        raise ValueError(f"{reference_file}: {ref.n_contigs} contigs; the engine indexes at most 65535")
     # homopolymer runs are disjoint by nature; book-ended runs of different bases must stay separate
     runs = vcf_native.read_intervals(runs_file, ref.names, merge=False) if runs_file else None
     tracks = [vcf_native.read_intervals(p, ref.names, merge=True) for p in (annotate_intervals or [])]
@@ -36,10 +34,12 @@ def cg_insertion_mask(vt: S.VariantTable) -> np.ndarray:
     submodule): an insertion whose inserted bases are exactly CCG or GGC."""
     out = np.zeros(vt.n, dtype=bool)
     ins = np.flatnonzero((vt.alt_len == vt.ref_len + 3) & (vt.ref_len == 1))
-    ccg, ggc = S.encode_bases("CCG"), S.encode_bases("GGC")
-    for i in ins:
-        tail = vt.alleles[vt.alt_off[i] + 1: vt.alt_off[i] + 4]
-        out[i] = bool(np.array_equal(tail, ccg) or np.array_equal(tail, ggc))
+    if ins.size:
+        off = vt.alt_off[ins].astype(np.int64)
+        # the three inserted bases as one base-8 number (codes 0..4): CCG / GGC
+        tail = (vt.alleles[off + 1].astype(np.int64) << 6) | (vt.alleles[off + 2].astype(np.int64) << 3) | vt.alleles[off + 3]
+        ccg, ggc = (int(x[0]) << 6 | int(x[1]) << 3 | int(x[2]) for x in (S.encode_bases("CCG"), S.encode_bases("GGC")))
+        out[ins] = (tail == ccg) | (tail == ggc)
     return out
 
 

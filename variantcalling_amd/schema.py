@@ -124,7 +124,7 @@ class VariantTable:
 
     COLS = ("contig", "pos", "ref_len", "alt_len", "ref_off", "alt_off",
             "qual", "sor", "dp", "ad_ref", "ad_alt", "gq", "gt")
-    DTYPES = dict(contig=np.uint8, pos=np.int32, ref_len=np.uint16, alt_len=np.uint16,
+    DTYPES = dict(contig=np.uint16, pos=np.int32, ref_len=np.uint16, alt_len=np.uint16,
                   ref_off=np.uint32, alt_off=np.uint32, qual=np.float32, sor=np.float32,
                   dp=np.int32, ad_ref=np.int32, ad_alt=np.int32, gq=np.uint8, gt=np.uint8)
 

@@ -69,7 +69,7 @@ def make_genome(total_len: int, n_contigs: int = 24, seed: int = 20260116,
 
 def _global_to_contig(ref: Reference, g: np.ndarray):
     c = np.searchsorted(ref.contig_off, g, side="right") - 1
-    return c.astype(np.uint8), (g - ref.contig_off[c] + 1).astype(np.int32)
+    return c.astype(np.uint16), (g - ref.contig_off[c] + 1).astype(np.int32)
 
 
 def make_variants(ref: Reference, n: int, seed: int = 20260116, snv_only: bool = False,
