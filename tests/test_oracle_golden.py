@@ -167,6 +167,44 @@ def test_forest_predict_matches_sklearn():
         assert np.array_equal(O.forest_predict(f, Xe)[1], clf.predict_proba(Xe)[:, 1])
 
 
+def test_count_valued_leaves_score_like_sklearn_1_2_predict_proba():
+    """The reference pins scikit-learn 1.2.2 (setup/environment.yml:399): tree_.value holds weighted sample
+    counts and predict_proba normalises every leaf row.  Emulated on trees fitted here: the same trees with
+    value := fraction x weighted_n_node_samples must flatten to the normalised rows and score as the
+    count-normalising predict_proba does."""
+    from types import SimpleNamespace
+    from sklearn.ensemble import RandomForestClassifier
+    rng = np.random.default_rng(9)
+    X = rng.normal(size=(3000, 6)).astype(np.float32)
+    y = (X[:, 0] - X[:, 2] + rng.normal(0, 0.7, 3000) > 0).astype(int)
+    clf = RandomForestClassifier(n_estimators=12, max_depth=6, random_state=4).fit(X, y)
+    ests = []
+    for e in clf.estimators_:
+        t = e.tree_
+        counts = t.value * t.weighted_n_node_samples[:, None, None]          # what 1.2.2 stores
+        ests.append(SimpleNamespace(classes_=e.classes_, tree_=SimpleNamespace(
+            node_count=t.node_count, children_left=t.children_left, children_right=t.children_right, feature=t.feature,
+            threshold=t.threshold, value=counts, max_depth=t.max_depth)))
+    old = SimpleNamespace(estimators_=ests, classes_=clf.classes_, n_features_in_=6)
+    f = model_io.flatten_sklearn(old)
+    assert np.allclose(f.leaf_value.sum(axis=1), 1.0, atol=1e-12)
+    Xt = rng.normal(size=(2000, 6)).astype(np.float32)
+    # predict_proba of 1.2.2: per tree value[leaf] / value[leaf].sum(), averaged over the trees in order
+    acc = np.zeros((Xt.shape[0], 2))
+    for e, o in zip(clf.estimators_, ests):
+        leaf = e.apply(Xt)
+        v = o.tree_.value[leaf, 0, :]
+        nz = v.sum(axis=1, keepdims=True)
+        nz[nz == 0.0] = 1.0
+        acc += v / nz
+    acc /= len(ests)
+    p0, p1 = O.forest_predict(f, Xt)
+    assert np.array_equal(p0, acc[:, 0]) and np.array_equal(p1, acc[:, 1])
+    # and the fraction-valued (>= 1.3) trees are left untouched
+    f_new = model_io.flatten_sklearn(clf)
+    assert np.array_equal(O.forest_predict(f_new, Xt)[1], clf.predict_proba(Xt)[:, 1])
+
+
 def test_gbt_semantics():
     """XGBoost rules: x < thr goes left, f32 margin accumulated in tree order, sigmoid in f32."""
     t0 = (np.array([0, -1, -1]), np.array([0.5, 0, 0], np.float32), np.array([1, -1, -1]), np.array([2, -1, -1]),

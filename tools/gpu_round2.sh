@@ -4,7 +4,7 @@
 tag=${1:-r02}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests -m gpu -q -x --timeout 300 2>&1 | tail -40 > gpurun_out/$tag.tests.log
+timeout 900 python -m pytest tests -m gpu -q --timeout 300 2>&1 | tail -150 > gpurun_out/$tag.tests.log
 tail -5 gpurun_out/$tag.tests.log
 timeout 300 python bench.py --steps 20 --warmup 3 --cpu-sample 0 > gpurun_out/$tag.bench.json 2> gpurun_out/$tag.bench.err
 cat gpurun_out/$tag.bench.json | head -c 1500; echo

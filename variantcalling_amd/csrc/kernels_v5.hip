@@ -27,6 +27,9 @@
 // other feature is a non-negative integer and is used as it stands, clamped to one past the largest threshold
 // the forest tests (ugvc_v2.hpp) - no code tables, no gathers.
 // Semantics are those of the oracle (oracle/oracle.py); parity tests run v5, v3 and v1 against it.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "ugvc_walk.hpp"
@@ -238,9 +241,15 @@ struct Scratch {                    // wave-private LDS (byte addresses)
 __device__ __forceinline__ void featurize_snp_tile(const V5Args& v, const Scratch& sc, int64_t tile, int lane, uint32_t i, bool live,
                                                    bool has_model) {
     const FilterArgs& a = v.f;
+    const int stage = (a.ablate >> 20) & 15;       // debugging ladder: leave after stage k (0 = run everything)
     Cols k;
+    if (stage == 10) { if (tile == 1) a.score[lane] = (float)a.contig[i]; return; }
+    if (stage == 11) { if (tile == 1) a.score[lane] = (float)a.ref_len[i]; return; }
+    if (stage == 12) { if (tile == 1) a.score[lane] = (float)(a.ref_off[i] + a.alt_off[i]); return; }
+    if (stage == 13) { if (live) a.flags[i] = 7; return; }
     k.c = a.contig[i]; k.pos = a.pos[i]; k.rl = a.ref_len[i];
     k.ro = a.ref_off[i]; k.ao = a.alt_off[i];
+    if (stage == 2) { if (live) a.flags[i] = (uint8_t)k.rl; return; }
     const int64_t clo = a.contig_off[k.c], chi = a.contig_off[k.c + 1];
     const uint32_t clen = (uint32_t)(chi - clo);
     const uint32_t p0 = (uint32_t)(k.pos - 1);
@@ -251,8 +260,10 @@ __device__ __forceinline__ void featurize_snp_tile(const V5Args& v, const Scratc
     const uint32_t sh = (uint32_t)(g0 - 5) & 3u;
     const uint4 xw = *reinterpret_cast<const uint4*>(a.ref + wa);
     const uint32_t rbase = a.alleles[k.ro], abase = a.alleles[k.ao];
+    if (stage == 3) { if (live) a.flags[i] = (uint8_t)(xw.x + rbase + abase); return; }
     k.qual = a.qual[i]; k.sor = a.sor[i];
     k.dp = a.dp[i]; k.adr = a.ad_ref[i]; k.ada = a.ad_alt[i]; k.gq = a.gq[i];
+    if (stage == 4) { if (live) a.flags[i] = (uint8_t)(k.dp + k.gq + (int)k.qual); return; }
 
     // ---- side-table slices of this tile -> wave-private LDS (sentinel padded)
     const int c0 = rfl(k.c);
@@ -324,6 +335,7 @@ __device__ __forceinline__ void featurize_snp_tile(const V5Args& v, const Scratc
     const uint32_t n_at = (uint32_t)__popc(at_bytes(w0) & 0x01010100u) + (uint32_t)__popc(at_bytes(w1)) + (uint32_t)__popc(at_bytes(w2) & 0x00010101u);
     const uint32_t gc_cnt = gc_len - n_at;
     const float gc = lds_f32(sc.gctab_b + 4u * (gc_len * 11u + gc_cnt));
+    if (stage == 5) { if (live) a.flags[i] = (uint8_t)(gc * 10.f + lm + rm); return; }
     // cycle skip
     int css;
     if (motif_n || rbase == 0 || abase == 0) css = 0;
@@ -351,6 +363,7 @@ __device__ __forceinline__ void featurize_snp_tile(const V5Args& v, const Scratc
         }
     }
 
+    if (stage == 6) { if (live) a.flags[i] = (uint8_t)css; return; }
     // ---- joins
     JoinOut jo{false, false, false, 0u};
     if (!joins_on) {
@@ -452,7 +465,7 @@ __device__ __forceinline__ void featurize_snp_tile(const V5Args& v, const Scratc
     if (jo.cohort) flags |= UGVC_FLAG_COHORT_FP;
     if (a.mark_hpol && (jo.inside_run || jo.close_run)) flags |= UGVC_FLAG_HPOL_RUN;
     if (live) a.flags[i] = flags;
-    if (!has_model) return;
+    if (!has_model || stage == 7) return;
 
     // ---- codes -> the wave's code planes (the staged slices are dead: LDS executes a wave's accesses in order)
     const float vaf = k.dp > 0 ? __fdiv_rn((float)k.ada, (float)k.dp) : 0.0f;
@@ -830,12 +843,17 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
     // tiles against their own group's
     const Lds5 L = lds5_fill(smem, pg0, has0, v.thr, v.thr_lds_len, v.css_lut, tid, blockDim.x);
     __syncthreads();
+    if (((v.f.ablate >> 20) & 15) == 1) return;
     Scratch sc;
     sc.base = L.scratch_b + (uint32_t)(wave * v.scratch_bytes);
     sc.thr_b = L.thr_b; sc.gctab_b = L.gctab_b; sc.css_b = L.css_b;
     const int hslot = ((lane & 31) << 1) | (lane >> 5);
     const uint32_t planes_lane_b = sc.base + 2u * (uint32_t)hslot;
-    const int64_t ns = cload(v.tile_cnt), ni = (v.f.ablate & 262144) ? 0 : cload(v.tile_cnt + 1);
+    const int64_t ns = (uint32_t)rfl((int)v.tile_cnt[0]), ni = (v.f.ablate & 262144) ? 0 : (uint32_t)rfl((int)v.tile_cnt[1]);
+    if (((v.f.ablate >> 20) & 15) == 8) {                     // debugging: the tile counts and the first indices
+        if (blockIdx.x == 0 && tid == 0) { v.f.score[0] = (float)ns; v.f.score[1] = (float)ni; v.f.score[2] = (float)v.snp_idx[0]; v.f.score[3] = (float)v.snp_idx[63]; v.f.score[4] = (float)v.max_tiles; }
+        return;
+    }
     const int64_t stride = (int64_t)gridDim.x * n_waves;
     // tile slots are wave-major over the workgroups: a short last round leaves a few waves busy on every CU
     int64_t ts = (int64_t)wave * gridDim.x + blockIdx.x, ti = ts;
@@ -844,13 +862,19 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
         if (do_indel) {
             const uint32_t id = v.indel_idx[ti * 64 + lane];
             const bool live = id != ~0u;
-            const uint32_t i = live ? id : (uint32_t)rfl((int)id);
+            const uint32_t id0 = (uint32_t)rfl((int)id);       // (outside the select: a ternary would read the first PADDING lane)
+            const uint32_t i = live ? id : id0;
             featurize_indel_tile(v, sc, ti, lane, i, live);
             ti += stride;
         } else {
             const uint32_t id = v.snp_idx[ts * 64 + lane];
             const bool live = id != ~0u;
-            const uint32_t i = live ? id : (uint32_t)rfl((int)id);
+            const uint32_t id0 = (uint32_t)rfl((int)id);       // (outside the select: a ternary would read the first PADDING lane)
+            const uint32_t i = live ? id : id0;
+            if (((v.f.ablate >> 20) & 15) == 9) {              // debugging: what a wave is about to work on
+                if (ts == 1) { v.f.score[lane] = (float)id; v.f.score[64 + lane] = (float)i; v.f.score[128 + lane] = (float)v.f.pos[i < (uint32_t)v.f.n ? i : 0]; }
+                return;
+            }
             featurize_snp_tile(v, sc, ts, lane, i, live, has0);
             if (has0) {
                 float score = 0.f;
@@ -1003,7 +1027,7 @@ static size_t k5_forest_lds(const PackedGroupView& pg, int n_waves) {
 // LDS budget of the fused kernel for this configuration: 16, 12 or 8 waves of scratch beside the SNP forest
 int v5_fused_waves(const V5Args& v) {
     for (int w : {16, 12, 8}) {
-        if (lds5_bytes(v.pg[0], v.pg[0].ok != 0, v.thr_lds_len, w, v.scratch_bytes) + 1024 <= 160 * 1024) return w;
+        if (lds5_bytes(v.pg[0], v.pg[0].ok != 0, v.thr_lds_len, w, v.scratch_bytes) <= 158 * 1024) return w;
     }
     return 0;
 }
@@ -1016,15 +1040,29 @@ int launch_filter_v5(ugvc_ctx* ctx, const FilterArgs& a) {
     static bool attr_set = false;
     if (!attr_set) {
         for (K f : {(K)fused5_kernel, (K)forest5_kernel})
-            UGVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+            UGVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
         attr_set = true;
     }
+    // UGVC_DEBUG_SYNC=1: name every launch on stderr and wait for it (a GPU memory fault aborts the process; the
+    // last name printed is the kernel that faulted)
+    static const bool dbg = getenv("UGVC_DEBUG_SYNC") != nullptr;
+    auto step = [&](const char* name) -> int {
+        if (!dbg) return 0;
+        fprintf(stderr, "[v5] %s done? ", name);
+        fflush(stderr);
+        UGVC_HIP(hipStreamSynchronize(ctx->stream));
+        fprintf(stderr, "ok\n");
+        return 0;
+    };
     UGVC_HIP(hipMemsetAsync(v.tile_cnt, 0, 16, ctx->stream));
     hipLaunchKernelGGL(compact5_kernel, dim3((unsigned)v.n_cblocks), dim3(kCBlock5), 0, ctx->stream, v);
-    const int64_t nbr = ((int64_t)v.max_tiles + 1) * 16;        // >= 8 x SNP tiles + 16 x indel tiles
+    if (step("compact5")) return -1;
+    const int64_t nbr = (int64_t)v.max_tiles * 24;               // 8 threads per SNP tile + 16 per indel tile
     hipLaunchKernelGGL(bracket5_kernel, dim3((unsigned)((nbr + 255) / 256)), dim3(256), 0, ctx->stream, v);
+    if (step("bracket5")) return -1;
     const size_t lds_f = lds5_bytes(v.pg[0], v.pg[0].ok != 0, v.thr_lds_len, v.n_waves, v.scratch_bytes);
     hipLaunchKernelGGL(fused5_kernel, dim3((unsigned)ctx->n_cus), dim3(v.n_waves * 64), lds_f, ctx->stream, v);
+    if (step("fused5")) return -1;
     if (!(a.ablate & 262144) && (v.pg[1].ok || v.pg[2].ok)) {
         int n_waves = 0;
         size_t lds = 0;
@@ -1032,10 +1070,11 @@ int launch_filter_v5(ugvc_ctx* ctx, const FilterArgs& a) {
             size_t need = 0;
             for (int g = 1; g < UGVC_N_GROUPS; ++g)
                 if (v.pg[g].ok) need = std::max(need, k5_forest_lds(v.pg[g], w));
-            if (need + 2048 <= 160 * 1024) { n_waves = w; lds = need; break; }
+            if (need + 1088 <= 158 * 1024) { n_waves = w; lds = need; break; }
         }
         if (n_waves == 0) return fail("internal: packed forest does not fit LDS");
         hipLaunchKernelGGL(forest5_kernel, dim3((unsigned)ctx->n_cus), dim3(n_waves * 64), lds, ctx->stream, v);
+        if (step("forest5")) return -1;
     }
     UGVC_HIP(hipGetLastError());
     return 0;

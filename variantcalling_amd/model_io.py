@@ -66,7 +66,15 @@ def flatten_sklearn(model, n_features: int | None = None) -> S.FlatForest:
         left = np.where(is_leaf, leaf_id, t.children_left + node_base).astype(np.int32)
         right = np.where(is_leaf, 0, t.children_right + node_base).astype(np.int32)
         thr = np.where(is_leaf, 0.0, t.threshold)
-        val = t.value[is_leaf, 0, :]
+        val = np.asarray(t.value[is_leaf, 0, :], dtype=np.float64)
+        # scikit-learn <= 1.2 (the reference pins 1.2.2, setup/environment.yml:399) stores weighted sample COUNTS per
+        # leaf and `predict_proba` divides every row by its sum (zero sums stay); >= 1.3 stores the fractions and
+        # returns them untouched.  Count-valued leaves are recognised by a row sum above 1 and normalised exactly
+        # as that predict_proba does, so a reference `--model_file` pickle scores as it does in the reference.
+        rs = val.sum(axis=1, keepdims=True)
+        if val.size and float(rs.max()) > 1.0 + 1e-9:
+            rs[rs == 0.0] = 1.0
+            val = val / rs
         if val.shape[1] == 1:                       # single-class tree
             only = int(e.classes_[0]) if hasattr(e, "classes_") else 0
             full = np.zeros((val.shape[0], 2))
