@@ -7,15 +7,16 @@
 //
 //   compact5_kernel   every 1024-variant block splits its rows by variant class (ref_len == alt_len: the SNP
 //                     forest; else an indel) into tiles of 64 row indices; a tile is one wave's work and is pure
-//                     in class, so every lane of a wave walks the SAME forest (no lane is idle in a walk).
+//                     in class, so every lane of a wave walks the SAME forest (no lane is idle in a walk).  Tile
+//                     slots come from 64 sharded counters (one atomic per block and class).
 //   bracket5_kernel   per tile, the lower bound of its first (indel tiles: and last) variant in every searched
 //                     side table (two-level search, L2-resident 1/64 sample first).
 //   fused5_kernel     one 16-wave workgroup per CU holds the SNP forest in LDS (rank-coded complete trees,
-//                     single-sum layout) and the SNP group's float thresholds.  A wave is autonomous - no
-//                     workgroup barrier after the prologue: it loads its tile's columns, an 11-base reference
-//                     window per lane (one 16-byte load, realigned with v_alignbyte), stages the side-table slices
-//                     its tile can touch in wave-private LDS (sentinel padded, so the descents carry no bounds
-//                     test), derives the features, writes 16-bit codes straight into its code planes and walks
+//                     single-sum layout) and the float thresholds.  A wave is autonomous - no workgroup barrier
+//                     after the prologue: it loads its tile's columns, an 11-base reference window per lane (one
+//                     16-byte load, realigned with v_alignbyte), stages the side-table slices its tile can touch
+//                     in wave-private LDS (sentinel padded: the lock-step descents carry no bounds test and no
+//                     branch), derives the features, writes 16-bit codes straight into its code planes and walks
 //                     the forest; score / FILTER / flags leave in variant order (coalesced).  While one wave waits
 //                     for memory the other fifteen walk: the featurize latency that bounded K1 disappears under
 //                     the LDS-bound walk.  Indel tiles (18 % of a WGS callset) are featurised by the same waves
@@ -26,6 +27,7 @@
 // Codes: floats (qual, sor, vaf, gc) are ranked against the group's sorted thresholds (exact, as v3); every
 // other feature is a non-negative integer and is used as it stands, clamped to one past the largest threshold
 // the forest tests (ugvc_v2.hpp) - no code tables, no gathers.
+// The number of annotation tracks is a template parameter: the per-table code is straight-line.
 // Semantics are those of the oracle (oracle/oracle.py); parity tests run v5, v3 and v1 against it.
 #include <stdio.h>
 #include <stdlib.h>
@@ -41,33 +43,51 @@ namespace ugvc {
 template <class T> __device__ __forceinline__ T cload(const T* p) {
     return *(const UGVC_CONST T*)(uintptr_t)p;
 }
-
 __device__ __forceinline__ uint2 cload2(const uint2* p) {
     const u32x2_t x = *(const UGVC_CONST u32x2_t*)(uintptr_t)p;
     return make_uint2(x.x, x.y);
 }
+__device__ __forceinline__ void lds_st32(uint32_t a, int32_t x) { *(UGVC_LDS int32_t*)(uintptr_t)a = x; }
+__device__ __forceinline__ void lds_st64(uint32_t a, uint64_t x) { *(UGVC_LDS uint64_t*)(uintptr_t)a = x; }
+__device__ __forceinline__ void lds_st16(uint32_t a, uint32_t x) { *(UGVC_LDS uint16_t*)(uintptr_t)a = (uint16_t)x; }
+__device__ __forceinline__ uint32_t lds_u8(uint32_t a) { return *(UGVC_LDS const uint8_t*)(uintptr_t)a; }
 
-constexpr int kGcTab = 128;          // gc_content = gctab[len * 11 + count], len, count in 0..10
+constexpr int kGcRank = 121;         // gc_content takes 121 values (count / len, len and count in 0..10): its rank code is a table
+constexpr int kGcRankBytes = 768;    // 3 groups x 121 u16, padded
 constexpr int kWinRowB = kWinStride * 4;
 
 // ---- Kc: variant classes -> tiles of 64 row indices ---------------------------------------------------
-__global__ __launch_bounds__(kCBlock5) void compact5_kernel(const V5Args v) {
-    __shared__ unsigned ws[kCBlock5 / 64], wi[kCBlock5 / 64];
+// A workgroup of four waves owns kCBlock5 = 1024 consecutive rows (256 per wave, four rounds of 64): small
+// workgroups keep thousands of them in flight, so the one returning atomic each needs is hidden.
+__global__ __launch_bounds__(256) void compact5_kernel(const V5Args v) {
+    __shared__ unsigned ws[4], wi[4];
     __shared__ unsigned base_s, base_i;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t i = (int64_t)blockIdx.x * kCBlock5 + tid;
-    if (i < UGVC_N_GROUPS * kShards) v.counters[i * kCounterStride] = 0;      // the record lists of this pass start empty
-    bool snp = false, ind = false;
-    if (i < v.f.n) {
-        snp = v.f.ref_len[i] == v.f.alt_len[i];
-        ind = !snp;
+    {
+        const int64_t g = (int64_t)blockIdx.x * 256 + tid;
+        if (g < UGVC_N_GROUPS * kShards) v.counters[g * kCounterStride] = 0;   // the record lists of this pass start empty
     }
-    const unsigned long long ms = __ballot(snp), mi = __ballot(ind);
-    if (lane == 0) { ws[wave] = (unsigned)__popcll(ms); wi[wave] = (unsigned)__popcll(mi); }
+    const int64_t i0 = (int64_t)blockIdx.x * kCBlock5 + wave * 256 + lane;
+    unsigned long long ms[4], mi[4];
+    unsigned cs = 0, ci = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t i = i0 + r * 64;
+        bool snp = false, ind = false;
+        if (i < v.f.n) {
+            snp = v.f.ref_len[i] == v.f.alt_len[i];
+            ind = !snp;
+        }
+        ms[r] = __ballot(snp);
+        mi[r] = __ballot(ind);
+        cs += (unsigned)__popcll(ms[r]);
+        ci += (unsigned)__popcll(mi[r]);
+    }
+    if (lane == 0) { ws[wave] = cs; wi[wave] = ci; }
     __syncthreads();
     unsigned ps = 0, pi = 0, ts = 0, ti = 0;
 #pragma unroll
-    for (int w = 0; w < kCBlock5 / 64; ++w) {
+    for (int w = 0; w < 4; ++w) {
         const unsigned a = ws[w], b = wi[w];
         ps += w < wave ? a : 0u;
         pi += w < wave ? b : 0u;
@@ -75,15 +95,22 @@ __global__ __launch_bounds__(kCBlock5) void compact5_kernel(const V5Args v) {
         ti += b;
     }
     const unsigned nts = (ts + 63) >> 6, nti = (ti + 63) >> 6;
-    if (tid == 0) {
-        base_s = nts ? atomicAdd(&v.tile_cnt[0], nts) : 0u;
-        base_i = nti ? atomicAdd(&v.tile_cnt[1], nti) : 0u;
-    }
+    // tile slots: 64 shards of `shard_tiles` slots per class, one atomic per block and class on the block's shard
+    // (a single counter per class serialises ~5000 same-address atomics: 116 us per 5 M variants)
+    const unsigned shard = blockIdx.x & (kTileShards5 - 1);
+    if (tid == 0) base_s = nts ? atomicAdd(&v.tile_cnt[shard * kTileCntStride5], nts) : 0u;
+    if (tid == 64) base_i = nti ? atomicAdd(&v.tile_cnt[(kTileShards5 + shard) * kTileCntStride5], nti) : 0u;
     __syncthreads();
-    const unsigned bs = base_s, bi = base_i;
+    const unsigned bs = shard * (unsigned)v.shard_tiles + base_s, bi = shard * (unsigned)v.shard_tiles + base_i;
     const unsigned long long below = (1ull << lane) - 1;
-    if (snp) v.snp_idx[(size_t)bs * 64 + ps + (unsigned)__popcll(ms & below)] = (uint32_t)i;
-    if (ind) v.indel_idx[(size_t)bi * 64 + pi + (unsigned)__popcll(mi & below)] = (uint32_t)i;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t i = (uint32_t)(i0 + r * 64);
+        if ((ms[r] >> lane) & 1) v.snp_idx[(size_t)bs * 64 + ps + (unsigned)__popcll(ms[r] & below)] = i;
+        if ((mi[r] >> lane) & 1) v.indel_idx[(size_t)bi * 64 + pi + (unsigned)__popcll(mi[r] & below)] = i;
+        ps += (unsigned)__popcll(ms[r]);
+        pi += (unsigned)__popcll(mi[r]);
+    }
     if ((unsigned)tid < nts * 64 - ts) v.snp_idx[(size_t)bs * 64 + ts + tid] = ~0u;          // padding of the last tile
     if ((unsigned)tid < nti * 64 - ti) v.indel_idx[(size_t)bi * 64 + ti + tid] = ~0u;
     if ((unsigned)tid < nts) v.tile_n[bs + tid] = (uint8_t)((unsigned)tid + 1 < nts ? 64u : ts - 64u * (nts - 1));
@@ -91,34 +118,66 @@ __global__ __launch_bounds__(kCBlock5) void compact5_kernel(const V5Args v) {
 }
 
 // ---- K0: per tile, lower bounds of its first (indel tiles: and last) variant in the searched tables ---
-__global__ void bracket5_kernel(const V5Args v) {
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t ns = v.tile_cnt[0], ni = v.tile_cnt[1];
-    const FilterArgs& f = v.f;
-    int64_t tile;
-    int a;
-    bool is_indel;
-    if (gid < ns * 8) { tile = gid >> 3; a = (int)(gid & 7); is_indel = false; }
-    else {
-        const int64_t g2 = gid - ns * 8;
-        if (g2 >= ni * 16) return;
-        tile = g2 >> 4; a = (int)(g2 & 15); is_indel = true;
+// One thread per (REAL tile, searched table): the tile counters of both classes are scanned in LDS, a thread finds
+// its tile by its rank among the real tiles - no lane idles on an empty slot or an absent table (the searches are
+// chains of ~22 dependent loads: what counts is how many waves the launch needs, not their instruction count).
+__global__ __launch_bounds__(256) void bracket5_kernel(const V5Args v) {
+    __shared__ unsigned incl[2][kTileShards5];
+    const int tid = threadIdx.x;
+    if (tid < 2 * kTileShards5) {
+        const int cls = tid >> 6, sh = tid & 63;
+        unsigned x = v.tile_cnt[(cls * kTileShards5 + sh) * kTileCntStride5];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned y = __shfl_up(x, d);
+            if (sh >= d) x += y;
+        }
+        incl[cls][sh] = x;
     }
-    const int t = a & 7;
-    if (t >= kJoin5) return;
+    __syncthreads();
+    const FilterArgs& f = v.f;
+    // active tables, in order: runs (if any), tracks, blacklist (if any)
+    const int n_act = (f.has_runs ? 1 : 0) + f.n_tracks + (f.n_bl > 0 ? 1 : 0);
+    if (n_act == 0) return;
+    const int64_t ns = incl[0][kTileShards5 - 1], ni = incl[1][kTileShards5 - 1];
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + tid;
+    int64_t rank;                       // rank of the tile among the real tiles of its class
+    int k, last;
+    bool is_indel;
+    if (gid < ns * n_act) { rank = gid / n_act; k = (int)(gid - rank * n_act); last = 0; is_indel = false; }
+    else {
+        const int64_t g2 = gid - ns * n_act;
+        if (g2 >= ni * 2 * n_act) return;
+        rank = g2 / (2 * n_act);
+        const int r = (int)(g2 - rank * 2 * n_act);
+        last = r >= n_act;
+        k = last ? r - n_act : r;
+        is_indel = true;
+    }
+    int t = k + (f.has_runs ? 0 : 1);                                   // table index: 0 runs, 1.. tracks, kJoin5 - 1 blacklist
+    if (t > f.n_tracks) t = kJoin5 - 1;
+    const unsigned* inc = incl[is_indel ? 1 : 0];
+    int lo = 0, len = kTileShards5;
+    while (len > 0) {                                                   // first shard whose inclusive count exceeds the rank
+        const int half = len >> 1;
+        const bool le = inc[lo + half] <= (unsigned)rank;
+        lo = le ? lo + half + 1 : lo;
+        len = le ? len - half - 1 : half;
+    }
+    const int shard = lo;
+    const int64_t tile = (int64_t)shard * v.shard_tiles + (rank - (shard > 0 ? inc[shard - 1] : 0u));
     const uint32_t* list = is_indel ? v.indel_idx : v.snp_idx;
-    const int slot = a >= 8 ? (int)v.tile_n[(size_t)v.max_tiles + tile] - 1 : 0;
+    const int slot = last ? (int)v.tile_n[(size_t)v.max_tiles + tile] - 1 : 0;
     const uint32_t i = list[tile * 64 + slot];
     const int c = f.contig[i], pos = f.pos[i];
-    int out = 0;
-    if (t == kJoin5 - 1) {
-        if (f.n_bl > 0) out = lb_two_level_g<uint64_t>(f.bl, f.bl_coarse, 0, (int)f.n_bl, ((uint64_t)c << 32) | (uint32_t)pos);
-    } else if (table_present(f, t)) {
+    int out;
+    if (t == kJoin5 - 1) out = lb_two_level_g<uint64_t>(f.bl, f.bl_coarse, 0, (int)f.n_bl, ((uint64_t)c << 32) | (uint32_t)pos);
+    else {
         const TrackView& tv = table_view(f, t);
         out = lb_two_level_g<int32_t>(tv.starts, tv.coarse, tv.ptr[c], tv.ptr[c + 1], pos);
     }
-    if (is_indel) v.br_indel[tile * 16 + a] = out;
-    else v.br_snp[tile * 8 + a] = out;
+    if (is_indel) v.br_indel[tile * 16 + (last ? 8 : 0) + t] = out;
+    else v.br_snp[tile * 8 + t] = out;
 }
 
 // ---- joins ---------------------------------------------------------------------------------------
@@ -153,65 +212,80 @@ __device__ __forceinline__ void interval_verdict(int t, int sg, int plo, int phi
     }
 }
 
-// Searches on the resident tables themselves, all tables in lock-step: per lane the range [lo, hi) of every
-// table (a tile's brackets, or the whole contig).
-__device__ __forceinline__ void join_global(const FilterArgs& a, const int (&lo)[kJoin5], const int (&hi)[kJoin5],
-                                            const int (&plo)[kJoin5 - 1], const int (&phi)[kJoin5 - 1], int pos, uint64_t key, JoinOut& o) {
-    int base[kJoin5], len[kJoin5];
+// One table searched in HBM (rows [lo, hi) per lane): the rare paths - a tile that spans contigs, a slice that
+// outgrew its staging area.  Kept out of line so the common path stays small.
+__device__ __forceinline__ void join_one_global(const FilterArgs* ap, int t, int lo, int hi, int plo, int phi, int pos, uint64_t key,
+                                             JoinOut* op) {
+    const FilterArgs& a = *ap;
+    JoinOut o = *op;
+    if (t == kJoin5 - 1) {
+        const int r = lb_u64_g(a.bl, lo, hi, key);
+        o.cohort = r < (int)a.n_bl && a.bl[r] == key;
+    } else if (phi > plo) {
+        const TrackView& tv = table_view(a, t);
+        const int sg = lb_i32_g(tv.starts, lo, hi, pos);
+        const int top = phi - 1;
+        auto S = [&](int i) { return tv.starts[i < plo ? plo : (i > top ? top : i)]; };     // clamped into the contig's rows;
+        auto E = [&](int i) { return tv.ends[i < plo ? plo : (i > top ? top : i)]; };       // interval_verdict's guards discard them
+        if (t == 0) { o.inside_run = o.close_run = false; }
+        else o.trk &= ~(1u << (t - 1));
+        interval_verdict(t, sg, plo, phi, pos, a.hpol_dist, S, E, o);
+    }
+    *op = o;
+}
+
+// Bracketed searches of an indel tile on the resident tables themselves, all tables in lock-step (rows
+// [lo, hi) of every table, wave-uniform).
+template <int NTRK>
+__device__ __forceinline__ void join_bracketed(const FilterArgs& a, const int (&lo)[kJoin5], const int (&hi)[kJoin5],
+                                               const int (&plo)[kJoin5 - 1], const int (&phi)[kJoin5 - 1], int pos, uint64_t key, JoinOut& o) {
+    constexpr int NT = 1 + NTRK;
+    int base[NT], len[NT];
+    int bbase = lo[kJoin5 - 1], blen = a.n_bl > 0 ? hi[kJoin5 - 1] - lo[kJoin5 - 1] : 0;
 #pragma unroll
-    for (int t = 0; t < kJoin5; ++t) {
+    for (int t = 0; t < NT; ++t) {
         base[t] = lo[t];
-        len[t] = hi[t] - lo[t];
-        const bool present = t == kJoin5 - 1 ? a.n_bl > 0 : table_present(a, t);
-        if (!present || len[t] < 0) len[t] = 0;
+        len[t] = (t > 0 || a.has_runs) ? hi[t] - lo[t] : 0;
     }
     for (;;) {
-        bool more = false;
-        int x[kJoin5 - 1];
+        int x[NT];
         uint64_t xk = 0;
+        bool more = false;
 #pragma unroll
-        for (int t = 0; t < kJoin5 - 1; ++t) {
+        for (int t = 0; t < NT; ++t) {
             x[t] = 0;
-            if (table_present(a, t) && len[t] > 0) x[t] = table_view(a, t).starts[base[t] + (len[t] >> 1)];
+            if (len[t] > 0) x[t] = table_view(a, t).starts[base[t] + (len[t] >> 1)];
         }
-        if (len[kJoin5 - 1] > 0) xk = a.bl[base[kJoin5 - 1] + (len[kJoin5 - 1] >> 1)];
+        if (blen > 0) xk = a.bl[bbase + (blen >> 1)];
 #pragma unroll
-        for (int t = 0; t < kJoin5; ++t) {
+        for (int t = 0; t < NT; ++t) {
             if (len[t] > 0) {
                 const int half = len[t] >> 1;
-                const bool lt = t == kJoin5 - 1 ? xk < key : x[t] < pos;
+                const bool lt = x[t] < pos;
                 base[t] = lt ? base[t] + half + 1 : base[t];
                 len[t] = lt ? len[t] - half - 1 : half;
                 more |= len[t] > 0;
             }
         }
+        if (blen > 0) {
+            const int half = blen >> 1;
+            const bool lt = xk < key;
+            bbase = lt ? bbase + half + 1 : bbase;
+            blen = lt ? blen - half - 1 : half;
+            more |= blen > 0;
+        }
         if (__ballot(more) == 0) break;
     }
 #pragma unroll
-    for (int t = 0; t < kJoin5 - 1; ++t) {
-        if (!table_present(a, t)) continue;
+    for (int t = 0; t < NT; ++t) {
+        if ((t == 0 && !a.has_runs) || phi[t] <= plo[t]) continue;
         const TrackView& tv = table_view(a, t);
-        const int top = phi[t] - 1;                           // reads are clamped into the contig's rows; the guards of
-        auto S = [&](int i) { return tv.starts[i < plo[t] ? plo[t] : (i > top ? (top > plo[t] ? top : plo[t]) : i)]; };   // interval_verdict
-        auto E = [&](int i) { return tv.ends[i < plo[t] ? plo[t] : (i > top ? (top > plo[t] ? top : plo[t]) : i)]; };     // discard them
-        if (phi[t] > plo[t]) interval_verdict(t, base[t], plo[t], phi[t], pos, a.hpol_dist, S, E, o);
+        const int top = phi[t] - 1, bot = plo[t];
+        auto S = [&](int i) { return tv.starts[i < bot ? bot : (i > top ? top : i)]; };
+        auto E = [&](int i) { return tv.ends[i < bot ? bot : (i > top ? top : i)]; };
+        interval_verdict(t, base[t], plo[t], phi[t], pos, a.hpol_dist, S, E, o);
     }
-    if (a.n_bl > 0) {
-        const int r = base[kJoin5 - 1];
-        if (r < (int)a.n_bl && a.bl[r] == key) o.cohort = true;
-    }
-}
-
-// ---- float features: rank among a sorted LDS slice -----------------------------------------------------
-// q0 = LDS address of the element BEFORE the slice, qend = address of its last element, bits: 2^bits > length.
-__device__ __forceinline__ uint32_t rank_f32(float x, uint32_t q0, uint32_t qend, int bits) {
-    uint32_t q = q0;
-    for (int s = bits - 1; s >= 0; --s) {
-        const uint32_t cand = q + (4u << s);
-        const float t = lds_f32(cand);
-        q = ((int32_t)(qend - cand) >= 0 && t < x) ? cand : q;
-    }
-    return (q - q0) >> 2;
+    if (a.n_bl > 0 && bbase < (int)a.n_bl && a.bl[bbase] == key) o.cohort = true;
 }
 
 __device__ __forceinline__ uint32_t raw_code(int x, int cap) {          // x < 0 ? 0 : min(x, cap) + 1
@@ -222,93 +296,144 @@ __device__ __forceinline__ bool any_zero_byte(uint32_t x) { return ((x - 0x01010
 // A or T bytes (codes 1, 4) of a packed base word -> 0x01 per byte
 __device__ __forceinline__ uint32_t at_bytes(uint32_t x) { return ((x & ~(x >> 1)) | (x >> 2)) & 0x01010101u; }
 
-struct Cols {                       // one variant's columns
-    int c, pos, rl, al;
+struct Scratch {                    // LDS byte addresses
+    uint32_t base;                  // wave-private: window rows / staged slices / code planes, one after the other in time
+    uint32_t eyt_b;                 // group 0's qual / sor / vaf thresholds, level order
+    uint32_t thr_b;                 // the indel groups' sorted threshold slices (skewed)
+    uint32_t gcr_b;                 // gc rank codes [group][len * 11 + count], u16
+    uint32_t css_b;
+};
+
+// Indel tiles: lock-step descents of qual / sor / vaf over the lane's group's sorted threshold slices (slice of
+// feature k: elements [off, off + len) of the staged table); rank = #thresholds < x, NaN -> len (compares false:
+// always the right branch).  The table is SKEWED in LDS - element j sits at dword j + (j >> 5): the candidates of a
+// power-of-two descent step are congruent modulo the step, i.e. on ONE bank in a plain layout.
+__device__ __forceinline__ void rank3_sorted(const float (&fx)[3], uint32_t thr_b, const uint32_t (&off)[3], const uint32_t (&len)[3], int bits,
+                                             uint32_t (&cd)[3]) {
+    uint32_t q[3];                                               // thresholds known to lie below x
+#pragma unroll
+    for (int e = 0; e < 3; ++e) q[e] = 0;
+    for (int s = bits - 1; s >= 0; --s) {
+        uint32_t cand[3];
+        float t[3];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            cand[e] = q[e] + (1u << s);                          // the cand-th threshold of the slice = element off + cand - 1
+            const uint32_t j = off[e] + cand[e] - 1u;
+            t[e] = lds_f32(thr_b + 4u * (j + (j >> 5)));
+        }
+#pragma unroll
+        for (int e = 0; e < 3; ++e) q[e] = (cand[e] <= len[e] && t[e] < fx[e]) ? cand[e] : q[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 3; ++e) cd[e] = fx[e] != fx[e] ? len[e] : q[e];
+}
+
+// SNP tiles: the same ranks from group 0's level-order trees (model_pack.hip): i = 2 i + (t < x), `bits` levels, the
+// leaf index is the rank; three VALU per level and feature, reads of one level on consecutive LDS words.
+__device__ __forceinline__ void rank3_eyt(const float (&fx)[3], const uint32_t (&base)[3], const int (&bits)[3], const uint32_t (&len)[3],
+                                          uint32_t (&cd)[3]) {
+    uint32_t i[3] = {1u, 1u, 1u};
+    const int bmin = min(bits[0], min(bits[1], bits[2])), bmax = max(bits[0], max(bits[1], bits[2]));
+    for (int s = 0; s < bmin; ++s) {
+        float t[3];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) t[e] = lds_f32(base[e] + 4u * i[e]);
+#pragma unroll
+        for (int e = 0; e < 3; ++e) i[e] = 2u * i[e] + (t[e] < fx[e] ? 1u : 0u);
+    }
+    for (int s = bmin; s < bmax; ++s) {
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+            if (s < bits[e]) {
+                const float t = lds_f32(base[e] + 4u * i[e]);
+                i[e] = 2u * i[e] + (t < fx[e] ? 1u : 0u);
+            }
+    }
+#pragma unroll
+    for (int e = 0; e < 3; ++e) cd[e] = fx[e] != fx[e] ? len[e] : i[e] - (1u << bits[e]);
+}
+
+struct SnpCols {                    // the columns of one substitution (fetched one tile ahead of their use)
+    int c, pos, rl;
     uint32_t ro, ao;
     float qual, sor;
     int dp, adr, ada, gq;
 };
 
-struct Scratch {                    // wave-private LDS (byte addresses)
-    uint32_t base;                  // window rows / staged slices / code planes, one after the other in time
-    uint32_t thr_b;                 // float thresholds
-    uint32_t gctab_b;
-    uint32_t css_b;
-};
+__device__ __forceinline__ SnpCols load_snp_cols(const FilterArgs& a, uint32_t i) {
+    SnpCols k;
+    k.c = a.contig[i]; k.pos = a.pos[i]; k.rl = a.ref_len[i];
+    k.ro = a.ref_off[i]; k.ao = a.alt_off[i];
+    k.qual = a.qual[i]; k.sor = a.sor[i];
+    k.dp = a.dp[i]; k.adr = a.ad_ref[i]; k.ada = a.ad_alt[i]; k.gq = a.gq[i];
+    return k;
+}
 
 // ---- SNP / MNP tile: features of 64 substitutions (ref_len == alt_len) ---------------------------------
 // Writes the flags column, leaves the 16-bit codes of the group-0 forest in the wave's code planes.
-__device__ __forceinline__ void featurize_snp_tile(const V5Args& v, const Scratch& sc, int64_t tile, int lane, uint32_t i, bool live,
-                                                   bool has_model) {
+template <int NTRK>
+__device__ __forceinline__ void featurize_snp_tile(const V5Args& v, const Scratch& sc, int64_t tile, int lane, uint32_t i, bool live, bool has_model,
+                                                   const SnpCols& k) {
+    constexpr int NT = 1 + NTRK;                               // interval tables: runs + tracks
     const FilterArgs& a = v.f;
-    const int stage = (a.ablate >> 20) & 15;       // debugging ladder: leave after stage k (0 = run everything)
-    Cols k;
-    if (stage == 10) { if (tile == 1) a.score[lane] = (float)a.contig[i]; return; }
-    if (stage == 11) { if (tile == 1) a.score[lane] = (float)a.ref_len[i]; return; }
-    if (stage == 12) { if (tile == 1) a.score[lane] = (float)(a.ref_off[i] + a.alt_off[i]); return; }
-    if (stage == 13) { if (live) a.flags[i] = 7; return; }
-    k.c = a.contig[i]; k.pos = a.pos[i]; k.rl = a.ref_len[i];
-    k.ro = a.ref_off[i]; k.ao = a.alt_off[i];
-    if (stage == 2) { if (live) a.flags[i] = (uint8_t)k.rl; return; }
-    const int64_t clo = a.contig_off[k.c], chi = a.contig_off[k.c + 1];
+    const int c = k.c, pos = k.pos, rl = k.rl;
+    const uint32_t ro = k.ro, ao = k.ao;
+    const int c0 = rfl(c);
+    const bool uni = __ballot(c != c0) == 0;                    // one contig (all but a handful of tiles)
+    int64_t clo, chi;
+    if (uni) { clo = cload(a.contig_off + c0); chi = cload(a.contig_off + c0 + 1); }   // scalar loads: no round trip in front of the window
+    else { clo = a.contig_off[c]; chi = a.contig_off[c + 1]; }
     const uint32_t clen = (uint32_t)(chi - clo);
-    const uint32_t p0 = (uint32_t)(k.pos - 1);
+    const uint32_t p0 = (uint32_t)(pos - 1);
     const int64_t g0 = clo + p0;
     // 11 bases pos-5 .. pos+5: one dword-aligned 16-byte load, realigned per lane (the buffer is padded by 64
     // bytes at both ends)
     const int64_t wa = (g0 - 5) & ~(int64_t)3;
     const uint32_t sh = (uint32_t)(g0 - 5) & 3u;
     const uint4 xw = *reinterpret_cast<const uint4*>(a.ref + wa);
-    const uint32_t rbase = a.alleles[k.ro], abase = a.alleles[k.ao];
-    if (stage == 3) { if (live) a.flags[i] = (uint8_t)(xw.x + rbase + abase); return; }
-    k.qual = a.qual[i]; k.sor = a.sor[i];
-    k.dp = a.dp[i]; k.adr = a.ad_ref[i]; k.ada = a.ad_alt[i]; k.gq = a.gq[i];
-    if (stage == 4) { if (live) a.flags[i] = (uint8_t)(k.dp + k.gq + (int)k.qual); return; }
+    const uint32_t rbase = a.alleles[ro], abase = a.alleles[ao];
 
     // ---- side-table slices of this tile -> wave-private LDS (sentinel padded)
-    const int c0 = rfl(k.c);
-    const bool uni = __ballot(k.c != c0) == 0;                  // one contig (all but a handful of tiles)
     const int n_live = (int)__popcll(__ballot(live));
-    const int pos_max = __builtin_amdgcn_readlane(k.pos, n_live - 1);
-    const uint64_t key = ((uint64_t)(uint32_t)k.c << 32) | (uint32_t)k.pos;
-    const uint64_t key_max = ((uint64_t)(uint32_t)c0 << 32) | (uint32_t)pos_max;
-    int L[kJoin5], plo[kJoin5 - 1], phi[kJoin5 - 1];
+    const int pos_max = __builtin_amdgcn_readlane(pos, n_live - 1);
+    const uint64_t key = ((uint64_t)(uint32_t)c << 32) | (uint32_t)pos;
     const bool joins_on = !(a.ablate & 524288);
+    int L[NT], plo[NT], phi[NT];
     if (uni && joins_on) {
 #pragma unroll
-        for (int t = 0; t < kJoin5 - 1; ++t) {
+        for (int t = 0; t < NT; ++t) {
             L[t] = plo[t] = phi[t] = 0;
-            if (!table_present(a, t)) continue;
+            if (t == 0 && !a.has_runs) continue;
             const TrackView& tv = table_view(a, t);
             const int cap = v.jcap[t];
             L[t] = cload(v.br_snp + tile * 8 + t) - 2;
             plo[t] = cload(tv.ptr + c0);
             phi[t] = cload(tv.ptr + c0 + 1);
-            const int na = v.na[t];
+            const int top = max(v.na[t] - 1, 0);
             const uint32_t dS = sc.base + 4u * (uint32_t)v.joff[t], dE = dS + 4u * (uint32_t)cap;
-            for (int e = lane; e < cap; e += 64) {
-                const int gi = L[t] + e;
-                const int gs = gi < 0 ? 0 : (gi >= na ? (na > 0 ? na - 1 : 0) : gi);
+            {
+                const int gi = L[t] + lane;
+                const uint32_t gs = (uint32_t)max(min(gi, top), 0);
                 const int sv = tv.starts[gs], ev = tv.ends[gs];
-                *(UGVC_LDS int32_t*)(uintptr_t)(dS + 4u * e) = gi < plo[t] ? INT32_MIN : (gi >= phi[t] ? INT32_MAX : sv);
-                *(UGVC_LDS int32_t*)(uintptr_t)(dE + 4u * e) = ev;
+                lds_st32(dS + 4u * lane, gi < plo[t] ? INT32_MIN : (gi >= phi[t] ? INT32_MAX : sv));
+                lds_st32(dE + 4u * lane, ev);
+            }
+            if (cap > 64) {
+                const int gi = L[t] + 64 + lane;
+                const uint32_t gs = (uint32_t)max(min(gi, top), 0);
+                const int sv = tv.starts[gs], ev = tv.ends[gs];
+                lds_st32(dS + 256u + 4u * lane, gi < plo[t] ? INT32_MIN : (gi >= phi[t] ? INT32_MAX : sv));
+                lds_st32(dE + 256u + 4u * lane, ev);
             }
         }
-        {
-            const int t = kJoin5 - 1;
-            L[t] = 0;
-            if (a.n_bl > 0) {
-                const int cap = v.jcap[t];
-                L[t] = cload(v.br_snp + tile * 8 + t);
-                const uint32_t dK = sc.base + 4u * (uint32_t)v.joff[t];
-                for (int e = lane; e < cap; e += 64) {
-                    const int64_t gi = (int64_t)L[t] + e;
-                    const uint64_t kv = gi < a.n_bl ? a.bl[gi] : ~0ull;
-                    *(UGVC_LDS uint64_t*)(uintptr_t)(dK + 8u * e) = kv;
-                }
-            }
+        if (a.n_bl > 0) {
+            const int64_t gi = (int64_t)cload(v.br_snp + tile * 8 + kJoin5 - 1) + lane;
+            lds_st64(sc.base + 4u * (uint32_t)v.joff[kJoin5 - 1] + 8u * lane, gi < a.n_bl ? a.bl[gi] : ~0ull);
         }
     }
+    const float qual = k.qual, sor = k.sor;
+    const int dp = k.dp, adr = k.adr, ada = k.ada, gq = k.gq;
 
     // ---- window: bases pos-5 .. pos+5 in bytes 0..10 of (w0, w1, w2)
     uint32_t w0 = __builtin_amdgcn_alignbyte(xw.y, xw.x, sh);
@@ -333,182 +458,150 @@ __device__ __forceinline__ void featurize_snp_tile(const V5Args& v, const Scratc
     const bool motif_n = any_zero_byte(w0) || any_zero_byte(w1 | 0x0000FF00u) || any_zero_byte(w2 | 0xFF000000u);
     // gc_content (10): bases pos-4 .. pos+5; everything that is not A / T counts (N included, as the reference's string test)
     const uint32_t n_at = (uint32_t)__popc(at_bytes(w0) & 0x01010100u) + (uint32_t)__popc(at_bytes(w1)) + (uint32_t)__popc(at_bytes(w2) & 0x00010101u);
-    const uint32_t gc_cnt = gc_len - n_at;
-    const float gc = lds_f32(sc.gctab_b + 4u * (gc_len * 11u + gc_cnt));
-    if (stage == 5) { if (live) a.flags[i] = (uint8_t)(gc * 10.f + lm + rm); return; }
+    const uint32_t gc_code = lds_u16(sc.gcr_b + 2u * (gc_len * 11u + (gc_len - n_at)));       // group 0
     // cycle skip
-    int css;
-    if (motif_n || rbase == 0 || abase == 0) css = 0;
-    else css = *(UGVC_LDS const uint8_t*)(uintptr_t)(sc.css_b + (((b4 - 1) << 6) | ((rbase - 1) << 4) | ((abase - 1) << 2) | (b6 - 1)));
-    if (__ballot(k.rl > 1) != 0) {                               // MNPs: the full flow-space walk
-        if (k.rl > 1) {
+    int css = 0;
+    if (!(motif_n || rbase == 0 || abase == 0)) css = (int)lds_u8(sc.css_b + (((b4 - 1) << 6) | ((rbase - 1) << 4) | ((abase - 1) << 2) | (b6 - 1)));
+    if (__ballot(rl > 1) != 0) {                                 // MNPs: the full flow-space walk
+        if (rl > 1) {
             const uint8_t* __restrict__ apool = a.alleles;
             bool has_n = motif_n;
-            for (int q = 0; q < k.rl; ++q) has_n |= apool[k.ro + q] == 0 || apool[k.ao + q] == 0;
+            for (int q = 0; q < rl; ++q) has_n |= apool[ro + q] == 0 || apool[ao + q] == 0;
             if (has_n) css = 0;
             else {
                 auto wbyte = [&](int q) -> int { return (int)(((q < 4 ? w0 : (q < 8 ? w1 : w2)) >> (8 * (q & 3))) & 0xFFu); };
                 auto seq_r = [&](int q) -> int {
                     if (q < kMotif) return wbyte(q);
-                    if (q < kMotif + k.rl) return apool[k.ro + q - kMotif];
-                    return wbyte(q - k.rl + 1);
+                    if (q < kMotif + rl) return apool[ro + q - kMotif];
+                    return wbyte(q - rl + 1);
                 };
                 auto seq_a = [&](int q) -> int {
                     if (q < kMotif) return wbyte(q);
-                    if (q < kMotif + k.rl) return apool[k.ao + q - kMotif];
-                    return wbyte(q - k.rl + 1);
+                    if (q < kMotif + rl) return apool[ao + q - kMotif];
+                    return wbyte(q - rl + 1);
                 };
-                css = cycle_skip_walk(k.rl + 2 * kMotif, a.flow, seq_r, seq_a);
+                css = cycle_skip_walk(rl + 2 * kMotif, a.flow, seq_r, seq_a);
             }
         }
     }
 
-    if (stage == 6) { if (live) a.flags[i] = (uint8_t)css; return; }
     // ---- joins
     JoinOut jo{false, false, false, 0u};
     if (!joins_on) {
     } else if (uni) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // rank among the staged starts of every table, all descents in lock-step; a table whose staged slice
-        // does not reach the tile's last variant is searched in HBM instead (dense stretches)
-        uint32_t p[kJoin5];
-        bool cov[kJoin5];
-        int maxcap = 0;
+        // rank among the staged starts of every table: seven descent steps in lock-step, no bounds test (sentinels)
+        // and no branch (a table staged with 64 entries makes a step of zero at 64)
+        uint32_t p[NT], A[NT], maskB[NT];
+        const uint32_t Ab = sc.base + 4u * (uint32_t)v.joff[kJoin5 - 1];
+        uint32_t pb = Ab - 8u;
+        const uint64_t key_max = ((uint64_t)(uint32_t)c0 << 32) | (uint32_t)pos_max;
+        bool miss = false;
 #pragma unroll
-        for (int t = 0; t < kJoin5; ++t) {
-            const int cap = v.jcap[t];
-            const bool present = t == kJoin5 - 1 ? a.n_bl > 0 : table_present(a, t);
-            const uint32_t A = sc.base + 4u * (uint32_t)v.joff[t];
-            cov[t] = false;
-            p[t] = A - (t == kJoin5 - 1 ? 8u : 4u);
-            if (present && cap > 0) {
-                if (t == kJoin5 - 1) cov[t] = lds_u64(A + 8u * (uint32_t)(cap - 1)) >= key_max;
-                else cov[t] = lds_i32(A + 4u * (uint32_t)(cap - 1)) >= pos_max;
-                cov[t] = rfl((int)cov[t]) != 0;
-                if (cov[t]) maxcap = cap > maxcap ? cap : maxcap;
-            }
+        for (int t = 0; t < NT; ++t) {
+            A[t] = sc.base + 4u * (uint32_t)v.joff[t];
+            p[t] = A[t] - 4u;
+            maskB[t] = 4u * (uint32_t)(v.jcap[t] - 1);
+            // a staged slice that does not reach the tile's last variant: that table is searched in HBM (dense stretches)
+            if (t > 0 || a.has_runs) miss |= lds_i32(A[t] + maskB[t]) < pos_max;
         }
-        for (int s = maxcap >> 1; s >= 1; s >>= 1) {
-            uint32_t cand[kJoin5];
-            int x[kJoin5 - 1];
-            uint64_t xk = 0;
+        if (a.n_bl > 0) miss |= lds_u64(Ab + 8u * (kBlCap5 - 1)) < key_max;
 #pragma unroll
-            for (int t = 0; t < kJoin5 - 1; ++t) {
-                cand[t] = p[t] + 4u * (uint32_t)s;
-                x[t] = INT32_MAX;
-                if (cov[t] && s < v.jcap[t]) x[t] = lds_i32(cand[t]);
+        for (int sb = 256; sb >= 4; sb >>= 1) {
+            uint32_t cand[NT];
+            int x[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                cand[t] = p[t] + ((uint32_t)sb & maskB[t]);
+                x[t] = lds_i32(cand[t]);
             }
-            cand[kJoin5 - 1] = p[kJoin5 - 1] + 8u * (uint32_t)s;
-            if (cov[kJoin5 - 1] && s < v.jcap[kJoin5 - 1]) xk = lds_u64(cand[kJoin5 - 1]);
-            else xk = ~0ull;
+            const uint32_t cb = pb + (uint32_t)((2 * sb) & (8 * (kBlCap5 - 1)));
+            const uint64_t xk = lds_u64(cb);
 #pragma unroll
-            for (int t = 0; t < kJoin5 - 1; ++t) p[t] = x[t] < k.pos ? cand[t] : p[t];
-            p[kJoin5 - 1] = xk < key ? cand[kJoin5 - 1] : p[kJoin5 - 1];
+            for (int t = 0; t < NT; ++t) p[t] = x[t] < pos ? cand[t] : p[t];
+            pb = xk < key ? cb : pb;
         }
-        bool missed = false;
 #pragma unroll
-        for (int t = 0; t < kJoin5 - 1; ++t) {
-            if (!table_present(a, t)) continue;
-            if (!cov[t]) { missed = true; continue; }
-            const uint32_t A = sc.base + 4u * (uint32_t)v.joff[t];
+        for (int t = 0; t < NT; ++t) {
+            if (t == 0 && !a.has_runs) continue;
             const uint32_t dE = 4u * (uint32_t)v.jcap[t];
-            const int r = (int)((p[t] + 4u - A) >> 2);             // staged starts below pos
-            const int sg = L[t] + r;
-            auto S = [&](int gi) { return lds_i32(A + 4u * (uint32_t)(gi - L[t])); };
-            auto E = [&](int gi) { return lds_i32(A + dE + 4u * (uint32_t)(gi - L[t])); };
-            interval_verdict(t, sg, plo[t], phi[t], k.pos, a.hpol_dist, S, E, jo);
+            const int sg = L[t] + (int)((p[t] + 4u - A[t]) >> 2);   // staged starts below pos
+            const uint32_t ps = p[t];                               // LDS address of starts[sg - 1]
+            auto S = [&](int gi) { return lds_i32(ps + 4u * (uint32_t)(gi - sg + 1)); };
+            auto E = [&](int gi) { return lds_i32(ps + dE + 4u * (uint32_t)(gi - sg + 1)); };
+            interval_verdict(t, sg, plo[t], phi[t], pos, a.hpol_dist, S, E, jo);
         }
-        if (a.n_bl > 0) {
-            const int t = kJoin5 - 1;
-            if (!cov[t]) missed = true;
-            else if (lds_u64(p[t] + 8u) == key) jo.cohort = true;   // the staged key at the rank (sentinel beyond the table)
-        }
-        if (missed) {
-            int lo_[kJoin5], hi_[kJoin5];
+        if (a.n_bl > 0 && lds_u64(pb + 8u) == key) jo.cohort = true;   // the staged key at the rank (sentinel beyond the table)
+        if (__ballot(miss) != 0) {
 #pragma unroll
-            for (int t = 0; t < kJoin5 - 1; ++t) {
-                const bool need = table_present(a, t) && !cov[t];
-                lo_[t] = plo[t];
-                hi_[t] = need ? phi[t] : plo[t];
+            for (int t = 0; t < NT; ++t) {
+                if (t == 0 && !a.has_runs) continue;
+                if (__ballot(lds_i32(A[t] + maskB[t]) < pos_max) != 0) join_one_global(&a, t, plo[t], phi[t], plo[t], phi[t], pos, key, &jo);
             }
-            lo_[kJoin5 - 1] = 0;
-            hi_[kJoin5 - 1] = (a.n_bl > 0 && !cov[kJoin5 - 1]) ? (int)a.n_bl : 0;
-            JoinOut j2{false, false, false, 0u};
-            join_global(a, lo_, hi_, plo, phi, k.pos, key, j2);
-            // only the tables searched here report
-            if (table_present(a, 0) && !cov[0]) { jo.inside_run = j2.inside_run; jo.close_run = j2.close_run; }
-#pragma unroll
-            for (int t = 1; t < kJoin5 - 1; ++t)
-                if (table_present(a, t) && !cov[t]) jo.trk = (jo.trk & ~(1u << (t - 1))) | (j2.trk & (1u << (t - 1)));
-            if (a.n_bl > 0 && !cov[kJoin5 - 1]) jo.cohort = j2.cohort;
+            if (a.n_bl > 0 && __ballot(lds_u64(Ab + 8u * (kBlCap5 - 1)) < key_max) != 0)
+                join_one_global(&a, kJoin5 - 1, 0, (int)a.n_bl, 0, 0, pos, key, &jo);
         }
     } else {
         // a tile that spans contigs: every lane searches its own contig's rows
-        int lo_[kJoin5], hi_[kJoin5], pl[kJoin5 - 1], ph[kJoin5 - 1];
 #pragma unroll
-        for (int t = 0; t < kJoin5 - 1; ++t) {
-            pl[t] = ph[t] = 0;
-            if (table_present(a, t)) {
-                const TrackView& tv = table_view(a, t);
-                pl[t] = tv.ptr[k.c];
-                ph[t] = tv.ptr[k.c + 1];
-            }
-            lo_[t] = pl[t];
-            hi_[t] = ph[t];
+        for (int t = 0; t < NT; ++t) {
+            if (t == 0 && !a.has_runs) continue;
+            const TrackView& tv = table_view(a, t);
+            const int pl = tv.ptr[c], ph = tv.ptr[c + 1];
+            join_one_global(&a, t, pl, ph, pl, ph, pos, key, &jo);
         }
-        lo_[kJoin5 - 1] = 0;
-        hi_[kJoin5 - 1] = (int)a.n_bl;
-        join_global(a, lo_, hi_, pl, ph, k.pos, key, jo);
+        if (a.n_bl > 0) join_one_global(&a, kJoin5 - 1, 0, (int)a.n_bl, 0, 0, pos, key, &jo);
     }
     uint8_t flags = (uint8_t)(jo.trk << UGVC_FLAG_TRACK0_SHIFT);
     if (jo.cohort) flags |= UGVC_FLAG_COHORT_FP;
     if (a.mark_hpol && (jo.inside_run || jo.close_run)) flags |= UGVC_FLAG_HPOL_RUN;
     if (live) a.flags[i] = flags;
-    if (!has_model || stage == 7) return;
+    if (!has_model) return;
 
     // ---- codes -> the wave's code planes (the staged slices are dead: LDS executes a wave's accesses in order)
-    const float vaf = k.dp > 0 ? __fdiv_rn((float)k.ada, (float)k.dp) : 0.0f;
-    const uint32_t used = v.used5[0];
+    const float vaf = dp > 0 ? __fdiv_rn((float)ada, (float)dp) : 0.0f;
+    uint32_t cd[3];
+    {
+        const float fx[3] = {qual, sor, vaf};
+        const int fj[3] = {0, 1, 5};
+        uint32_t base[3], len[3];
+        int bits[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            base[q] = sc.eyt_b + 4u * (uint32_t)v.eyt_off[q];
+            bits[q] = v.eyt_bits[q];
+            len[q] = cload2(v.desc3 + fj[q]).y & 0xFFFFu;             // group 0
+        }
+        rank3_eyt(fx, base, bits, len, cd);
+    }
+    __builtin_amdgcn_wave_barrier();
     const int hslot = ((lane & 31) << 1) | (lane >> 5);
     const uint32_t pl_b = sc.base + 2u * (uint32_t)hslot;
-    auto put = [&](int f, uint32_t code) {
-        if (used & (1u << f)) *(UGVC_LDS uint16_t*)(uintptr_t)(pl_b + 128u * (uint32_t)f) = (uint16_t)code;
-    };
-    {
-        const float fx[4] = {k.qual, k.sor, vaf, gc};
-        const int fj[4] = {0, 1, 5, 13};
-        uint32_t cd[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            cd[q] = 0;
-            if (!(used & (1u << fj[q]))) continue;
-            const uint2 d = cload2(v.desc3 + fj[q]);                 // group 0
-            const uint32_t off = d.x & 0xFFFFFu, len = d.y & 0xFFFFu;
-            const uint32_t q0 = sc.thr_b + 4u * off - 4u;
-            cd[q] = rank_f32(fx[q], q0, q0 + 4u * len, v.thr0_bits4[q]);
-            if (fx[q] != fx[q]) cd[q] = len;                        // NaN compares false: always the right branch
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int q = 0; q < 4; ++q) put(fj[q], cd[q]);
+    lds_st16(pl_b + 128u * 0, cd[0]);
+    lds_st16(pl_b + 128u * 1, cd[1]);
+    lds_st16(pl_b + 128u * 2, raw_code(dp, v.cap5[0][2]));
+    lds_st16(pl_b + 128u * 3, raw_code(adr, v.cap5[0][3]));
+    lds_st16(pl_b + 128u * 4, raw_code(ada, v.cap5[0][4]));
+    lds_st16(pl_b + 128u * 5, cd[2]);
+    lds_st16(pl_b + 128u * 6, raw_code(gq, v.cap5[0][6]));
+    if (v.used5[0] & 0x780u) {                                       // classify, indel_length, hmer length / base: 0
+        lds_st16(pl_b + 128u * 7, 1u); lds_st16(pl_b + 128u * 8, 1u); lds_st16(pl_b + 128u * 9, 1u); lds_st16(pl_b + 128u * 10, 1u);
     }
-    put(2, raw_code(k.dp, v.cap5[0][2]));
-    put(3, raw_code(k.adr, v.cap5[0][3]));
-    put(4, raw_code(k.ada, v.cap5[0][4]));
-    put(6, raw_code(k.gq, v.cap5[0][6]));
-    put(7, 1u); put(8, 1u); put(9, 1u); put(10, 1u);                // classify, indel_length, hmer length / base: 0
-    put(11, raw_code(lm, v.cap5[0][11]));
-    put(12, raw_code(rm, v.cap5[0][12]));
-    put(14, raw_code(css, v.cap5[0][14]));
-    put(15, jo.inside_run ? 2u : 1u);
-    put(16, jo.close_run ? 2u : 1u);
+    lds_st16(pl_b + 128u * 11, raw_code(lm, v.cap5[0][11]));
+    lds_st16(pl_b + 128u * 12, raw_code(rm, v.cap5[0][12]));
+    lds_st16(pl_b + 128u * 13, gc_code);
+    lds_st16(pl_b + 128u * 14, raw_code(css, v.cap5[0][14]));
+    lds_st16(pl_b + 128u * 15, jo.inside_run ? 2u : 1u);
+    lds_st16(pl_b + 128u * 16, jo.close_run ? 2u : 1u);
 #pragma unroll
-    for (int t = 0; t < UGVC_MAX_TRACKS; ++t) put(17 + t, (jo.trk >> t) & 1u ? 2u : 1u);
+    for (int t = 0; t < UGVC_MAX_TRACKS; ++t) lds_st16(pl_b + 128u * (17 + t), (jo.trk >> t) & 1u ? 2u : 1u);
 }
 
 // ---- indel tile: features of 64 length-changing variants -> raw-code records of groups 1 / 2 -------------
+template <int NTRK>
 __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scratch& sc, int64_t tile, int lane, uint32_t i, bool live) {
+    constexpr int NT = 1 + NTRK;
     const FilterArgs& a = v.f;
     const uint8_t* __restrict__ apool = a.alleles;
     const int c = a.contig[i], pos = a.pos[i], rl = a.ref_len[i], al = a.alt_len[i];
@@ -524,7 +617,6 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
     if (ws < 0) ws = 0;
     const int o0 = (int)(g0 - ws);                            // byte of the variant's first base, 6..21 (less at genome start)
     const uint32_t wrow_b = sc.base + (uint32_t)(lane * kWinRowB);
-    UGVC_LDS uint32_t* wrow = (UGVC_LDS uint32_t*)(uintptr_t)wrow_b;
     {
         const uint4* src = reinterpret_cast<const uint4*>(a.ref + ws);
         const uint4 x0 = src[0], x1 = src[1], x2 = src[2];
@@ -542,7 +634,7 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
             }
         }
 #pragma unroll
-        for (int q = 0; q < kWinDw; ++q) wrow[q] = w[q];
+        for (int q = 0; q < kWinDw; ++q) lds_st32(wrow_b + 4u * q, (int32_t)w[q]);
     }
     // allele bytes: the tail of the longer allele
     const uint32_t lo_off = ins ? ao : ro;
@@ -552,11 +644,9 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
     ab[1] = apool[lo_off + (2 < ln ? 2 : ln - 1)];
 #pragma unroll
     for (int q = 2; q < 8; ++q) ab[q] = apool[lo_off + (q + 1 < ln ? q + 1 : ln - 1)];
-    const float qual = a.qual[i], sor = a.sor[i];
-    const int dp = a.dp[i], adr = a.ad_ref[i], ada = a.ad_alt[i], gq = a.gq[i];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    auto wb = [&](int o) -> int { return (int)*(UGVC_LDS const uint8_t*)(uintptr_t)(wrow_b + (uint32_t)o); };
+    auto wb = [&](int o) -> int { return (int)lds_u8(wrow_b + (uint32_t)o); };
     auto ref_at = [&](int d) -> int {                         // reference base at contig offset p0 + d (0 outside the contig)
         const int o = o0 + d;
         if (o >= 0 && o < kWinBytes) return wb(o);
@@ -625,42 +715,44 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
         gc_len += inb;
         gc_cnt += inb && bb != 1 && bb != 4;
     }
-    const float gc = lds_f32(sc.gctab_b + 4u * (uint32_t)(gc_len * 11 + gc_cnt));
+    const uint32_t gc_idx = (uint32_t)(gc_len * 11 + gc_cnt);
 
     // ---- joins on the resident tables, inside the tile's brackets
     const int c0 = rfl(c);
     const bool uni = __ballot(c != c0) == 0;
     const uint64_t key = ((uint64_t)(uint32_t)c << 32) | (uint32_t)pos;
     JoinOut jo{false, false, false, 0u};
-    if (!(a.ablate & 524288)) {
+    if (a.ablate & 524288) {
+    } else if (uni) {
         int lo_[kJoin5], hi_[kJoin5], pl[kJoin5 - 1], ph[kJoin5 - 1];
 #pragma unroll
-        for (int t = 0; t < kJoin5 - 1; ++t) {
+        for (int t = 0; t < NT; ++t) {
             pl[t] = ph[t] = lo_[t] = hi_[t] = 0;
-            if (!table_present(a, t)) continue;
+            if (t == 0 && !a.has_runs) continue;
             const TrackView& tv = table_view(a, t);
-            if (uni) {
-                pl[t] = cload(tv.ptr + c0);
-                ph[t] = cload(tv.ptr + c0 + 1);
-                lo_[t] = cload(v.br_indel + tile * 16 + t);
-                hi_[t] = cload(v.br_indel + tile * 16 + 8 + t);
-            } else {
-                pl[t] = tv.ptr[c];
-                ph[t] = tv.ptr[c + 1];
-                lo_[t] = pl[t];
-                hi_[t] = ph[t];
-            }
+            pl[t] = cload(tv.ptr + c0);
+            ph[t] = cload(tv.ptr + c0 + 1);
+            lo_[t] = cload(v.br_indel + tile * 16 + t);
+            hi_[t] = cload(v.br_indel + tile * 16 + 8 + t);
         }
-        lo_[kJoin5 - 1] = uni ? cload(v.br_indel + tile * 16 + kJoin5 - 1) : 0;
-        hi_[kJoin5 - 1] = uni ? cload(v.br_indel + tile * 16 + 8 + kJoin5 - 1) : (int)a.n_bl;
-        join_global(a, lo_, hi_, pl, ph, pos, key, jo);
+        lo_[kJoin5 - 1] = cload(v.br_indel + tile * 16 + kJoin5 - 1);
+        hi_[kJoin5 - 1] = cload(v.br_indel + tile * 16 + 8 + kJoin5 - 1);
+        join_bracketed<NTRK>(a, lo_, hi_, pl, ph, pos, key, jo);
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (t == 0 && !a.has_runs) continue;
+            const TrackView& tv = table_view(a, t);
+            const int pl = tv.ptr[c], ph = tv.ptr[c + 1];
+            join_one_global(&a, t, pl, ph, pl, ph, pos, key, &jo);
+        }
+        if (a.n_bl > 0) join_one_global(&a, kJoin5 - 1, 0, (int)a.n_bl, 0, 0, pos, key, &jo);
     }
     uint8_t flags = (uint8_t)(jo.trk << UGVC_FLAG_TRACK0_SHIFT);
     if (jo.cohort) flags |= UGVC_FLAG_COHORT_FP;
     if (a.mark_hpol && (jo.inside_run || jo.close_run)) flags |= UGVC_FLAG_HPOL_RUN;
     if (live) a.flags[i] = flags;
-    const bool ok1 = v.pg[1].ok != 0, ok2 = v.pg[2].ok != 0;
-    const bool pg_ok = group == 1 ? ok1 : ok2;
+    const bool pg_ok = group == 1 ? v.pg[1].ok != 0 : v.pg[2].ok != 0;
     if (live && !pg_ok) {                                      // no model for this variant type: score 0, PASS
         a.score[i] = 0.f;
         a.filter[i] = UGVC_FILTER_PASS;
@@ -676,42 +768,25 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
     const unsigned grank = (unsigned)__popcll((group == 1 ? m1 : m2) & below);
 
     // ---- codes of the lane's own group
+    const float qual = a.qual[i], sor = a.sor[i];
+    const int dp = a.dp[i], adr = a.ad_ref[i], ada = a.ad_alt[i], gq = a.gq[i];
     const float vaf = dp > 0 ? __fdiv_rn((float)ada, (float)dp) : 0.0f;
     uint32_t cd[4] = {0, 0, 0, 0};
     if (__ballot(mine) != 0) {
-        const float fx[4] = {qual, sor, vaf, gc};
-        const int fj[4] = {0, 1, 5, 13};
-        uint32_t q[4], q0[4], qend[4], len4[4];
+        const float fx[3] = {qual, sor, vaf};
+        const int fj[3] = {0, 1, 5};
+        uint32_t off3[3], len3[3], c3[3];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < 3; ++s) {
             const uint2 d1 = cload2(v.desc3 + 1 * kMaxFeatures + fj[s]), d2 = cload2(v.desc3 + 2 * kMaxFeatures + fj[s]);
-            const uint32_t off = (group == 1 ? d1.x : d2.x) & 0xFFFFFu;
-            len4[s] = (group == 1 ? d1.y : d2.y) & 0xFFFFu;
-            q0[s] = sc.thr_b + 4u * off - 4u;
-            q[s] = q0[s];
-            qend[s] = q0[s] + 4u * len4[s];
+            off3[s] = ((group == 1 ? d1.x : d2.x) & 0xFFFFFu) - (uint32_t)v.thr0_len;       // the staged table starts at group 1
+            len3[s] = (group == 1 ? d1.y : d2.y) & 0xFFFFu;
         }
-        const int fbm = max(max(v.thr_bits4[0], v.thr_bits4[1]), max(v.thr_bits4[2], v.thr_bits4[3]));
-        for (int s = fbm - 1; s >= 0; --s) {
-            uint32_t cand[4];
-            float t[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                cand[e] = q[e] + (4u << s);
-                t[e] = lds_f32(cand[e]);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) q[e] = ((int32_t)(qend[e] - cand[e]) >= 0 && t[e] < fx[e]) ? cand[e] : q[e];
-        }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            cd[s] = (q[s] - q0[s]) >> 2;
-            if (fx[s] != fx[s]) cd[s] = len4[s];
-        }
+        rank3_sorted(fx, sc.thr_b, off3, len3, v.thr_bits, c3);
+        cd[0] = c3[0]; cd[1] = c3[1]; cd[2] = c3[2];
+        cd[3] = lds_u16(sc.gcr_b + 2u * ((uint32_t)group * kGcRank + gc_idx));
     }
-    const int* cap = group == 1 ? v.cap5[1] : v.cap5[2];
     auto rc = [&](int f, int x) -> uint32_t { return raw_code(x, group == 1 ? v.cap5[1][f] : v.cap5[2][f]); };
-    (void)cap;
     uint32_t r[kRec5Dwords];
     r[0] = cd[0] | (cd[1] << 16);                                        // qual, sor
     r[1] = rc(2, dp) | (rc(3, adr) << 16);
@@ -735,11 +810,25 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
 }
 
 // ---- single-sum walk of one forest over the wave's code planes -> (tree_score, FILTER) -------------------
+template <int NTM>
 __device__ __forceinline__ void walk_forest(const PackedGroupView& pg, uint32_t hi_b, uint32_t last_b, uint32_t p1_b,
                                             uint32_t planes_lane_b, float& score, uint8_t& filt) {
     const int T = pg.T, D = pg.D, H = (1 << D) >> 1;
     double a1 = 0.0;
     int t = 0;
+    if (NTM > 8) {
+        // more trees in flight per lane: in the fused kernel only part of a CU's waves walk at any time, so a walking
+        // wave has to keep more LDS requests outstanding to fill the pipeline
+        for (; t + NTM <= T; t += NTM) {
+            uint32_t pi[NTM];
+            walk4<NTM>(hi_b, last_b, planes_lane_b, t, D, H, pi);
+            double pv[NTM];
+#pragma unroll
+            for (int q = 0; q < NTM; ++q) pv[q] = lds_f64(p1_b + 8u * pi[q]);
+#pragma unroll
+            for (int q = 0; q < NTM; ++q) a1 += pv[q];
+        }
+    }
     for (; t + 8 <= T; t += 8) {
         uint32_t pi[8];
         walk4<8>(hi_b, last_b, planes_lane_b, t, D, H, pi);
@@ -772,13 +861,14 @@ __device__ __forceinline__ void walk_forest(const PackedGroupView& pg, uint32_t 
     }
 }
 
-// LDS of a workgroup: group forest (hi | last | p1, 16-byte padded) | thresholds | gctab | css | wave scratch
+// LDS of a workgroup: group forest (hi | last | p1, 16-byte padded) | group 0's level-order threshold trees | the
+// indel groups' sorted thresholds (skewed) | gc rank codes | css | wave scratch
 struct Lds5 {
-    uint32_t hi_b, last_b, p1_b, thr_b, gctab_b, css_b, scratch_b;
+    uint32_t hi_b, last_b, p1_b, eyt_b, thr_b, gcr_b, css_b, scratch_b;
 };
 
-__device__ __forceinline__ Lds5 lds5_fill(unsigned char* smem, const PackedGroupView& pg, bool with_forest, const float* thr, int n_thr,
-                                          const uint8_t* css_lut, int tid, int nthreads) {
+__device__ __forceinline__ Lds5 lds5_fill(unsigned char* smem, const V5Args& v, bool with_forest, int tid, int nthreads) {
+    const PackedGroupView& pg = v.pg[0];
     Lds5 L;
     size_t off = 0;
     const size_t n_hi = with_forest ? ((size_t)pg.T << pg.D) / 2 : 0;
@@ -802,36 +892,60 @@ __device__ __forceinline__ Lds5 lds5_fill(unsigned char* smem, const PackedGroup
             else d2[q - n0 - n1] = s2[q - n0 - n1];
         }
     }
+    float* eyt_l = reinterpret_cast<float*>(smem + off);
+    for (int q = tid; q < v.eyt_len / 4; q += nthreads) reinterpret_cast<float4*>(eyt_l)[q] = reinterpret_cast<const float4*>(v.eyt)[q];
+    L.eyt_b = lds_addr(eyt_l);
+    off += (size_t)v.eyt_len * 4;
     float* thr_l = reinterpret_cast<float*>(smem + off);
-    const size_t b_thr = ((size_t)n_thr * 4 + 15) & ~(size_t)15;
-    for (int q = tid; q < (n_thr + 3) / 4; q += nthreads) reinterpret_cast<float4*>(thr_l)[q] = reinterpret_cast<const float4*>(thr)[q];
+    const int n_thr = v.thr_lds_len - v.thr0_len;                                          // groups 1 and 2
+    for (int q = tid; q < n_thr; q += nthreads) thr_l[q + (q >> 5)] = v.thr[v.thr0_len + q];   // skewed: element j at j + (j >> 5)
     L.thr_b = lds_addr(thr_l);
-    off += b_thr;
-    float* gct = reinterpret_cast<float*>(smem + off);
-    for (int q = tid; q < kGcTab; q += nthreads) {
-        const int len = q / 11, cnt = q % 11;
-        gct[q] = (len > 0 && len <= 10 && cnt <= len) ? (float)((double)cnt / (double)len) : 0.0f;
+    off += ((size_t)(n_thr + (n_thr >> 5) + 1) * 4 + 15) & ~(size_t)15;
+    uint16_t* gcr = reinterpret_cast<uint16_t*>(smem + off);
+    for (int q = tid; q < UGVC_N_GROUPS * kGcRank; q += nthreads) {
+        const int g = q / kGcRank, r = q % kGcRank, len = r / 11, cnt = r % 11;
+        const float f = (len > 0 && cnt <= len) ? (float)((double)cnt / (double)len) : 0.0f;
+        const uint2 d = v.desc3[g * kMaxFeatures + 13];
+        const float* t = v.thr + (d.x & 0xFFFFFu);
+        const int n = (int)(d.y & 0xFFFFu);
+        int rank = 0;
+        for (int e = 0; e < n; ++e) rank += t[e] < f ? 1 : 0;
+        gcr[q] = (uint16_t)rank;
     }
-    L.gctab_b = lds_addr(gct);
-    off += kGcTab * 4;
+    L.gcr_b = lds_addr(gcr);
+    off += kGcRankBytes;
     uint8_t* css = smem + off;
-    for (int q = tid; q < 256; q += nthreads) css[q] = css_lut[q];
+    for (int q = tid; q < 256; q += nthreads) css[q] = v.css_lut[q];
     L.css_b = lds_addr(css);
     off += 256;
     L.scratch_b = lds_addr(smem + off);
     return L;
 }
 
-static size_t lds5_bytes(const PackedGroupView& pg, bool with_forest, int n_thr, int n_waves, int scratch_bytes) {
+static size_t lds5_bytes(const V5Args& v, int n_waves) {
+    const PackedGroupView& pg = v.pg[0];
+    const bool with_forest = pg.ok != 0;
     const size_t n_hi = with_forest ? ((size_t)pg.T << pg.D) / 2 : 0;
     size_t b = ((n_hi * 4 + 15) & ~(size_t)15) + ((n_hi * 8 + 15) & ~(size_t)15);
     if (with_forest) b += ((size_t)pg.n_pairs * 8 + 15) & ~(size_t)15;
-    b += ((size_t)n_thr * 4 + 15) & ~(size_t)15;
-    b += kGcTab * 4 + 256;
-    return b + (size_t)n_waves * scratch_bytes;
+    b += (size_t)v.eyt_len * 4;
+    const int n_thr = v.thr_lds_len - v.thr0_len;
+    b += ((size_t)(n_thr + (n_thr >> 5) + 1) * 4 + 15) & ~(size_t)15;
+    b += kGcRankBytes + 256;
+    const int n_iw = std::min(v.n_indel_waves, n_waves - 1);
+    return b + (size_t)(n_waves - n_iw) * v.scratch_bytes + (size_t)n_iw * v.scratch_indel;
+}
+
+// Tile of a wave's k-th unit of work: the 64 shard counters of a class are scanned once per wave (lane s holds
+// the inclusive count of shards 0..s); virtual index -> (shard, slot in the shard).
+__device__ __forceinline__ int64_t tile_of(int64_t vidx, unsigned incl, int shard_tiles) {
+    const int shard = (int)__popcll(__ballot(incl <= (unsigned)vidx));
+    const unsigned excl = shard > 0 ? (unsigned)__builtin_amdgcn_readlane((int)incl, shard - 1) : 0u;
+    return (int64_t)shard * shard_tiles + ((unsigned)vidx - excl);
 }
 
 // ---- Kf: persistent, one workgroup per CU; every wave works through tiles on its own --------------------
+template <int NTRK, int NTW>
 __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -841,55 +955,80 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
     const bool has0 = pg0.ok != 0;
     // the thresholds of every group: SNP tiles rank against group 0's slices (the head of the table), indel
     // tiles against their own group's
-    const Lds5 L = lds5_fill(smem, pg0, has0, v.thr, v.thr_lds_len, v.css_lut, tid, blockDim.x);
+    const Lds5 L = lds5_fill(smem, v, has0, tid, blockDim.x);
     __syncthreads();
-    if (((v.f.ablate >> 20) & 15) == 1) return;
     Scratch sc;
-    sc.base = L.scratch_b + (uint32_t)(wave * v.scratch_bytes);
-    sc.thr_b = L.thr_b; sc.gctab_b = L.gctab_b; sc.css_b = L.css_b;
+    sc.eyt_b = L.eyt_b; sc.thr_b = L.thr_b; sc.gcr_b = L.gcr_b; sc.css_b = L.css_b;
     const int hslot = ((lane & 31) << 1) | (lane >> 5);
+    // inclusive scans of the shard counters of both classes
+    unsigned incl_s = v.tile_cnt[lane * kTileCntStride5], incl_i = v.tile_cnt[(kTileShards5 + lane) * kTileCntStride5];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned ys = __shfl_up(incl_s, d), yi = __shfl_up(incl_i, d);
+        if (lane >= d) { incl_s += ys; incl_i += yi; }
+    }
+    const int64_t ns = (unsigned)__builtin_amdgcn_readlane((int)incl_s, 63);
+    const int64_t ni = (v.f.ablate & 262144) ? 0 : (unsigned)__builtin_amdgcn_readlane((int)incl_i, 63);
+    // Wave roles: the last `n_iw` waves of a workgroup featurise the indel tiles (memory-latency bound, no walk),
+    // the others run the SNP pipeline: a tile's row indices and columns are fetched ONE TILE AHEAD (indices at the
+    // top of the previous tile, columns just before its walk), so a tile starts with its window / allele / slice
+    // gathers instead of two dependent round trips.  Work slots are wave-major over the workgroups: a short last
+    // round leaves a few waves busy on every CU.
+    const int n_iw = v.n_indel_waves, n_sw = n_waves - n_iw;
+    sc.base = L.scratch_b + (uint32_t)(wave < n_sw ? wave * v.scratch_bytes : n_sw * v.scratch_bytes + (wave - n_sw) * v.scratch_indel);
     const uint32_t planes_lane_b = sc.base + 2u * (uint32_t)hslot;
-    const int64_t ns = (uint32_t)rfl((int)v.tile_cnt[0]), ni = (v.f.ablate & 262144) ? 0 : (uint32_t)rfl((int)v.tile_cnt[1]);
-    if (((v.f.ablate >> 20) & 15) == 8) {                     // debugging: the tile counts and the first indices
-        if (blockIdx.x == 0 && tid == 0) { v.f.score[0] = (float)ns; v.f.score[1] = (float)ni; v.f.score[2] = (float)v.snp_idx[0]; v.f.score[3] = (float)v.snp_idx[63]; v.f.score[4] = (float)v.max_tiles; }
+    if (wave >= n_sw) {
+        const int64_t stride = (int64_t)gridDim.x * n_iw;
+        for (int64_t ti = (int64_t)(wave - n_sw) * gridDim.x + blockIdx.x; ti < ni; ti += stride) {
+            const int64_t tile = tile_of(ti, incl_i, v.shard_tiles);
+            const uint32_t id = v.indel_idx[tile * 64 + lane];
+            const bool live = id != ~0u;
+            const uint32_t id0 = (uint32_t)rfl((int)id);       // (outside the select: a ternary would read the first PADDING lane)
+            featurize_indel_tile<NTRK>(v, sc, tile, lane, live ? id : id0, live);
+            __builtin_amdgcn_wave_barrier();
+        }
         return;
     }
-    const int64_t stride = (int64_t)gridDim.x * n_waves;
-    // tile slots are wave-major over the workgroups: a short last round leaves a few waves busy on every CU
-    int64_t ts = (int64_t)wave * gridDim.x + blockIdx.x, ti = ts;
-    for (int it = 0; ts < ns || ti < ni; ++it) {
-        const bool do_indel = ti < ni && ((it & 3) == 3 || ts >= ns);
-        if (do_indel) {
-            const uint32_t id = v.indel_idx[ti * 64 + lane];
-            const bool live = id != ~0u;
-            const uint32_t id0 = (uint32_t)rfl((int)id);       // (outside the select: a ternary would read the first PADDING lane)
-            const uint32_t i = live ? id : id0;
-            featurize_indel_tile(v, sc, ti, lane, i, live);
-            ti += stride;
-        } else {
-            const uint32_t id = v.snp_idx[ts * 64 + lane];
-            const bool live = id != ~0u;
-            const uint32_t id0 = (uint32_t)rfl((int)id);       // (outside the select: a ternary would read the first PADDING lane)
-            const uint32_t i = live ? id : id0;
-            if (((v.f.ablate >> 20) & 15) == 9) {              // debugging: what a wave is about to work on
-                if (ts == 1) { v.f.score[lane] = (float)id; v.f.score[64 + lane] = (float)i; v.f.score[128 + lane] = (float)v.f.pos[i < (uint32_t)v.f.n ? i : 0]; }
-                return;
-            }
-            featurize_snp_tile(v, sc, ts, lane, i, live, has0);
-            if (has0) {
-                float score = 0.f;
-                uint8_t filt = UGVC_FILTER_PASS;
-                if (!(v.f.ablate & 131072)) walk_forest(pg0, L.hi_b, L.last_b, L.p1_b, planes_lane_b, score, filt);
-                if (live) {
-                    v.f.score[i] = score;
-                    v.f.filter[i] = filt;
-                }
-            } else if (live) {                                 // no model for substitutions: score 0, PASS
-                v.f.score[i] = 0.f;
-                v.f.filter[i] = UGVC_FILTER_PASS;
-            }
-            ts += stride;
+    const int64_t stride = (int64_t)gridDim.x * n_sw;
+    int64_t ts = (int64_t)wave * gridDim.x + blockIdx.x;
+    if (ts >= ns) return;
+    auto fetch_ids = [&](int64_t vidx, uint32_t& id, uint32_t& i, bool& live) {
+        id = v.snp_idx[tile_of(vidx, incl_s, v.shard_tiles) * 64 + lane];
+        live = id != ~0u;
+        const uint32_t id0 = (uint32_t)rfl((int)id);
+        i = live ? id : id0;
+    };
+    uint32_t id, i;
+    bool live;
+    fetch_ids(ts, id, i, live);
+    SnpCols cols = load_snp_cols(v.f, i);
+    for (; ts < ns; ts += stride) {
+        const int64_t tile = tile_of(ts, incl_s, v.shard_tiles);
+        const bool more = ts + stride < ns;
+        uint32_t id_n = 0, i_n = 0;
+        bool live_n = false;
+        if (more) id_n = v.snp_idx[tile_of(ts + stride, incl_s, v.shard_tiles) * 64 + lane];     // consumed after the joins
+        featurize_snp_tile<NTRK>(v, sc, tile, lane, i, live, has0, cols);
+        SnpCols cols_n = cols;
+        if (more) {
+            live_n = id_n != ~0u;
+            const uint32_t id0 = (uint32_t)rfl((int)id_n);
+            i_n = live_n ? id_n : id0;
+            cols_n = load_snp_cols(v.f, i_n);                   // in flight during the walk
         }
+        if (has0) {
+            float score = 0.f;
+            uint8_t filt = UGVC_FILTER_PASS;
+            if (!(v.f.ablate & 131072)) walk_forest<NTW>(pg0, L.hi_b, L.last_b, L.p1_b, planes_lane_b, score, filt);
+            if (live) {
+                v.f.score[i] = score;
+                v.f.filter[i] = filt;
+            }
+        } else if (live) {                                     // no model for substitutions: score 0, PASS
+            v.f.score[i] = 0.f;
+            v.f.filter[i] = UGVC_FILTER_PASS;
+        }
+        cols = cols_n; i = i_n; live = live_n;
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -999,18 +1138,16 @@ __global__ __launch_bounds__(kK2Threads) void forest5_kernel(const V5Args v) {
         const uint4 q0 = n0, q1 = n1, q2 = n2;
         const bool live = live_next;
         if ((uint64_t)(chunk + waves) * 64 < n) fetch(chunk + waves, live_next, n0, n1, n2);
+        // record dword d holds the codes of features 2 d and 2 d + 1; one 16-bit store per plane
         const uint32_t w[11] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z};
-        // record dword d holds the codes of two features (kRecFeat); one 16-bit store per plane
-        const int feat_lo[11] = {0, 2, 4, 6, 8, 10, 12, 14, 16, 18, 20};
-        const int feat_hi[11] = {1, 3, 5, 7, 9, 11, 13, 15, 17, 19, 21};
 #pragma unroll
         for (int d = 0; d < 11; ++d) {
-            if (feat_lo[d] < kMaxFeatures) *(UGVC_LDS uint16_t*)(uintptr_t)(planes_lane_b + 128u * feat_lo[d]) = (uint16_t)(w[d] & 0xFFFFu);
-            if (feat_hi[d] < kMaxFeatures) *(UGVC_LDS uint16_t*)(uintptr_t)(planes_lane_b + 128u * feat_hi[d]) = (uint16_t)(w[d] >> 16);
+            lds_st16(planes_lane_b + 128u * (2 * d), w[d] & 0xFFFFu);
+            lds_st16(planes_lane_b + 128u * (2 * d + 1), w[d] >> 16);
         }
         float score;
         uint8_t filt;
-        walk_forest(pg, hi_b, last_b, p1_b, planes_lane_b, score, filt);
+        walk_forest<8>(pg, hi_b, last_b, p1_b, planes_lane_b, score, filt);
         if (live) {
             v.f.score[q2.w] = score;
             v.f.filter[q2.w] = filt;
@@ -1027,19 +1164,32 @@ static size_t k5_forest_lds(const PackedGroupView& pg, int n_waves) {
 // LDS budget of the fused kernel for this configuration: 16, 12 or 8 waves of scratch beside the SNP forest
 int v5_fused_waves(const V5Args& v) {
     for (int w : {16, 12, 8}) {
-        if (lds5_bytes(v.pg[0], v.pg[0].ok != 0, v.thr_lds_len, w, v.scratch_bytes) <= 158 * 1024) return w;
+        if (lds5_bytes(v, w) <= 158 * 1024) return w;
     }
     return 0;
+}
+
+using K5 = void (*)(const V5Args);
+// 16 trees in flight per lane (8 measured 4 % slower: 506 vs 485 us; kernel variant bit 28 selects 8 for the 3-track kernel)
+static K5 fused5_for(int n_tracks, bool narrow = false) {
+    if (narrow && n_tracks == 3) return fused5_kernel<3, 8>;
+    switch (n_tracks) {
+        case 0: return fused5_kernel<0, 16>;
+        case 1: return fused5_kernel<1, 16>;
+        case 2: return fused5_kernel<2, 16>;
+        case 3: return fused5_kernel<3, 16>;
+        case 4: return fused5_kernel<4, 16>;
+        default: return fused5_kernel<5, 16>;
+    }
 }
 
 int launch_filter_v5(ugvc_ctx* ctx, const FilterArgs& a) {
     if (a.n == 0) return 0;
     V5Args v;
     if (v5_fill_args(ctx, v, a)) return -1;
-    using K = void (*)(const V5Args);
     static bool attr_set = false;
     if (!attr_set) {
-        for (K f : {(K)fused5_kernel, (K)forest5_kernel})
+        for (K5 f : {fused5_for(0), fused5_for(1), fused5_for(2), fused5_for(3), fused5_for(4), fused5_for(5), fused5_for(3, true), (K5)forest5_kernel})
             UGVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
         attr_set = true;
     }
@@ -1054,14 +1204,16 @@ int launch_filter_v5(ugvc_ctx* ctx, const FilterArgs& a) {
         fprintf(stderr, "ok\n");
         return 0;
     };
-    UGVC_HIP(hipMemsetAsync(v.tile_cnt, 0, 16, ctx->stream));
-    hipLaunchKernelGGL(compact5_kernel, dim3((unsigned)v.n_cblocks), dim3(kCBlock5), 0, ctx->stream, v);
+    UGVC_HIP(hipMemsetAsync(v.tile_cnt, 0, 2 * kTileShards5 * kTileCntStride5 * 4, ctx->stream));
+    hipLaunchKernelGGL(compact5_kernel, dim3((unsigned)v.n_cblocks), dim3(256), 0, ctx->stream, v);
     if (step("compact5")) return -1;
-    const int64_t nbr = (int64_t)v.max_tiles * 24;               // 8 threads per SNP tile + 16 per indel tile
+    // real tiles of both classes together: at most one per 64 rows plus one per class and compaction block
+    const int n_act = (a.has_runs ? 1 : 0) + a.n_tracks + (a.n_bl > 0 ? 1 : 0);
+    const int64_t nbr = ((a.n + 63) / 64 + 2 * (int64_t)v.n_cblocks) * 2 * std::max(n_act, 1);
     hipLaunchKernelGGL(bracket5_kernel, dim3((unsigned)((nbr + 255) / 256)), dim3(256), 0, ctx->stream, v);
     if (step("bracket5")) return -1;
-    const size_t lds_f = lds5_bytes(v.pg[0], v.pg[0].ok != 0, v.thr_lds_len, v.n_waves, v.scratch_bytes);
-    hipLaunchKernelGGL(fused5_kernel, dim3((unsigned)ctx->n_cus), dim3(v.n_waves * 64), lds_f, ctx->stream, v);
+    const size_t lds_f = lds5_bytes(v, v.n_waves);
+    hipLaunchKernelGGL(fused5_for(a.n_tracks, (a.ablate & (1 << 28)) != 0), dim3((unsigned)ctx->n_cus), dim3(v.n_waves * 64), lds_f, ctx->stream, v);
     if (step("fused5")) return -1;
     if (!(a.ablate & 262144) && (v.pg[1].ok || v.pg[2].ok)) {
         int n_waves = 0;

@@ -44,7 +44,8 @@ struct V2Group {
 struct V2State {
     V2Group g[UGVC_N_GROUPS];
     DeviceBuf desc, desc3, lut, thr, css, brackets, brackets3, counters, prof;
-    DeviceBuf snp_idx, indel_idx, tile_cnt, tile_n, br_snp, br_indel, rec5[UGVC_N_GROUPS];   // v5
+    DeviceBuf snp_idx, indel_idx, tile_cnt, tile_n, br_snp, br_indel, rec5[UGVC_N_GROUPS], eyt;   // v5
+    int eyt_off[3] = {0, 0, 0}, eyt_bits[3] = {0, 0, 0}, eyt_len = 0;
     int thr0_len = 0, thr0_bits4[4] = {0, 0, 0, 0};
     std::vector<uint2> h_desc3;
     int thr_bits4[4] = {0, 0, 0, 0};        // descent depth per float feature (qual, sor, vaf, gc), max over groups
@@ -66,7 +67,7 @@ void v2_destroy(ugvc_ctx* ctx) {
     if (!ctx->v2) return;
     V2State* s = static_cast<V2State*>(ctx->v2);
     DeviceBuf* bufs[] = {&s->desc, &s->desc3, &s->lut, &s->thr, &s->css, &s->brackets, &s->brackets3, &s->counters, &s->prof,
-                         &s->snp_idx, &s->indel_idx, &s->tile_cnt, &s->tile_n, &s->br_snp, &s->br_indel};
+                         &s->snp_idx, &s->indel_idx, &s->tile_cnt, &s->tile_n, &s->br_snp, &s->br_indel, &s->eyt};
     for (auto* b : bufs) if (b->p) (void)hipFree(b->p);
     for (auto& r : s->rec) if (r.p) (void)hipFree(r.p);
     for (auto& r : s->rec5) if (r.p) (void)hipFree(r.p);
@@ -402,6 +403,39 @@ int finalize_pack(ugvc_ctx* ctx) {
         if (upload(ctx, s->desc3, desc3.data(), desc3.size() * sizeof(uint2))) return -1;
         for (int k = 0; k < 4; ++k) s->thr_bits4[k] = thr_bits4[k];
         s->h_desc3 = desc3;
+        {
+            // v5, group 0: the thresholds of qual / sor / vaf as complete binary search trees in level order (index 1 =
+            // root, children 2 i and 2 i + 1, padded with +inf): a descent is `i = 2 i + (t < x)`, its reads at one level
+            // fall on consecutive LDS words (no power-of-two bank pile-up), and the leaf index is the rank
+            std::vector<float> eyt;
+            const int fj[3] = {0, 1, 5};
+            for (int k = 0; k < 3; ++k) {
+                const std::vector<float> empty;
+                const auto& u = s->g[0].set ? s->g[0].uthr[fj[k]] : empty;
+                const int n = (int)u.size();
+                int bits = 0;
+                while ((1 << bits) - 1 < n) ++bits;
+                s->eyt_bits[k] = bits;
+                s->eyt_off[k] = (int)eyt.size();
+                const int size = 1 << bits;
+                std::vector<float> e((size_t)size, std::numeric_limits<float>::infinity());
+                int pos = 0;
+                std::vector<std::pair<int, int>> stack;       // in-order walk of the implicit tree
+                int i = 1;
+                while (i < size || !stack.empty()) {
+                    while (i < size) { stack.push_back({i, 0}); i = 2 * i; }
+                    i = stack.back().first;
+                    stack.pop_back();
+                    e[(size_t)i] = pos < n ? u[(size_t)pos] : std::numeric_limits<float>::infinity();
+                    ++pos;
+                    i = 2 * i + 1;
+                }
+                eyt.insert(eyt.end(), e.begin(), e.end());
+            }
+            eyt.resize((eyt.size() + 3) & ~(size_t)3, std::numeric_limits<float>::infinity());
+            s->eyt_len = (int)eyt.size();
+            if (upload(ctx, s->eyt, eyt.data(), eyt.size() * 4)) return -1;
+        }
         for (int k = 0; k < 4; ++k) {
             const int f = k == 0 ? 0 : (k == 1 ? 1 : (k == 2 ? 5 : 13));
             const int m = s->g[0].set ? (int)s->g[0].uthr[f].size() : 0;
@@ -616,13 +650,23 @@ int v5_fill_args(ugvc_ctx* ctx, V5Args& v, const FilterArgs& a) {
     v.desc3 = s->desc3.as<uint2>();
     v.thr_lds_len = s->thr_lds_len;
     v.thr0_len = s->thr0_len;
-    for (int k = 0; k < 4; ++k) { v.thr_bits4[k] = s->thr_bits4[k]; v.thr0_bits4[k] = s->thr0_bits4[k]; }
+    v.thr_bits = 0;
+    for (int gi = 1; gi < UGVC_N_GROUPS; ++gi)
+        for (int f : {0, 1, 5}) {
+            const int m = s->g[gi].set ? (int)s->g[gi].uthr[f].size() : 0;
+            v.thr_bits = std::max(v.thr_bits, m > 0 ? 32 - __builtin_clz((unsigned)m) : 0);
+        }
+    v.eyt = s->eyt.as<float>();
+    v.eyt_len = s->eyt_len;
+    for (int k = 0; k < 3; ++k) { v.eyt_off[k] = s->eyt_off[k]; v.eyt_bits[k] = s->eyt_bits[k]; }
     v.css_lut = s->css.as<uint8_t>();
     v.n_cblocks = (int)((n + kCBlock5 - 1) / kCBlock5);
-    v.max_tiles = (int)((n + kTile5 - 1) / kTile5) + v.n_cblocks + 1;
+    // tile slots: every compaction block hands out at most kCBlock5 / 64 + 1 tiles per class, to its own shard
+    v.shard_tiles = ((v.n_cblocks + kTileShards5 - 1) / kTileShards5) * (kCBlock5 / kTile5 + 1);
+    v.max_tiles = kTileShards5 * v.shard_tiles;
     v.shard_cap5 = ((v.max_tiles + kShards - 1) / kShards) * kTile5;
     if (ensure(s->snp_idx, (size_t)v.max_tiles * kTile5 * 4) || ensure(s->indel_idx, (size_t)v.max_tiles * kTile5 * 4)) return -1;
-    if (ensure(s->tile_cnt, 64) || ensure(s->tile_n, (size_t)v.max_tiles * 2 + 64)) return -1;
+    if (ensure(s->tile_cnt, (size_t)2 * kTileShards5 * kTileCntStride5 * 4) || ensure(s->tile_n, (size_t)v.max_tiles * 2 + 64)) return -1;
     if (ensure(s->br_snp, (size_t)v.max_tiles * 8 * 4) || ensure(s->br_indel, (size_t)v.max_tiles * 16 * 4)) return -1;
     if (ensure(s->counters, (size_t)UGVC_N_GROUPS * kShards * kCounterStride * 4)) return -1;
     v.snp_idx = s->snp_idx.as<uint32_t>();
@@ -638,37 +682,41 @@ int v5_fill_args(ugvc_ctx* ctx, V5Args& v, const FilterArgs& a) {
         if (ensure(s->rec5[gi], (size_t)kShards * v.shard_cap5 * kRec5Dwords * 4)) return -1;
         v.rec5[gi] = s->rec5[gi].as<uint4>();
     }
-    // staged slice of table t in the SNP path: the rows a tile of 64 substitutions can touch - about 96 consecutive
-    // variants' worth at a WGS class mix - twice over, as a power of two; a tile that needs more searches HBM
-    for (int t = 0; t < kJoin5; ++t) v.na[t] = v.jcap[t] = v.joff[t] = 0;
+    // staged slice of an interval table in the SNP path: 64 rows, or 128 for the tables whose density puts more than
+    // ~40 rows under a tile of 64 substitutions (about 96 consecutive variants at a WGS class mix), densest first,
+    // while a wave's scratch has room; a tile that needs more searches HBM.  Blacklist: kBlCap5 keys.
+    for (int t = 0; t < kJoin5; ++t) { v.na[t] = 0; v.jcap[t] = 64; v.joff[t] = 0; }
     v.na[0] = ctx->has_runs ? (int)ctx->runs_n : 0;
     for (int t = 0; t < ctx->n_tracks; ++t) v.na[1 + t] = (int)ctx->trk_n[t];
     v.na[kJoin5 - 1] = (int)ctx->n_bl;
-    const int budget = 1024;                                  // dwords of a wave's scratch for the slices
-    for (int shrink = 0;; ++shrink) {
-        int used = 0;
-        for (int t = 0; t < kJoin5; ++t) {
-            const bool present = t == kJoin5 - 1 ? ctx->n_bl > 0 : (t == 0 ? ctx->has_runs != 0 : t - 1 < ctx->n_tracks);
-            v.jcap[t] = 0;
-            if (!present) continue;
-            const double per_tile = (double)v.na[t] / (double)std::max<int64_t>(n, 1) * 96.0;
-            int cap = 16;
-            while (cap < 512 && cap < 2.0 * per_tile + 8.0) cap <<= 1;
-            cap = std::max(16, cap >> shrink);
-            v.jcap[t] = cap;
-            v.joff[t] = used;
-            used += 2 * cap;                                  // starts + ends, or 8-byte keys
-        }
-        if (used <= budget || shrink >= 5) break;
-    }
+    v.jcap[kJoin5 - 1] = kBlCap5;
     {
+        const int n_int = 1 + ctx->n_tracks;
+        int budget = (3072 - kBlCap5 * 8) / 4 - n_int * 128;                 // dwords left of 3 KB after 64 rows of every table
+        std::vector<int> order;
+        for (int t = 0; t < n_int; ++t) order.push_back(t);
+        std::sort(order.begin(), order.end(), [&](int x, int y) { return v.na[x] > v.na[y]; });
+        for (int t : order) {
+            const double per_tile = (double)v.na[t] / (double)std::max<int64_t>(n, 1) * 96.0;
+            if (per_tile > 40.0 && budget >= 128) { v.jcap[t] = 128; budget -= 128; }
+        }
         int used = 0;
-        for (int t = 0; t < kJoin5; ++t) used = std::max(used, v.joff[t] + 2 * v.jcap[t]);
-        v.scratch_bytes = std::max({used * 4, kTile5 * 13 * 4 /* 48-byte window rows, stride 13 dwords */, kMaxFeatures * 128});
-        v.scratch_bytes = (v.scratch_bytes + 63) & ~63;
+        for (int t = 0; t < n_int; ++t) { v.joff[t] = used; used += 2 * v.jcap[t]; }
+        v.joff[kJoin5 - 1] = used;                                           // 8-byte keys: `used` is even
+        used += 2 * kBlCap5;
+        v.scratch_bytes = (std::max(used * 4, kMaxFeatures * 128) + 63) & ~63;                 // staged slices, then the code planes
+        v.scratch_indel = kTile5 * 13 * 4;                                                      // 48-byte window rows, stride 13 dwords
     }
+    v.n_indel_waves = 0;
     v.n_waves = v5_fused_waves(v);
     if (v.n_waves == 0) return fail("internal: the SNP forest does not fit the fused kernel's LDS");
+    // indel tiles are ~1/5 of a WGS callset's tiles and take about as long as an SNP tile with its walk: 1/4 of the waves
+    // (kernel variant bits 24-27 override, profiling)
+    v.n_indel_waves = ((a.ablate >> 24) & 15) ? ((a.ablate >> 24) & 15) : v.n_waves / 4;
+    if (v.n_indel_waves >= v.n_waves) v.n_indel_waves = v.n_waves - 1;
+    if (v5_fused_waves(v) < v.n_waves) v.n_waves = v5_fused_waves(v);   // (the indel waves' larger scratch)
+    if (v.n_waves == 0) return fail("internal: the SNP forest does not fit the fused kernel's LDS");
+    if (v.n_indel_waves >= v.n_waves) v.n_indel_waves = v.n_waves - 1;
     return 0;
 }
 
@@ -691,7 +739,7 @@ bool v5_available(ugvc_ctx* ctx) {
     const V2Group& g0 = s->g[0];
     size_t forest = 0;
     if (g0.set) forest = ((size_t)g0.T << g0.D) / 2 * 12 + (size_t)g0.n_pairs * 8 + 64;
-    if (forest + (size_t)s->thr_lds_len * 4 + 1024 + 8 * 4160 + 1024 > 160 * 1024) return false;
+    if (forest + (size_t)(s->thr_lds_len - s->thr0_len) * 33 / 8 + (size_t)s->eyt_len * 4 + 2048 + 6 * 3072 + 2 * 3328 > 158 * 1024) return false;
     return true;
 }
 

@@ -92,6 +92,9 @@ constexpr int kRec5Dwords = 12;               // raw record: 20 codes (u16, by f
 constexpr int kTile5 = 64;                    // variants per tile = one wave
 constexpr int kCBlock5 = 1024;                // variants per compaction workgroup
 constexpr int kJoin5 = UGVC_MAX_TRACKS + 2;   // runs, tracks, blacklist
+constexpr int kTileShards5 = 64;              // tile-slot counters per variant class (one atomic per compaction block)
+constexpr int kTileCntStride5 = 16;           // dwords between counters (64 bytes)
+constexpr int kBlCap5 = 64;                   // staged blacklist keys per SNP tile
 
 struct V5Args {
     FilterArgs f;
@@ -100,27 +103,31 @@ struct V5Args {
     const uint2* desc3;                  // [3][kMaxFeatures] {off, len | ...} of the float slices
     int thr_lds_len;                     // floats staged by the indel path (all groups)
     int thr0_len;                        // floats of group 0 (prefix of thr)
-    int thr_bits4[4];                    // descent depth over all groups
-    int thr0_bits4[4];                   // descent depth, group 0
+    int thr_bits;                        // descent depth of the float-feature searches of the indel groups (sorted slices)
+    const float* eyt;                    // group 0: qual / sor / vaf thresholds as complete search trees (Eytzinger order, +inf padded)
+    int eyt_off[3], eyt_bits[3], eyt_len;
     int cap5[UGVC_N_GROUPS][kMaxFeatures];
     uint32_t used5[UGVC_N_GROUPS];       // features a group's forest tests
     const uint8_t* css_lut;
     uint32_t* snp_idx;                   // tiles of 64 variant indices, ~0u = padding
     uint32_t* indel_idx;
-    uint32_t* tile_cnt;                  // [0] SNP tiles, [1] indel tiles (zeroed before every pass)
+    uint32_t* tile_cnt;                  // [class][kTileShards5] x kTileCntStride5: tiles handed out per shard (zeroed before every pass)
+    int shard_tiles;                     // tile slots per shard: tile id = shard * shard_tiles + slot
     uint8_t* tile_n;                     // real entries per tile: [0, max_tiles) SNP, [max_tiles, 2 max_tiles) indel
     int32_t* br_snp;                     // [max_tiles][8]  lower bounds of the tile's first variant
     int32_t* br_indel;                   // [max_tiles][16] + lower bounds of its last variant
     uint4* rec5[UGVC_N_GROUPS];
     uint32_t* counters;                  // [UGVC_N_GROUPS][kShards] x kCounterStride
     int shard_cap5;
-    int jcap[kJoin5];                    // staged elements per table in the SNP path (power of two; 0 = absent)
+    int jcap[kJoin5];                    // staged elements per table in the SNP path: 64 or 128 (blacklist: kBlCap5)
     int joff[kJoin5];                    // dword offset of the staged starts (ends follow at + jcap); keys: 2 dwords each
     int na[kJoin5];                      // table lengths
-    int max_tiles;
+    int max_tiles;                       // tile slots per class = kTileShards5 * shard_tiles
     int n_cblocks;
-    int scratch_bytes;                   // per-wave LDS scratch of the fused kernel
+    int scratch_bytes;                   // per-wave LDS scratch of the fused kernel's SNP waves
+    int scratch_indel;                   // ... of its indel waves (48-byte window rows)
     int n_waves;
+    int n_indel_waves;                   // waves of a fused workgroup that work on indel tiles
 };
 
 int v5_fill_args(ugvc_ctx* ctx, V5Args& v, const FilterArgs& a);
