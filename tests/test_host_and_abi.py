@@ -225,3 +225,35 @@ def test_variant_table_validation():
     with pytest.raises(ValueError, match="qual"):
         vt.validate()
     assert cs.variants.slice(10, 10).n == 0
+
+
+def test_set_model_rejects_malformed_tables_before_the_abi():
+    """The ABI takes bare pointers + one node count: mismatched node arrays or a leaf table that is not [n, 2] would be read
+    out of bounds on the host side of the library.  The binding refuses them (no GPU needed: the check precedes the call)."""
+    import copy
+    from variantcalling_amd import model_io
+    from variantcalling_amd.engine import Engine
+    f = model_io.load_models(os.path.join(ROOT, "tests", "golden", "synth_rf_v1.npz"))["rf_model_ignore_gt_incl_hpol_runs"][0]
+    eng = Engine.__new__(Engine)                        # no context: set_model must fail before touching the library
+    eng.lib, eng._h = None, None
+    bad = copy.copy(f)
+    bad.threshold = f.threshold[:-1]
+    with pytest.raises(ValueError, match="differ in length"):
+        eng.set_model(0, bad)
+    bad = copy.copy(f)
+    bad.leaf_value = f.leaf_value[:, 0]
+    with pytest.raises(ValueError, match=r"\[n_leaves, 2\]"):
+        eng.set_model(0, bad)
+    bad = copy.copy(f)
+    bad.leaf_value = f.leaf_value[:, :1]
+    with pytest.raises(ValueError, match=r"\[n_leaves, 2\]"):
+        eng.set_model(0, bad)
+
+
+def test_frame_to_table_rejects_alleles_longer_than_u16():
+    from variantcalling_amd.io import concordance, h5
+    fr = h5.Frame([("chrom", np.array(["chr1", "chr1"], object)), ("pos", np.array([10, 20])),
+                   ("ref", np.array(["A", "A" * 70000], object)),
+                   ("alleles", np.array([("A", "C"), ("A" * 70000, "A")], object))])
+    with pytest.raises(ValueError, match="longer than 65535"):
+        concordance.frame_to_table(fr, ["chr1"])

@@ -98,7 +98,7 @@ int ugvc_eval_counts(ugvc_ctx* ctx, const int8_t* label, const uint16_t* cat_bit
     const int64_t n = ctx->n;
     for (int c = 0; c < kEvalCats; ++c) for (int k = 0; k < 4; ++k) out[c][k] = 0;
     if (n == 0) return 0;
-    if (!ctx->r_filter.p) return fail("no scored variants resident (ugvc_filter_resident)");
+    if (!ctx->r_filter.p || !ctx->scored) return fail("no scored variants resident: run ugvc_filter_resident after ugvc_variants_upload");
     UGVC_HIP(hipSetDevice(ctx->device));
     DeviceBuf d_lab, d_cat, d_out;
     int rc = 0;

@@ -63,10 +63,8 @@ __global__ __launch_bounds__(256) void compact5_kernel(const V5Args v) {
     __shared__ unsigned ws[4], wi[4];
     __shared__ unsigned base_s, base_i;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    {
-        const int64_t g = (int64_t)blockIdx.x * 256 + tid;
-        if (g < UGVC_N_GROUPS * kShards) v.counters[g * kCounterStride] = 0;   // the record lists of this pass start empty
-    }
+    for (int64_t g = (int64_t)blockIdx.x * 256 + tid; g < UGVC_N_GROUPS * kShards; g += (int64_t)gridDim.x * 256)
+        v.counters[g * kCounterStride] = 0;                            // the record lists of this pass start empty
     const int64_t i0 = (int64_t)blockIdx.x * kCBlock5 + wave * 256 + lane;
     unsigned long long ms[4], mi[4];
     unsigned cs = 0, ci = 0;
@@ -977,7 +975,13 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
     const int n_iw = v.n_indel_waves, n_sw = n_waves - n_iw;
     sc.base = L.scratch_b + (uint32_t)(wave < n_sw ? wave * v.scratch_bytes : n_sw * v.scratch_bytes + (wave - n_sw) * v.scratch_indel);
     const uint32_t planes_lane_b = sc.base + 2u * (uint32_t)hslot;
+    // A featurize phase is a short instruction stream between long memory waits; the walk is a long stream that waits
+    // on LDS.  Featurize runs at raised priority (kernel variant bit 29 turns that off): it wins the SIMD's issue
+    // arbitration against the walking waves, gets back to walking sooner, and the walkers lose slots they would
+    // mostly have spent waiting.
+    const bool prio = !(v.f.ablate & (1 << 29));
     if (wave >= n_sw) {
+        if (prio) __builtin_amdgcn_s_setprio(2);
         const int64_t stride = (int64_t)gridDim.x * n_iw;
         for (int64_t ti = (int64_t)(wave - n_sw) * gridDim.x + blockIdx.x; ti < ni; ti += stride) {
             const int64_t tile = tile_of(ti, incl_i, v.shard_tiles);
@@ -1007,6 +1011,7 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
         const bool more = ts + stride < ns;
         uint32_t id_n = 0, i_n = 0;
         bool live_n = false;
+        if (prio) __builtin_amdgcn_s_setprio(2);
         if (more) id_n = v.snp_idx[tile_of(ts + stride, incl_s, v.shard_tiles) * 64 + lane];     // consumed after the joins
         featurize_snp_tile<NTRK>(v, sc, tile, lane, i, live, has0, cols);
         SnpCols cols_n = cols;
@@ -1016,6 +1021,7 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
             i_n = live_n ? id_n : id0;
             cols_n = load_snp_cols(v.f, i_n);                   // in flight during the walk
         }
+        if (prio) __builtin_amdgcn_s_setprio(0);
         if (has0) {
             float score = 0.f;
             uint8_t filt = UGVC_FILTER_PASS;

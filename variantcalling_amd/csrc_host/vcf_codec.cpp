@@ -666,6 +666,7 @@ int ugvc_vcf_read(const char* path, const char* const* contig_names, int n_conti
     // ---- lines: part p owns the lines that START inside its byte range
     const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(threads, tn / (1 << 16)));
     std::vector<std::vector<Span>> hdr_p((size_t)parts), rec_p((size_t)parts);
+    std::vector<int64_t> too_long((size_t)parts, -1);                 // byte offset of a line longer than a Span can hold
     parallel_ranges(tn, parts, [&](int p, int64_t lo, int64_t hi) {
         int64_t s = lo;
         if (lo > 0) {
@@ -683,13 +684,16 @@ int ugvc_vcf_read(const char* path, const char* const* contig_names, int n_conti
                 bool blank = true;
                 for (int64_t q = s; q < le && blank; ++q) blank = is_space(base[q]);
                 if (!blank) {
-                    if (le - s > INT32_MAX) return;
+                    if (le - s > INT32_MAX) { too_long[(size_t)p] = s; return; }
                     rec_p[(size_t)p].push_back(Span{s, (int32_t)(le - s)});
                 }
             }
             s = e + 1;
         }
     });
+    for (int p = 0; p < parts; ++p)
+        if (too_long[(size_t)p] >= 0)                                 // (reported, not silently dropped with the rest of the part)
+            return fail(h->path + ": line at byte " + std::to_string(too_long[(size_t)p]) + " is longer than 2 GiB");
     for (int p = 0; p < parts; ++p) {
         h->hdr_lines.insert(h->hdr_lines.end(), hdr_p[(size_t)p].begin(), hdr_p[(size_t)p].end());
         h->rec_lines.insert(h->rec_lines.end(), rec_p[(size_t)p].begin(), rec_p[(size_t)p].end());

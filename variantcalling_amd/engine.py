@@ -202,6 +202,15 @@ class Engine:
         feat, thr = _col(f.feature, np.int32), _col(f.threshold, np.float32)
         left, right = _col(f.left, np.int32), _col(f.right, np.int32)
         roots, leaves = _col(f.tree_root, np.int32), _col(f.leaf_value, np.float64)
+        # the C ABI takes bare pointers: shapes are checked here (a hand-made or damaged model file must not make the
+        # library read past an array)
+        if not (feat.ndim == thr.ndim == left.ndim == right.ndim == roots.ndim == 1):
+            raise ValueError("model node / root arrays must be one-dimensional")
+        if not (feat.size == thr.size == left.size == right.size):
+            raise ValueError(f"model node arrays differ in length: feature {feat.size}, threshold {thr.size}, "
+                             f"left {left.size}, right {right.size}")
+        if leaves.ndim != 2 or leaves.shape[1] != 2:
+            raise ValueError(f"leaf_value must be [n_leaves, 2], got shape {leaves.shape}")
         self._check(self.lib.ugvc_model_upload(
             self._h, group, f.kind, _p(feat, _i32p), _p(thr, _f32p), _p(left, _i32p), _p(right, _i32p),
             feat.size, _p(roots, _i32p), roots.size, _p(leaves, _f64p), leaves.shape[0], f.n_features,

@@ -100,8 +100,14 @@ def frame_to_table(fr: h5.Frame, contig_names, is_mutect: bool = False, label_co
     m = rows.size
     refs = [ref[i].encode() for i in rows]
     alts = [alt[i].encode() for i in rows]
-    rl = np.fromiter((len(x) for x in refs), np.int64, m).astype(np.uint16)
-    al = np.fromiter((len(x) for x in alts), np.int64, m).astype(np.uint16)
+    rl64 = np.fromiter((len(x) for x in refs), np.int64, m)
+    al64 = np.fromiter((len(x) for x in alts), np.int64, m)
+    if m and max(int(rl64.max()), int(al64.max())) > 65535:
+        # the allele-length columns are u16 (the native VCF reader rejects such records as well): a wrapped length
+        # would misalign every later allele offset
+        bad = int(np.flatnonzero((rl64 > 65535) | (al64 > 65535))[0])
+        raise ValueError(f"allele longer than 65535 bases at row {int(rows[bad])} ({int(max(rl64[bad], al64[bad]))} bases)")
+    rl, al = rl64.astype(np.uint16), al64.astype(np.uint16)
     off = np.concatenate([[0], np.cumsum(rl.astype(np.int64) + al)])
     pool = np.frombuffer(b"".join(r + a for r, a in zip(refs, alts)), dtype=np.uint8) if m else np.zeros(0, np.uint8)
 

@@ -667,8 +667,17 @@ try:
 except ImportError:                                               # numpy 1.x
     from numpy.core.multiarray import scalar as _np_scalar
 
+class _NdarrayToken:
+    """Stands for `numpy.ndarray` where pickles name it: as the `subtype` argument of `_reconstruct` (ignored there -
+    the array is always built as a _CheckedArray).  Calling it is refused: `ndarray(shape, dtype('O'))` followed by a
+    BUILD would reach numpy's unchecked `__setstate__`, which reads past a short object list (a crash, not an error)."""
+
+    def __call__(self, *args, **kwargs):
+        raise pickle.UnpicklingError("numpy.ndarray may only appear as the array type of a reconstructed array")
+
+
 _SAFE_GLOBALS = {
-    ("numpy", "ndarray"): np.ndarray, ("numpy", "dtype"): np.dtype,
+    ("numpy", "ndarray"): _NdarrayToken(), ("numpy", "dtype"): np.dtype,
     ("builtins", "tuple"): tuple, ("builtins", "list"): list, ("builtins", "dict"): dict, ("builtins", "set"): set,
     ("builtins", "frozenset"): frozenset, ("builtins", "complex"): complex, ("builtins", "bytearray"): bytearray,
     ("builtins", "slice"): slice, ("builtins", "range"): range, ("__builtin__", "tuple"): tuple, ("__builtin__", "list"): list,
