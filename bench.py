@@ -1,20 +1,27 @@
 #!/usr/bin/env python
 """Headline benchmark: variants/sec filtered on a 5 M-call WGS-shaped callset (BASELINE.json).
 
-One "step" = one scoring pass (featurize -> lookup -> quantise kernel, then the LDS-resident
-forest kernel; featurize -> lookup -> score -> FILTER) over the whole callset (C3: 5 M SNV+indel, 3.1 Gb genome, runs + 3 annotation tracks, 1 M-locus
-blacklist, 40-tree depth-8 forest per variant-type group), inputs already resident in HBM.
-With --gpus N > 1 (launched by torch.distributed.run, one process per GPU) the SAME callset is
-cut into N equal-count shards ("strong" scaling, BASELINE.json config C4) and every step ends
-with the RCCL all-gather of the (tree_score, filter, flags) columns over xGMI.
+Default workload `filter` (config C3): one "step" = one scoring pass over the whole callset - featurize ->
+lookup -> score -> FILTER: the four launches of csrc/kernels_v5.hip (compact5 -> bracket5 -> fused5 -> forest5) -
+on 5 M SNV+indel, 3.1 Gb genome, runs + 3 annotation tracks, 1 M-locus blacklist, 40-tree depth-8 forest per
+variant-type group, inputs already resident in HBM.  With --gpus N > 1 (launched by torch.distributed.run, one
+process per GPU; the ranks rendezvous over plain TCP, variantcalling_amd/dist.py) the SAME callset is cut into N
+equal-count shards ("strong" scaling, BASELINE.json config C4) and every step ends with the RCCL all-gather of the
+(tree_score, filter, flags) columns over xGMI.
 
-Prints ONE JSON line on rank 0.  roofline.achieved = 121.6 algorithmic bytes/variant
- x variants per launch / mean kernel launch duration measured
-with HIP events on the launch stream inside the timed region.
+Other workloads (same JSON shape, their own algorithmic bytes / flops and roofline; N = 1):
+  --workload c2          1 M SNV-only callset (config C2)
+  --workload pileup      a11 pileup tally, 5 M loci x ~30 observations, 84 B/locus
+  --workload sec_apply   SEC database apply on the 5 M resident calls, ~26 B/call
+  --workload c5_gemm     config C5: T = 100 depth-6 ensemble as a leaf-matrix GEMM on MFMA (int8), 2 M variants
+
+Prints ONE JSON line on rank 0.  roofline.achieved = algorithmic bytes x units per
+launch / mean launch duration measured with HIP events on the launch stream inside the timed region.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,13 +33,35 @@ import numpy as np  # noqa: E402
 
 ALG_BYTES_C3 = 121.6       # B/variant, fused featurize+lookup+score, SNV+indel
 ALG_BYTES_C2 = 107.6       # SNV-only
+ALG_BYTES_PILEUP = 84.0    # B/locus
+ALG_BYTES_SEC = 26.0       # B/call: key 8 + counts 12 + depth columns / flags 6
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_I8_PEAK_TOPS = 5000.0  # dense int8 = the fp8 rate (MI355X_MICROARCH.md)
 MODEL = "rf_model_ignore_gt_incl_hpol_runs"
+PASS_KERNELS = ("one scoring pass = compact5_kernel + bracket5_kernel + fused5_kernel + forest5_kernel "
+                "(csrc/kernels_v5.hip; HIP events around the four launches on the context stream)")
+
+_CPU_JOB = {}
+
+
+def _cpu_chunk(bounds):
+    """One worker of the multi-process CPU baseline: the reference-idiom restatement on rows [lo, hi)."""
+    from oracle import idiom
+    lo, hi = bounds
+    job = _CPU_JOB
+    sub = job["vt"].slice(lo, hi)
+    cs = job["cs"]
+    idiom.filter_variants_idiom(sub, cs.ref, cs.runs, cs.tracks, cs.blacklist, job["forests"], fasta=job["fa"])
+    return hi - lo
 
 
 def cpu_baseline(cs, forests, sample_n):
-    """Oracle restatement in the reference idiom (pandas per-row apply + tree scoring), one
-    process, on the first `sample_n` variants of the same callset.  Checker code only."""
+    """Oracle restatement in the reference idiom (pandas per-row apply + tree scoring): one process on the first
+    `sample_n` variants (the reference tool is single-process), then one process per host core over contig-ordered
+    chunks of a larger sample (the `--n_jobs` style of docs/run_comparison_pipeline.md:81).  Checker code only; runs
+    BEFORE the GPU context exists (the workers are forked)."""
+    import multiprocessing as mp
+
     from oracle import idiom, oracle as O
     sub = cs.variants.slice(0, sample_n)
     fa = idiom.PyFasta(cs.ref)
@@ -44,24 +73,62 @@ def cpu_baseline(cs, forests, sample_n):
     t0 = time.perf_counter()
     O.filter_variants(sub, cs.ref, cs.runs, cs.tracks, cs.blacklist, forests)
     t_vec = time.perf_counter() - t0
-    return dict(value=sub.n / t_idiom, unit="variants/s", cores=1, kind="port",
-                sample=f"first {sub.n} variants of the same callset; oracle/idiom.py (pandas per-row apply, "
-                       f"reference idiom B0) single process, {t_idiom:.1f} s",
-                vectorised_numpy_value=sub.n / t_vec, vectorised_numpy_seconds=round(t_vec, 2))
+    out = dict(value=sub.n / t_idiom, unit="variants/s", cores=1, kind="port",
+               sample=f"first {sub.n} variants of the same callset; oracle/idiom.py (pandas per-row apply, "
+                      f"reference idiom B0) single process, {t_idiom:.1f} s",
+               vectorised_numpy_value=sub.n / t_vec, vectorised_numpy_seconds=round(t_vec, 2))
+    cores = os.cpu_count() or 1
+    workers = max(1, min(cores, 256))
+    n_multi = int(min(cs.variants.n, max(sample_n, sub.n / t_idiom * 12.0 * workers)))    # ~12 s of work per worker
+    chunks = workers * 4
+    edges = np.linspace(0, n_multi, chunks + 1).astype(np.int64)
+    for c in np.unique(cs.variants.contig[:n_multi]):   # "open the FASTA" once, before the fork and outside the timed region
+        fa[int(c)]
+    _CPU_JOB.update(vt=cs.variants, cs=cs, forests=forests, fa=fa)
+    try:
+        ctx = mp.get_context("fork")
+        t0 = time.perf_counter()
+        with ctx.Pool(workers) as pool:
+            done = sum(pool.map(_cpu_chunk, [(int(edges[k]), int(edges[k + 1])) for k in range(chunks)], chunksize=1))
+        t_multi = time.perf_counter() - t0
+        out["multi"] = dict(value=done / t_multi, unit="variants/s", cores=workers,
+                            sample=f"first {done} variants in {chunks} position-ordered chunks, one forked process per host core "
+                                   f"({workers}), same idiom code, {t_multi:.1f} s wall incl. process start")
+    except Exception as e:                # a box that cannot fork this much: report, do not fail the bench
+        out["multi"] = dict(value=None, error=repr(e)[:200])
+    finally:
+        _CPU_JOB.clear()
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--variants", type=int, default=5_000_000)
-    ap.add_argument("--snv-only", action="store_true", help="C2 shape instead of C3")
-    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
-    ap.add_argument("--cpu-sample", type=int, default=100_000, help="variants timed on the CPU baseline (0 = skip)")
-    ap.add_argument("--variant", type=int, default=0, help="kernel variant (debug)")
-    args = ap.parse_args()
+def _git_head():
+    """Short commit hash of the tree the bench runs from (the GPU box gets a snapshot without .git: profiles/HEAD, written
+    by tools/gpu_*.sh callers before the snapshot is taken, stands in)."""
+    try:
+        h = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip()
+        if h:
+            return h
+    except Exception:
+        pass
+    p = os.path.join(ROOT, "profiles", "HEAD")
+    return open(p).read().strip() if os.path.exists(p) else None
 
+
+def _traffic():
+    """HBM bytes per launch from the PMC passes (tools/make_traffic_json.py); carries the commit it was measured at."""
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if not os.path.exists(tpath):
+        return None, None
+    with open(tpath) as fh:
+        d = json.load(fh)
+    return d.get("bytes_per_launch_5M"), d.get("commit")
+
+
+def _pct(ms, q):
+    return float(np.percentile(ms, q)) if len(ms) else None
+
+
+def run_filter(args):
     from variantcalling_amd import dist, model_io, shard, synth
     from variantcalling_amd.engine import Engine, configure
 
@@ -69,19 +136,29 @@ def main():
     if grp.world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={grp.world}: launch with "
                          f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}")
+    snv_only = args.workload == "c2"
+    n_var = 1_000_000 if (snv_only and args.variants == 5_000_000) else args.variants
     t_setup = time.perf_counter()
-    n_req = args.variants * (grp.world if args.scaling == "weak" else 1)
-    cs = synth.make_callset(n_req, snv_only=args.snv_only)
+    n_req = n_var * (grp.world if args.scaling == "weak" else 1)
+    cs = synth.make_callset(n_req, snv_only=snv_only)
     n_total = cs.variants.n
     forests = model_io.load_models(os.path.join(ROOT, "tests", "golden", "synth_rf_v1.npz"))[MODEL]
+    cpu = None
+    if grp.rank == 0 and grp.world == 1 and args.cpu_sample > 0:
+        cpu = cpu_baseline(cs, forests, min(args.cpu_sample, n_total))       # before the GPU context: forks
+        cpu["host_cores_available"] = os.cpu_count()
     mine = shard.shard_of(cs.variants, grp.rank, grp.world)
     cap = shard.shard_cap(n_total, grp.world)
 
     eng = Engine(grp.local_rank)
     info = eng.device_info()
-    configure(eng, cs.ref, cs.runs, cs.tracks, cs.blacklist, forests, "TGCA", 10, 10, True)
+    # every rank keeps only the part of the genome and of the side tables its shard can touch
+    ctx_tables = shard.slice_context(cs.ref, cs.runs, cs.tracks, cs.blacklist, mine) if grp.world > 1 else \
+        (cs.ref, cs.runs, cs.tracks, cs.blacklist, mine)
+    ref_r, runs_r, tracks_r, bl_r, mine_r = ctx_tables
+    configure(eng, ref_r, runs_r, tracks_r, bl_r, forests, "TGCA", 10, 10, True)
     eng.set_kernel_variant(args.variant)
-    eng.upload_variants(mine)
+    eng.upload_variants(mine_r)
     gather = grp.world > 1
     if gather:
         uid = grp.broadcast_bytes(eng.comm_unique_id() if grp.rank == 0 else None, 0)
@@ -100,6 +177,7 @@ def main():
     grp.barrier()
     wall = grp.max_float(time.perf_counter() - t0)
     ms_kernel_max = grp.max_float(ms_kernel)
+    step_ms = eng.last_step_ms(args.steps)
 
     # ---- post-run correctness spot check against the oracle (rank 0, small slice; untimed).  With a
     # collective the timed passes wrote straight into the gather buffers: one more pass fills the
@@ -124,44 +202,190 @@ def main():
         ok_all = grp.sum_float(1.0 if ok else 0.0) == grp.world
     else:
         ok_all = True
+    # ---- PCIe-inclusive rate of the host-buffer boundary (never `value`): upload + one pass + download
+    e2e = None
+    if grp.world == 1 and not args.no_e2e:
+        eng.filter_variants(mine)
+        ts = []
+        for _ in range(3):
+            t1 = time.perf_counter()
+            eng.filter_variants(mine)
+            ts.append(time.perf_counter() - t1)
+        e2e = dict(value=mine.n / min(ts), unit="variants/s", ms=min(ts) * 1e3,
+                   what="ugvc_filter_variants: H2D of the variant columns from pageable numpy buffers + one pass + D2H of the results")
 
     if grp.rank == 0:
-        alg = ALG_BYTES_C2 if args.snv_only else ALG_BYTES_C3
+        alg = ALG_BYTES_C2 if snv_only else ALG_BYTES_C3
         kern_ms = ms_kernel_max / args.steps
         achieved = alg * mine.n / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as fh:
-                traffic = json.load(fh).get("bytes_per_launch_5M")
+        traffic, traffic_commit = _traffic()
         out = dict(
             metric="variants/sec filtered (whole node), 5M-call WGS", value=n_total * args.steps / wall,
             unit="variants/s", n_gpus=grp.world, steps=args.steps, warmup=args.warmup,
             ms_per_step=wall / args.steps * 1e3, higher_is_better=True, scaling=args.scaling,
             vs_baseline=None, dtype="u8/i32 featurize + f32 compare + f64 accumulate", data="synthetic",
-            config=dict(workload=("C2 " if args.snv_only else "C3 ") + f"{n_total} variants "
-                        f"({'SNV-only' if args.snv_only else '82% SNV / 18% indel'}), 3.1 Gb 24-contig genome tiled from "
+            config=dict(workload=("C2 " if snv_only else "C3 ") + f"{n_total} variants "
+                        f"({'SNV-only' if snv_only else '82% SNV / 18% indel'}), 3.1 Gb 24-contig genome tiled from "
                         "real hg38 chr1 blocks, runs + 3 annotation tracks (5.0M intervals), 1M-locus blacklist, "
                         "RF 40 trees depth 8 x 3 groups, F=20; fused featurize+lookup+score+FILTER, inputs resident in HBM",
-                        variants_per_gpu=mine.n, model=MODEL, sharding=f"equal-count x{grp.world}",
+                        variants_per_gpu=mine.n, model=MODEL, sharding=f"equal-count x{grp.world}"
+                        + (", per-rank genome / side-table slices" if grp.world > 1 else ""),
                         collective="RCCL all-gather (score f32, filter u8, flags u8)" if gather else "none",
-                        device=info["name"], kernel_variant=args.variant),
+                        device=info["name"], kernel_variant=args.variant, commit=_git_head()),
             roofline=dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBPS, unit="GB/s",
-                          frac=achieved / HBM_PEAK_GBPS, traffic=traffic,
-                          kernel="one scoring pass = bracket3_kernel + featurize3_kernel + forest3_kernel "
-                                 "(HIP events around the three launches on the context stream)",
-                          kernel_ms=kern_ms, alg_bytes_per_variant=alg,
-                          variants_per_launch=mine.n),
+                          frac=achieved / HBM_PEAK_GBPS, traffic=traffic, traffic_measured_at_commit=traffic_commit,
+                          kernel=PASS_KERNELS, kernel_ms=kern_ms, kernel_ms_p5=_pct(step_ms, 5), kernel_ms_p50=_pct(step_ms, 50),
+                          kernel_ms_p95=_pct(step_ms, 95), alg_bytes_per_variant=alg, variants_per_launch=mine.n),
+            e2e_incl_pcie=e2e,
             parity=dict(oracle_slice_bit_exact=check, gather_consistent=ok_all),
-            setup_s=round(t_setup, 1))
-        if grp.world == 1 and args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(cs, forests, min(args.cpu_sample, n_total))
-            out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
-        else:
-            out["cpu_baseline"] = None
+            setup_s=round(t_setup, 1), cpu_baseline=cpu)
         print(json.dumps(out), flush=True)
     eng.close()
     grp.close()
+
+
+def _single_gpu_only(args):
+    if args.gpus != 1 or int(os.environ.get("WORLD_SIZE", "1")) != 1:
+        raise SystemExit(f"--workload {args.workload} is a single-GPU measurement (the path it times does not shard further)")
+
+
+def _line(metric, value, unit, args, ms, workload, roofline, extra=None, dtype="i32"):
+    out = dict(metric=metric, value=value, unit=unit, n_gpus=1, steps=args.steps, warmup=args.warmup, ms_per_step=ms,
+               higher_is_better=True, scaling="weak", vs_baseline=None, dtype=dtype, data="synthetic",
+               config=dict(workload=workload, commit=_git_head()), roofline=roofline, cpu_baseline=None)
+    out.update(extra or {})
+    print(json.dumps(out), flush=True)
+
+
+def run_pileup(args):
+    _single_gpu_only(args)
+    from oracle import oracle as O
+    from variantcalling_amd import synth
+    from variantcalling_amd.engine import Engine
+    n_loci = args.variants
+    off, obs = synth.make_pileup(n_loci, seed=5)
+    cpu = None
+    if args.cpu_sample > 0:
+        k = min(n_loci, max(args.cpu_sample, 200_000))
+        t0 = time.perf_counter()
+        O.pileup_tally(off[:k + 1], obs[:off[k]])
+        dt = time.perf_counter() - t0
+        cpu = dict(value=k / dt, unit="loci/s", cores=1, kind="port", sample=f"first {k} loci, oracle.pileup_tally (numpy), {dt:.1f} s")
+    eng = Engine(0)
+    eng.upload_pileup(off, obs)
+    if args.warmup:
+        eng.timed_pileup(args.warmup)
+    eng.device_sync()
+    t0 = time.perf_counter()
+    ms = eng.timed_pileup(args.steps)
+    eng.device_sync()
+    wall = time.perf_counter() - t0
+    kern_ms = ms / args.steps
+    achieved = ALG_BYTES_PILEUP * n_loci / (kern_ms * 1e-3) / 1e9
+    exp = O.pileup_tally(off[:2001], obs[:off[2000]])
+    got = eng.pileup_tally(off[:2001], obs[:off[2000]])
+    ok = all(np.array_equal(got[k], exp[k]) for k in ("ref_fwd", "ref_rev", "alt_fwd", "alt_rev", "other", "dp", "bq_ref", "bq_alt"))
+    _line("pileup loci/sec tallied", n_loci * args.steps / wall, "loci/s", args, wall / args.steps * 1e3,
+          f"a11 pileup tally: {n_loci} loci, {obs.size} observations (Poisson(30) deep), CSR resident in HBM",
+          dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBPS, unit="GB/s", frac=achieved / HBM_PEAK_GBPS, traffic=None,
+               kernel="pileup_kernel (csrc/kernels_aux.hip)", kernel_ms=kern_ms, alg_bytes_per_locus=ALG_BYTES_PILEUP),
+          dict(parity=dict(oracle_slice_bit_exact=bool(ok)), cpu_baseline=cpu), dtype="u16 observations, i32 tallies, f64 SOR")
+    eng.close()
+
+
+def run_sec_apply(args):
+    _single_gpu_only(args)
+    from variantcalling_amd import model_io, synth
+    from variantcalling_amd.engine import Engine, configure
+    cs = synth.make_callset(args.variants)
+    forests = model_io.load_models(os.path.join(ROOT, "tests", "golden", "synth_rf_v1.npz"))[MODEL]
+    eng = Engine(0)
+    configure(eng, cs.ref, cs.runs, cs.tracks, cs.blacklist, forests)
+    eng.upload_variants(cs.variants)
+    eng.filter_resident()
+    rng = np.random.default_rng(0)
+    vk = cs.variants.keys()
+    loci = np.unique(vk[rng.random(vk.size) < 0.4])
+    keys = loci[rng.integers(0, loci.size, 8_000_000)]
+    counts = rng.integers(0, 60, size=(keys.size, 3)).astype(np.int32)
+    db_k, db_e = eng.sec_db_build(keys, counts)
+    eng.set_sec_db(db_k, db_e)
+    for _ in range(max(args.warmup, 1)):
+        eng.sec_apply(mark=True, download=False)
+    eng.device_sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.sec_apply(mark=True, download=False)
+    eng.device_sync()
+    wall = time.perf_counter() - t0
+    ms = wall / args.steps * 1e3
+    achieved = ALG_BYTES_SEC * cs.variants.n / (ms * 1e-3) / 1e9
+    _line("SEC calls/sec tested against the cohort database", cs.variants.n * args.steps / wall, "variants/s", args, ms,
+          f"SEC apply: {cs.variants.n} resident calls against {db_k.size} database loci (k = 3), verdict into the resident flags",
+          dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBPS, unit="GB/s", frac=achieved / HBM_PEAK_GBPS, traffic=None,
+               kernel="sec_apply_kernel (csrc/kernels_sec.hip); host-timed launches (one launch per step, launch latency included)",
+               kernel_ms=ms, alg_bytes_per_variant=ALG_BYTES_SEC), dtype="i32 counts, f64 log-likelihoods")
+    eng.close()
+
+
+def run_c5(args):
+    _single_gpu_only(args)
+    from variantcalling_amd import model_io, synth
+    from variantcalling_amd.engine import Engine, configure
+    n = 2_000_000 if args.variants == 5_000_000 else args.variants
+    cs = synth.make_callset(n)
+    forests = model_io.load_models(os.path.join(ROOT, "tests", "golden", "synth_rf_v1.npz"))["xgb_model_ignore_gt_incl_hpol_runs"]
+    eng = Engine(0)
+    configure(eng, cs.ref, cs.runs, cs.tracks, cs.blacklist, forests)
+    eng.upload_variants(cs.variants)
+    X, group = eng.feature_matrix()
+    N = X.shape[0]
+    tot_gemm = tot_trav = 0.0
+    same = True
+    t0 = time.perf_counter()
+    for g in range(3):
+        rows = np.flatnonzero(group == g).astype(np.int32)
+        a, ms_a = eng.forest_gemm(g, rows, use_mfma=True, iters=args.steps)
+        b, ms_b = eng.forest_gemm(g, rows, use_mfma=False, iters=args.steps)
+        same &= bool(np.array_equal(a, b))
+        tot_gemm += ms_a
+        tot_trav += ms_b
+    wall = time.perf_counter() - t0
+    T, I, L = 100, 64, 64
+    tops = 2.0 * I * L * T * N / (tot_gemm * 1e-3) / 1e12
+    _line("variants/sec scored, leaf-matrix GEMM on MFMA (config C5)", N / (tot_gemm * 1e-3), "variants/s", args, tot_gemm,
+          f"C5: {N} variants, on-GPU N x 20 feature matrix, XGBoost-shaped T=100 depth-6 ensemble x 3 groups as path-matrix GEMM (i8 MFMA) "
+          "next to the row traversal",
+          dict(bound="mfma", achieved=tops, peak=MFMA_I8_PEAK_TOPS, unit="TOP/s (int8)", frac=tops / MFMA_I8_PEAK_TOPS, traffic=None,
+               kernel="forest_gemm_kernel (csrc/kernels_gemm.hip), v_mfma_i32_16x16x64_i8", kernel_ms=tot_gemm,
+               alg_ops_per_variant=2.0 * I * L * T, traversal_ms=tot_trav, traversal_variants_per_s=N / (tot_trav * 1e-3)),
+          dict(parity=dict(gemm_equals_traversal=bool(same)), wall_s=round(wall, 2)), dtype="f32 compares, int8 MFMA path matrix, f32 margins")
+    eng.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=["filter", "c2", "pileup", "sec_apply", "c5_gemm"], default="filter")
+    ap.add_argument("--variants", type=int, default=5_000_000, help="variants (loci for --workload pileup)")
+    ap.add_argument("--snv-only", action="store_true", help="C2 shape (same as --workload c2)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--cpu-sample", type=int, default=100_000, help="variants timed on the single-process CPU baseline (0 = skip)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive measurement")
+    ap.add_argument("--variant", type=int, default=0, help="kernel variant (debug)")
+    args = ap.parse_args()
+    if args.snv_only:
+        args.workload = "c2"
+    if args.workload in ("filter", "c2"):
+        run_filter(args)
+    elif args.workload == "pileup":
+        run_pileup(args)
+    elif args.workload == "sec_apply":
+        run_sec_apply(args)
+    else:
+        run_c5(args)
 
 
 if __name__ == "__main__":

@@ -146,6 +146,9 @@ int ugvc_timed_filter(ugvc_ctx* ctx, int iters, float* ms_total);
  * event pairs (what bench.py's roofline figure divides by). */
 int ugvc_timed_steps(ugvc_ctx* ctx, int iters, int64_t shard_cap, int gather, float* ms_total,
                      float* ms_kernel);
+/* per-step kernel milliseconds of the last ugvc_timed_steps (HIP event pairs on the launch stream): copies at most
+ * `cap` values, returns how many (bench.py's p5 / p95) */
+int ugvc_last_step_ms(ugvc_ctx* ctx, float* out, int cap);
 int ugvc_device_sync(ugvc_ctx* ctx);   /* hipDeviceSynchronize on the context's device */
 int ugvc_feature_matrix(ugvc_ctx* ctx, float* x_host, uint8_t* group_host);
 int ugvc_n_features(ugvc_ctx* ctx);

@@ -165,6 +165,25 @@ def test_v3_fallbacks_and_dense_tiles(engine, frozen_models, path):
                  "overlapping runs")
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_sliced_context_equals_full(engine, small_callset, frozen_models, world):
+    """What a rank of a multi-GPU run uploads - its shard plus the slices of the genome / interval tables / blacklist the
+    shard can touch, re-based (shard.slice_context) - scores exactly like the shard against the full tables."""
+    from variantcalling_amd import shard
+    cs = small_callset
+    _configure(engine, cs.ref, cs.runs, cs.tracks, cs.blacklist, frozen_models[RF])
+    whole = engine.filter_variants(cs.variants)
+    b = shard.shard_bounds(cs.variants.n, world)
+    for r in (0, world - 1):
+        mine = shard.shard_of(cs.variants, r, world)
+        ref_s, runs_s, tracks_s, bl_s, mine_s = shard.slice_context(cs.ref, cs.runs, cs.tracks, cs.blacklist, mine)
+        _configure(engine, ref_s, runs_s, tracks_s, bl_s, frozen_models[RF])
+        got = engine.filter_variants(mine_s)
+        lo, hi = int(b[r]), int(b[r + 1])
+        assert np.array_equal(got.flags, whole.flags[lo:hi]) and np.array_equal(got.filter, whole.filter[lo:hi])
+        assert np.array_equal(got.tree_score, whole.tree_score[lo:hi])
+
+
 def test_empty_no_tables_and_ragged(engine, small_callset, frozen_models):
     from variantcalling_amd.engine import Engine
     O = _oracle()

@@ -1,0 +1,61 @@
+"""Per-rank context slices ("reference slice [min_pos - 64, max_pos + 64] per touched contig + the
+overlapping part of each table"): scoring a shard against its sliced, re-based tables gives the rows of the whole-callset
+result.  CPU: on the oracle; GPU: the same through the C ABI (tests/test_gpu_parity.py::test_sliced_context_equals_full)."""
+import numpy as np
+import pytest
+
+import edge_cases as E
+from conftest import real_chr1_reference
+from oracle import oracle as O
+from variantcalling_amd import shard, synth
+
+RF = "rf_model_ignore_gt_incl_hpol_runs"
+
+
+def _same(got, full, lo, hi, what):
+    assert np.array_equal(got.flags, full.flags[lo:hi]), what
+    assert np.array_equal(got.filter, full.filter[lo:hi]), what
+    assert np.array_equal(got.tree_score, full.tree_score[lo:hi]), what
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sliced_context_scores_like_the_full_one(frozen_models, world):
+    cs = synth.make_callset(12_000, genome_len=6_000_000, n_contigs=4, seed=3)
+    forests = frozen_models[RF]
+    full = O.filter_variants(cs.variants, cs.ref, cs.runs, cs.tracks, cs.blacklist, forests)
+    b = shard.shard_bounds(cs.variants.n, world)
+    kept = 0
+    for r in range(world):
+        mine = shard.shard_of(cs.variants, r, world)
+        ref_s, runs_s, tracks_s, bl_s, mine_s = shard.slice_context(cs.ref, cs.runs, cs.tracks, cs.blacklist, mine)
+        assert ref_s.n_contigs == cs.ref.n_contigs and mine_s.n == mine.n and int(mine_s.pos.min()) >= 1
+        mine_s.validate()
+        _same(O.filter_variants(mine_s, ref_s, runs_s, tracks_s, bl_s, forests), full, int(b[r]), int(b[r + 1]), f"world {world} rank {r}")
+        kept += ref_s.codes.size
+    assert kept < 1.2 * cs.ref.codes.size                       # the ranks' slices together are about one genome
+
+
+def test_sliced_context_on_real_hg38_edges(frozen_models):
+    """Contig ends, N runs, 50 kb homopolymers, long deletions: a cut never splits a run a variant can see."""
+    ref = real_chr1_reference()
+    vt = E.edge_table(ref)
+    runs, tracks = E.simple_tracks(ref)
+    bl = np.unique(np.concatenate([vt.keys()[::7], vt.keys()[::11] + np.uint64(1)]))
+    forests = frozen_models[RF]
+    full = O.filter_variants(vt, ref, runs, tracks, bl, forests, hpol_len=8, hpol_dist=12)
+    for world in (2, 5):
+        b = shard.shard_bounds(vt.n, world)
+        for r in range(world):
+            mine = shard.shard_of(vt, r, world)
+            if mine.n == 0:
+                continue
+            ref_s, runs_s, tracks_s, bl_s, mine_s = shard.slice_context(ref, runs, tracks, bl, mine)
+            _same(O.filter_variants(mine_s, ref_s, runs_s, tracks_s, bl_s, forests, hpol_len=8, hpol_dist=12), full,
+                  int(b[r]), int(b[r + 1]), f"edges world {world} rank {r}")
+
+
+def test_empty_shard_and_missing_tables():
+    cs = synth.make_callset(500, genome_len=400_000, n_contigs=2, seed=5)
+    empty = cs.variants.slice(0, 0)
+    ref_s, runs_s, tracks_s, bl_s, mine_s = shard.slice_context(cs.ref, None, [], None, empty)
+    assert ref_s.codes.size == 0 and runs_s is None and tracks_s == [] and bl_s is None and mine_s.n == 0

@@ -531,15 +531,24 @@ int ugvc_timed_steps(ugvc_ctx* ctx, int iters, int64_t shard_cap, int gather, fl
     if (!rc) {
         UGVC_HIP(hipEventElapsedTime(ms_total, ctx->ev0, ctx->ev1));
         float sum = 0.f;
+        ctx->step_ms.assign((size_t)iters, 0.f);
         for (int it = 0; it < iters; ++it) {
             float ms = 0.f;
             UGVC_HIP(hipEventElapsedTime(&ms, ev[2 * it], ev[2 * it + 1]));
+            ctx->step_ms[(size_t)it] = ms;
             sum += ms;
         }
         *ms_kernel = sum;
     }
     for (auto& e : ev) (void)hipEventDestroy(e);
     return rc;
+}
+
+int ugvc_last_step_ms(ugvc_ctx* ctx, float* out, int cap) {
+    if (!ctx || (cap > 0 && !out)) return fail("NULL argument");
+    const int n = (int)std::min<size_t>(ctx->step_ms.size(), (size_t)std::max(cap, 0));
+    for (int k = 0; k < n; ++k) out[k] = ctx->step_ms[(size_t)k];
+    return n;
 }
 
 int ugvc_n_features(ugvc_ctx* ctx) { return ctx ? UGVC_N_BASE_FEATURES + ctx->n_tracks : -1; }

@@ -139,6 +139,7 @@ struct ugvc_ctx {
     int gather_pending[2] = {0, 0};
     int rank = 0, world = 1;
     int kernel_variant = 0;
+    std::vector<float> step_ms;     // per-step kernel times of the last ugvc_timed_steps
     void* v2 = nullptr;             // ugvc::V2State (model_pack.hip)
 };
 

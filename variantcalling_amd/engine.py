@@ -67,6 +67,7 @@ ABI = {
     "ugvc_timed_filter": (C.c_int, [_ctx, C.c_int, _f32p]),
     "ugvc_timed_steps": (C.c_int, [_ctx, C.c_int, C.c_int64, C.c_int, _f32p, _f32p]),
     "ugvc_device_sync": (C.c_int, [_ctx]),
+    "ugvc_last_step_ms": (C.c_int, [_ctx, _f32p, C.c_int]),
     "ugvc_feature_matrix": (C.c_int, [_ctx, _f32p, _u8p]),
     "ugvc_n_features": (C.c_int, [_ctx]),
     "ugvc_forest_gemm": (C.c_int, [_ctx, C.c_int, _i32p, C.c_int64, C.c_int, C.c_int, _f32p, _f32p]),
@@ -310,6 +311,14 @@ class Engine:
         tot, ker = C.c_float(), C.c_float()
         self._check(self.lib.ugvc_timed_steps(self._h, iters, shard_cap, int(gather), C.byref(tot), C.byref(ker)))
         return tot.value, ker.value
+
+    def last_step_ms(self, n: int) -> np.ndarray:
+        """Per-step kernel milliseconds of the last timed_steps call."""
+        out = np.zeros(max(n, 1), np.float32)
+        k = self.lib.ugvc_last_step_ms(self._h, _p(out, _f32p), int(n))
+        if k < 0:
+            self._check(k)
+        return out[:k]
 
     def device_sync(self):
         self._check(self.lib.ugvc_device_sync(self._h))

@@ -106,8 +106,20 @@ def read_blacklist(path: str, contig_names: list) -> np.ndarray:
                 out.append((np.uint64(c) << np.uint64(32)) | p)
         return np.unique(np.concatenate(out)) if out else np.zeros(0, np.uint64)
     if path.endswith((".pkl", ".pickle")):
-        with open(path, "rb") as fh:
-            obj = pickle.load(fh)
+        try:
+            with open(path, "rb") as fh:
+                obj = pickle.load(fh)
+        except (ImportError, AttributeError):
+            # the reference's blacklist pickle holds objects of an absent class: read its data (legacy_pickle.py)
+            from .. import legacy_pickle
+            got = legacy_pickle.find_loci(legacy_pickle.load(path))
+            if not got:
+                raise ValueError(f"{path}: no (chrom, pos) loci found in the pickle")
+            got = [(idx[str(c)], int(p_)) for c, p_ in got if str(c) in idx]
+            if not got:
+                return np.zeros(0, np.uint64)
+            a = np.array(got, dtype=np.int64)
+            return keys_from_loci(a[:, 0], a[:, 1])
         loci = []
 
         def walk(o):

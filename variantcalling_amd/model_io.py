@@ -48,8 +48,50 @@ def _depth(left, right, feature, root):
     return best
 
 
-def flatten_sklearn(model, n_features: int | None = None) -> S.FlatForest:
+# names the reference's frames give the engine's features (SURVEY.md appendix A "features fed to the forest";
+# ugvc/reports/report_data_loader.py:24-28,67-94): an estimator fitted on a named frame is re-indexed by name
+FEATURE_ALIASES = {"ad_0": "ad_ref", "ad[0]": "ad_ref", "ad_1": "ad_alt", "ad[1]": "ad_alt", "af": "vaf", "af_0": "vaf", "af[0]": "vaf",
+                   "max_vaf": "vaf", "indel": "indel_classify", "hmer_length": "hmer_indel_length"}
+
+
+def feature_permutation(model, track_names: list | None = None):
+    """Engine feature index of every input column of an estimator that carries `feature_names_in_`, or None when it
+    has no names (then its columns are taken to be in the engine's order).  Interval-annotation columns are matched to
+    `track_names` (the BED stems of --annotate_intervals, in command-line order)."""
+    names = getattr(model, "feature_names_in_", None)
+    if names is None:
+        return None
+    ours = {n: i for i, n in enumerate(S.BASE_FEATURES)}
+    tracks = {str(n): S.N_BASE_FEATURES + t for t, n in enumerate(track_names or [])}
+    perm, unknown = [], []
+    for n in (str(x) for x in names):
+        key = FEATURE_ALIASES.get(n.lower(), n.lower())
+        if key in ours:
+            perm.append(ours[key])
+        elif n in tracks:
+            perm.append(tracks[n])
+        elif key.startswith("track") and key[5:].isdigit():
+            perm.append(S.N_BASE_FEATURES + int(key[5:]))
+        else:
+            unknown.append(n)
+    if unknown:
+        raise ValueError(f"the model was fitted on columns this engine does not compute: {unknown}; engine features: "
+                         f"{list(S.BASE_FEATURES)} + one per --annotate_intervals file {list(track_names or [])}")
+    return np.asarray(perm, np.int32)
+
+
+def flatten_sklearn(model, n_features: int | None = None, track_names: list | None = None) -> S.FlatForest:
     """RandomForestClassifier / ExtraTrees / DecisionTreeClassifier (binary) -> FlatForest."""
+    perm = feature_permutation(model, track_names)
+    f = _flatten_sklearn(model, n_features)
+    if perm is not None:
+        inner = f.feature >= 0
+        f.feature = np.where(inner, perm[np.clip(f.feature, 0, perm.size - 1)], f.feature).astype(np.int32)
+        f.n_features = max(int(f.n_features), int(perm.max()) + 1)
+    return f
+
+
+def _flatten_sklearn(model, n_features: int | None = None) -> S.FlatForest:
     ests = list(model.estimators_) if hasattr(model, "estimators_") else [model]
     classes = list(getattr(model, "classes_", [0, 1]))
     if len(classes) > 2:
@@ -239,8 +281,16 @@ def load_model_file(path: str, model_name: str | None = None):
     if path.endswith(".npz"):
         models = load_models(path)
     else:
-        with open(path, "rb") as fh:
-            raw = pickle.load(fh)
+        try:
+            with open(path, "rb") as fh:
+                raw = pickle.load(fh)
+        except (ImportError, AttributeError):
+            # a pickle of the reference's own model classes (ugbio_filtering.*, absent here): read the data without
+            # the classes and pull the estimators out of the object graph (legacy_pickle.py)
+            from . import legacy_pickle
+            raw = legacy_pickle.find_estimators(legacy_pickle.load(path), S.GROUP_NAMES)
+            if not raw:
+                raise ValueError(f"{path}: no scikit-learn estimator found in the pickle")
         models = {}
         for name, m in (raw.items() if isinstance(raw, dict) else [("model", raw)]):
             if isinstance(m, dict):

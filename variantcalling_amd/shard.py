@@ -48,3 +48,73 @@ def pad_result(r: S.FilterResult, cap: int) -> S.FilterResult:
         out[: a.size] = a
         return out
     return S.FilterResult(pad(r.tree_score), pad(r.filter), pad(r.flags))
+
+
+def _slice_track(tr: S.IntervalTrack, lo: np.ndarray, hi: np.ndarray, shift: np.ndarray, touched: np.ndarray, pad: int) -> S.IntervalTrack:
+    """Rows of a per-contig sorted interval table that can matter to positions [lo[c], hi[c]) of every touched contig
+    (overlap within `pad`, plus one row of halo on either side), shifted into the sliced coordinates."""
+    n_contigs = tr.contig_ptr.size - 1
+    starts, ends, ptr = [], [], [0]
+    for c in range(n_contigs):
+        a, b = int(tr.contig_ptr[c]), int(tr.contig_ptr[c + 1])
+        kept = 0
+        if touched[c] and b > a:
+            s, e = tr.starts[a:b], tr.ends[a:b]
+            first = int(np.searchsorted(e, lo[c] - pad, side="left"))          # ends ascend per contig (checked at upload)
+            last = int(np.searchsorted(s, hi[c] + pad, side="right"))
+            first, last = max(first - 1, 0), min(last + 1, b - a)
+            if last > first:
+                starts.append(s[first:last].astype(np.int64) - shift[c])
+                ends.append(e[first:last].astype(np.int64) - shift[c])
+                kept = last - first
+        ptr.append(ptr[-1] + kept)
+    st = np.concatenate(starts).astype(np.int32) if starts else np.zeros(0, np.int32)
+    en = np.concatenate(ends).astype(np.int32) if ends else np.zeros(0, np.int32)
+    return S.IntervalTrack(st, en, np.asarray(ptr, np.int32), tr.name)
+
+
+def slice_context(ref: S.Reference, runs, tracks: list, blacklist, mine: S.VariantTable, margin: int = 64, pad: int = 128):
+    """What ONE rank needs of the resident tables to score its shard `mine`: per touched contig the
+    reference bases [min_pos - margin, max_pos + longest allele + margin) - extended to the end of the homopolymer run
+    the cut would fall into, so every run a variant of the shard can see is whole - the overlapping part of each interval
+    table (+ one row of halo) and the blacklist keys inside, all shifted into the sliced contigs' coordinates; untouched
+    contigs keep their index with length 0.  Returns (ref, runs, tracks, blacklist, variants) with results identical to
+    scoring `mine` against the full tables (tests/test_host_logic.py on the oracle, tests/test_gpu_parity.py on the GPU).
+    A 3.1 Gb genome becomes ~0.4 Gb per rank at 8 ranks."""
+    n_contigs = ref.n_contigs
+    lo = np.zeros(n_contigs, np.int64)
+    hi = np.zeros(n_contigs, np.int64)
+    touched = np.zeros(n_contigs, bool)
+    if mine.n:
+        c = mine.contig.astype(np.int64)
+        first = np.flatnonzero(np.r_[True, c[1:] != c[:-1]])
+        last = np.r_[first[1:], c.size] - 1
+        reach = mine.pos.astype(np.int64) + np.maximum(mine.ref_len, mine.alt_len).astype(np.int64)
+        for f, l in zip(first, last):
+            cc = int(c[f])
+            clen = ref.contig_len(cc)
+            a = max(int(mine.pos[f]) - 1 - margin, 0)
+            b = min(int(reach[f:l + 1].max()) + margin, clen)
+            seq = ref.codes[int(ref.contig_off[cc]): int(ref.contig_off[cc + 1])]
+            while b < clen and b > 0 and seq[b] == seq[b - 1]:                     # finish the run the cut falls into
+                b += 1
+            b = min(b + margin, clen)                                              # ... and keep the motif behind it
+            lo[cc], hi[cc], touched[cc] = a, b, True
+    parts = [ref.codes[int(ref.contig_off[cc]) + int(lo[cc]): int(ref.contig_off[cc]) + int(hi[cc])] for cc in range(n_contigs)]
+    off = np.concatenate([[0], np.cumsum([p.size for p in parts])]).astype(np.int64)
+    ref_s = S.Reference(np.concatenate(parts) if parts else np.zeros(0, np.uint8), off, list(ref.names))
+    shift = lo
+    runs_s = _slice_track(runs, lo, hi, shift, touched, pad) if runs is not None else None
+    tracks_s = [_slice_track(t, lo, hi, shift, touched, pad) for t in (tracks or [])]
+    bl_s = None
+    if blacklist is not None:
+        kc = (blacklist >> np.uint64(32)).astype(np.int64)
+        kp = (blacklist & np.uint64(0xFFFFFFFF)).astype(np.int64)
+        inside = (kc < n_contigs)
+        kcc = np.minimum(kc, n_contigs - 1)
+        inside &= touched[kcc] & (kp > lo[kcc]) & (kp <= hi[kcc])
+        bl_s = ((kc[inside].astype(np.uint64) << np.uint64(32)) | (kp[inside] - lo[kc[inside]]).astype(np.uint64)).astype(np.uint64)
+    kw = {col: np.ascontiguousarray(getattr(mine, col)) for col in mine.COLS}
+    kw["pos"] = (mine.pos.astype(np.int64) - lo[mine.contig.astype(np.int64)]).astype(np.int32)
+    mine_s = S.VariantTable(alleles=mine.alleles, **kw)
+    return ref_s, runs_s, tracks_s, bl_s, mine_s
