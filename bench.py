@@ -80,7 +80,7 @@ def cpu_baseline(cs, forests, sample_n):
     cores = os.cpu_count() or 1
     workers = max(1, min(cores, 256))
     n_multi = int(min(cs.variants.n, max(sample_n, sub.n / t_idiom * 12.0 * workers)))    # ~12 s of work per worker
-    chunks = workers * 4
+    chunks = workers                   # one chunk per process: each pays the tool's per-run table preparation once
     edges = np.linspace(0, n_multi, chunks + 1).astype(np.int64)
     for c in np.unique(cs.variants.contig[:n_multi]):   # "open the FASTA" once, before the fork and outside the timed region
         fa[int(c)]

@@ -57,6 +57,11 @@ typedef struct ugvc_vcf_view {
     const char* text;          /* inflated file; FILTER column of table row k = text[filter_off[k] ..] */
     const int64_t* filter_off;
     const int32_t* filter_len;
+    /* multi-allelic records: the table row carries the FIRST ALT; the host expands the rows with n_alt > 1 (or an ALT
+     * of '*') from the record text: table row k is text[rec_off[k] .. rec_off[k] + rec_len[k]) */
+    const uint8_t* n_alt;      /* ALT alleles of the record (capped at 255)                            */
+    const int64_t* rec_off;
+    const int32_t* rec_len;
 } ugvc_vcf_view;
 
 /* Read + inflate (.gz: BGZF blocks in parallel, plain gzip serially) + tokenise `path`.

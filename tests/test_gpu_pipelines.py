@@ -126,3 +126,60 @@ def test_train_then_filter(tmp_path):
             continue
         # and against scikit-learn itself
         assert np.array_equal(exp.tree_score[g0], models[name]["snp"].predict_proba(ft["X"][g0])[:, 1].astype(np.float32))
+
+
+def test_wgs_sized_contig_list_and_multiallelic_records_through_the_cli(tmp_path, frozen_models):
+    """A reference with the 3 366 contigs of the reference's production header (tests/golden/hg38_contigs.tsv.gz; short
+    synthetic sequences under the real names): calls on contigs beyond index 255 (alt / decoy / HLA) go through the tool,
+    multi-allelic records are scored per ALT allele and folded into one FILTER / TREE_SCORE per record (io/multiallelic.py),
+    a spanning-deletion allele gets no row.  Expected values: the oracle on the expanded table, folded by the same rule."""
+    from oracle import oracle as O
+    from variantcalling_amd.io import multiallelic, vcf_native
+    from variantcalling_amd.pipelines import filter_variants_pipeline
+    names = [ln.split("\t")[0] for ln in gzip.open(os.path.join(GOLDEN, "hg38_contigs.tsv.gz"), "rt") if not ln.startswith("#")]
+    rng = np.random.default_rng(12)
+    L = 1500
+    codes = rng.integers(1, 5, size=len(names) * L).astype(np.uint8)
+    ref = S.Reference(codes, (np.arange(len(names) + 1) * L).astype(np.int64), list(names))
+    fa = str(tmp_path / "wide.fa"); fasta.write_fasta(fa, ref)
+    lines = ["##fileformat=VCFv4.2"] + [f"##contig=<ID={n},length={L}>" for n in names] + \
+            ["#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\ts1"]
+    letters = "NACGT"
+    n_rec = 0
+    for c in sorted(set(rng.integers(0, len(names), 400).tolist()) | {0, 255, 256, 3365}):
+        for pos in sorted(set(rng.integers(20, L - 60, 3).tolist())):
+            r = letters[codes[c * L + pos - 1]]
+            others = [b for b in "ACGT" if b != r]
+            kind = int(rng.integers(0, 5))
+            if kind == 0:
+                alt, ad = f"{others[0]},{others[1]}", "7,9,11"
+            elif kind == 1:
+                alt, ad = f"*,{r}{others[2]}", "6,5,12"
+            elif kind == 2:
+                alt, ad = f"{others[0]},*,{r}AA", "4,8,3,10"
+            else:
+                alt, ad = others[int(rng.integers(0, 3))], "10,12"
+            dp = sum(int(x) for x in ad.split(","))
+            lines.append(f"{names[c]}\t{pos}\t.\t{r}\t{alt}\t{rng.exponential(60):.2f}\t.\tSOR={rng.lognormal(0, .7):.3f}\t"
+                         f"GT:AD:DP:GQ\t0/1:{ad}:{dp}:{int(rng.integers(0, 99))}")
+            n_rec += 1
+    vcf_path = str(tmp_path / "wide.vcf")
+    open(vcf_path, "w").write("\n".join(lines) + "\n")
+    out = str(tmp_path / "wide.filtered.vcf.gz")
+    runs = str(tmp_path / "runs.bed"); open(runs, "w").write("")
+    rc = filter_variants_pipeline.run(["filter_variants_pipeline", "--input_file", vcf_path, "--model_file", os.path.join(GOLDEN, "synth_rf_v1.npz"),
+                                       "--model_name", RF, "--runs_file", runs, "--reference_file", fa, "--output_file", out] +
+                                      sum((["--annotate_intervals", runs] for _ in range(3)), []))
+    assert rc == 0
+    v = vcf_native.read_vcf(vcf_path, names)
+    assert int(v.table.contig.max()) == 3365 and (v.n_alt > 1).sum() > 50
+    table, base = multiallelic.expand(v)
+    assert table.n > v.table.n
+    empty = [S.IntervalTrack(np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(len(names) + 1, np.int32), f"t{j}") for j in range(3)]
+    runs_t = S.IntervalTrack(np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(len(names) + 1, np.int32), "runs")
+    exp = multiallelic.collapse(O.filter_variants(table, ref, runs_t, empty, None, frozen_models[RF]), base, v.table.n)
+    score, tags = _parse_out(out, n_rec)
+    inv = np.argsort(v.order)                                   # file order -> table row (the input is sorted: identity)
+    assert np.array_equal(score[v.order], exp.tree_score) or np.array_equal(score, exp.tree_score[inv])
+    low = np.array(["LOW_SCORE" in t for t in tags])
+    assert np.array_equal(low[v.order], exp.filter == S.FILTER_LOW_SCORE)

@@ -29,7 +29,7 @@ from variantcalling_amd import legacy_pickle, model_io, schema as S
 MANIFEST = json.load(open(os.path.join(ROOT, "tests", "golden", "lfs_manifest.json")))
 LFS_ROOT = os.environ.get("UGVC_LFS_ROOT", "/root/reference/test/resources")
 FILTER_DIR = "system/test_filter_variants_pipeline"
-NEEDED = [f"{FILTER_DIR}/exact_gt.model.pkl", f"{FILTER_DIR}/approximate_gt.model.pkl",
+NEEDED = ["general/chr1_head/hg38_runs.conservative.bed", f"{FILTER_DIR}/exact_gt.model.pkl", f"{FILTER_DIR}/approximate_gt.model.pkl",
           f"{FILTER_DIR}/blacklist_example.chr1_1_1000000.pkl",
           f"{FILTER_DIR}/004777-X0024.annotated.AF_chr1_1_1000000.vcf.gz", f"{FILTER_DIR}/006919_no_frd_chr1_1_5000000.vcf.gz",
           f"{FILTER_DIR}/036269-NA24143-Z0016.frd_chr1_1_5000000_unfiltered.vcf.gz",
@@ -82,7 +82,8 @@ def test_manifest_agrees_with_the_pointer_files():
 
 # ---------------------------------------------------------------------------------------------- the replay itself
 def replay_filter_fixtures(root: str, out_dir: str, model_files=("exact_gt.model.pkl", "approximate_gt.model.pkl"),
-                           fasta="general/chr1_head/Homo_sapiens_assembly38.fasta", vcfs=None, blacklist="blacklist_example.chr1_1_1000000.pkl",
+                           fasta="general/chr1_head/Homo_sapiens_assembly38.fasta", runs="general/chr1_head/hg38_runs.conservative.bed",
+                           vcfs=None, blacklist="blacklist_example.chr1_1_1000000.pkl",
                            frame="system/test_train_models_pipeline/train_model_approximate_gt_input.h5"):
     """Run the filter tool on the fixture VCFs with every named model of the fixture pickles; returns a report dict:
     models found, per (model file, model name, vcf) the PASS / LOW_SCORE counts, and per feature the number of rows of
@@ -99,7 +100,8 @@ def replay_filter_fixtures(root: str, out_dir: str, model_files=("exact_gt.model
             for v in vcfs:
                 out = os.path.join(out_dir, f"{mf}.{name}.{v}".replace("/", "_"))
                 argv = ["filter_variants_pipeline", "--input_file", os.path.join(d, v), "--model_file", os.path.join(d, mf),
-                        "--model_name", name, "--reference_file", os.path.join(root, fasta), "--output_file", out]
+                        "--model_name", name, "--reference_file", os.path.join(root, fasta), "--runs_file", os.path.join(root, runs),
+                        "--output_file", out]
                 if blacklist:
                     argv += ["--blacklist", os.path.join(d, blacklist)]
                 filter_variants_pipeline.run(argv)
@@ -127,7 +129,7 @@ def _standin_model_pickle(frozen_models_rf, names=("rf_model_ignore_gt_incl_hpol
     of classes in a module `ugbio_filtering.variant_filtering_utils` that does not exist when the file is read."""
     from sklearn.ensemble import RandomForestClassifier
     rng = np.random.default_rng(3)
-    F = S.N_BASE_FEATURES + 3
+    F = S.N_BASE_FEATURES                            # no annotation tracks: the replay passes none
     X = rng.normal(size=(3000, F)).astype(np.float32)
     ests = {}
     for g, gname in enumerate(S.GROUP_NAMES):
@@ -266,6 +268,8 @@ def test_replay_on_a_stand_in_directory(tmp_path, frozen_models):
     for mf in ("exact_gt.model.pkl", "approximate_gt.model.pkl"):
         open(d / mf, "wb").write(raw)
     pickle.dump([("chr1", int(p)) for p in cs.variants.pos[::50]], open(d / "blacklist_example.chr1_1_1000000.pkl", "wb"))
+    from variantcalling_amd.io import bed
+    bed.write_bed(str(root / "general" / "chr1_head" / "hg38_runs.conservative.bed"), cs.runs, ["chr1"])
     rep = replay_filter_fixtures(str(root), str(tmp_path), vcfs=vcfs, frame="absent.h5")
     assert set(rep["models"]) == {"exact_gt.model.pkl", "approximate_gt.model.pkl"}
     assert len(rep["runs"]) == 2 * 2 * 3

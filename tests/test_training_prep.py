@@ -1,0 +1,57 @@
+"""training_prep_pipeline (BUILDER-DEFINED around docs/train_models_pipeline.md:5-10 and the fixture
+names of test/resources/unit/filtering/test_training_prep/) and the train flags that restrict / relabel the training
+set: --input_interval, --ignore_filter_status, --vcf_type (host logic, no GPU)."""
+import numpy as np
+import pytest
+
+from variantcalling_amd import schema as S
+from variantcalling_amd.io import concordance, h5
+from variantcalling_amd.pipelines import train_models_pipeline, training_prep_pipeline
+
+HDR = ["##fileformat=VCFv4.2", "##contig=<ID=c1>", "##contig=<ID=c2>", "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\ts1"]
+CALLS = [("c1", 100, "rs1", "A", "C", "PASS"), ("c1", 200, ".", "A", "G", "."), ("c1", 300, ".", "AT", "A", "LOW_SCORE"),
+         ("c1", 900, "rs2", "G", "T", "HPOL_RUN"), ("c2", 50, ".", "C", "CA", "."), ("c2", 70, "rs3", "T", "G", "COHORT_FP;LOW_SCORE")]
+
+
+def _vcf(path, info=lambda k: "SOR=1"):
+    lines = HDR + [f"{c}\t{p}\t{i}\t{r}\t{a}\t50\t{f}\t{info(k)}\tGT:AD:DP:GQ\t0/1:5,6:11:40" for k, (c, p, i, r, a, f) in enumerate(CALLS)]
+    open(path, "w").write("\n".join(lines) + "\n")
+
+
+def test_training_prep_labels_and_feeds_the_trainer(tmp_path):
+    fa = str(tmp_path / "r.fa")
+    open(fa, "w").write(">c1\n" + "ACGT" * 300 + "\n>c2\n" + "TTGCA" * 40 + "\n")
+    calls, ev = str(tmp_path / "input.vcf"), str(tmp_path / "vcfeval_output.vcf")
+    _vcf(calls)
+    # vcfeval says: call 0 TP, call 1 FP, call 4 TP; call 2 has no CALL tag (a baseline-only line)
+    _vcf(ev, info=lambda k: {0: "CALL=TP;BASE=TP", 1: "CALL=FP", 2: "BASE=FN", 4: "CALL=TP"}.get(k, "SOR=1"))
+    bl = str(tmp_path / "bl.npy")
+    np.save(bl, np.array([(0 << 32) | 300, (1 << 32) | 70], np.uint64))
+    hcr = str(tmp_path / "hcr.bed")
+    open(hcr, "w").write("c1\t0\t500\nc2\t0\t100\n")
+    prefix = str(tmp_path / "prep")
+    assert training_prep_pipeline.run(["training_prep_pipeline", "--call_vcf", calls, "--vcfeval_output", ev, "--blacklist", bl,
+                                       "--hcr", hcr, "--reference", fa, "--output_prefix", prefix]) == 0
+    lab = h5.read_hdf(prefix + ".h5", "labels")
+    assert lab["pos"].tolist() == [100, 200, 300, 900, 50, 70]
+    #            vcfeval TP, vcfeval FP, blacklist FP, outside the region, vcfeval TP, blacklist beats dbSNP
+    assert lab["label"].tolist() == [1, 0, 0, -1, 1, 0]
+    fr = concordance.read_concordance(prefix + ".h5", key="all")
+    assert list(fr["classify"]) == ["tp", "fp", "fp", None, "tp", "fp"]
+    vt, rows, label = concordance.frame_to_table(fr, ["c1", "c2"])
+    assert label.tolist() == [1, 0, 0, -1, 1, 0] and vt.pos.tolist() == [100, 200, 300, 900, 50, 70]
+    # approximate mode (no vcfeval): dbSNP => tp, blacklist => fp
+    assert training_prep_pipeline.run(["training_prep_pipeline", "--call_vcf", calls, "--blacklist", bl, "--reference", fa,
+                                       "--output_prefix", prefix + "2"]) == 0
+    assert h5.read_hdf(prefix + "2.h5", "labels")["label"].tolist() == [1, -1, 0, 1, -1, 0]
+
+
+def test_filter_status_and_interval_flags(tmp_path):
+    assert train_models_pipeline._was_filtered(["PASS", ".", "LOW_SCORE", "HPOL_RUN", "HPOL_RUN;LOW_SCORE", None, "COHORT_FP"]).tolist() == \
+        [False, False, True, False, True, False, True]
+    tr = S.IntervalTrack(np.array([10, 100], np.int32), np.array([20, 150], np.int32), np.array([0, 1, 2], np.int32), "r")
+    got = train_models_pipeline._inside_intervals(tr, np.array([0, 0, 0, 1, 1, 1], np.uint16), np.array([10, 11, 20, 100, 150, 151], np.int32))
+    assert got.tolist() == [False, True, True, False, True, False]
+    with pytest.raises(NotImplementedError, match="joint"):
+        train_models_pipeline.run(["train_models_pipeline", "--input_file", "x.vcf", "--reference", "r.fa", "--output_file_prefix",
+                                   str(tmp_path / "m"), "--vcf_type", "joint"])

@@ -4,7 +4,7 @@ pipelines take argv with the tool name first (as simppl hands it over), evaluate
 (/root/reference/ugvc/pipelines/evaluate_concordance.py:71,112-113)."""
 import sys
 
-TOOLS = ("filter_variants_pipeline", "train_models_pipeline", "evaluate_concordance", "calibrate_bridging_snvs")
+TOOLS = ("filter_variants_pipeline", "train_models_pipeline", "training_prep_pipeline", "evaluate_concordance", "calibrate_bridging_snvs")
 
 
 def main(argv):

@@ -326,12 +326,12 @@ struct ugvc_vcf {
     int64_t n = 0;
     // table order
     std::vector<uint16_t> contig;
-    std::vector<uint8_t> gq, gt, has_id, alleles;
-    std::vector<int32_t> pos, dp, ad_ref, ad_alt, filter_len;
+    std::vector<uint8_t> gq, gt, has_id, alleles, n_alt;
+    std::vector<int32_t> pos, dp, ad_ref, ad_alt, filter_len, rec_len;
     std::vector<uint16_t> ref_len, alt_len;
     std::vector<uint32_t> ref_off, alt_off;
     std::vector<float> qual, sor, tlod;
-    std::vector<int64_t> order, filter_off;
+    std::vector<int64_t> order, filter_off, rec_off;
     std::vector<std::string> contig_names;  // index = contig column (for the tabix index of the output)
 };
 
@@ -339,12 +339,12 @@ namespace {
 
 struct Parsed {                              // file order
     std::vector<uint16_t> contig;
-    std::vector<uint8_t> gq, gt, has_id;
+    std::vector<uint8_t> gq, gt, has_id, n_alt;
     std::vector<int32_t> pos, dp, adr, ada;
     std::vector<float> qual, sor, tlod;
     std::vector<Span> ref, alt, filt;
     void resize(size_t n) {
-        contig.resize(n); gq.resize(n); gt.resize(n); has_id.resize(n);
+        contig.resize(n); gq.resize(n); gt.resize(n); has_id.resize(n); n_alt.resize(n);
         pos.resize(n); dp.resize(n); adr.resize(n); ada.resize(n);
         qual.resize(n); sor.resize(n); tlod.resize(n);
         ref.resize(n); alt.resize(n); filt.resize(n);
@@ -394,6 +394,9 @@ bool parse_record(const char* base, Span line, int64_t k, const std::unordered_m
         const char* a = base + f[4].off;
         const char* c = static_cast<const char*>(memchr(a, ',', (size_t)f[4].len));
         P.alt[k] = Span{f[4].off, c ? (int32_t)(c - a) : f[4].len};
+        int na = 1;                                      // ALT alleles of the record (multi-allelic rows are expanded by the host)
+        for (int q = 0; q < f[4].len; ++q) na += a[q] == ',';
+        P.n_alt[k] = (uint8_t)(na > 255 ? 255 : na);
     }
     if (P.ref[k].len > 65535 || P.alt[k].len > 65535) {
         err = path + ": record " + std::to_string(k + 1) + ": allele longer than 65535 bases";
@@ -740,6 +743,7 @@ int ugvc_vcf_read(const char* path, const char* const* contig_names, int n_conti
 
     // ---- table columns
     h->contig.resize((size_t)n); h->gq.resize((size_t)n); h->gt.resize((size_t)n); h->has_id.resize((size_t)n);
+    h->n_alt.resize((size_t)n); h->rec_off.resize((size_t)n); h->rec_len.resize((size_t)n);
     h->pos.resize((size_t)n); h->dp.resize((size_t)n); h->ad_ref.resize((size_t)n); h->ad_alt.resize((size_t)n);
     h->ref_len.resize((size_t)n); h->alt_len.resize((size_t)n); h->ref_off.resize((size_t)n); h->alt_off.resize((size_t)n);
     h->qual.resize((size_t)n); h->sor.resize((size_t)n); h->tlod.resize((size_t)n);
@@ -761,6 +765,7 @@ int ugvc_vcf_read(const char* path, const char* const* contig_names, int n_conti
         for (int64_t k = lo; k < hi; ++k) {
             const size_t j = (size_t)h->order[(size_t)k], kk = (size_t)k;
             h->contig[kk] = P.contig[j]; h->pos[kk] = P.pos[j]; h->gq[kk] = P.gq[j]; h->gt[kk] = P.gt[j];
+            h->n_alt[kk] = P.n_alt[j]; h->rec_off[kk] = h->rec_lines[j].off; h->rec_len[kk] = h->rec_lines[j].len;
             h->has_id[kk] = P.has_id[j]; h->dp[kk] = P.dp[j]; h->ad_ref[kk] = P.adr[j]; h->ad_alt[kk] = P.ada[j];
             h->qual[kk] = P.qual[j]; h->sor[kk] = P.sor[j]; h->tlod[kk] = P.tlod[j];
             h->ref_len[kk] = (uint16_t)P.ref[j].len; h->alt_len[kk] = (uint16_t)P.alt[j].len;
@@ -788,6 +793,7 @@ int ugvc_vcf_get_view(const ugvc_vcf* h, ugvc_vcf_view* v) {
     v->qual = h->qual.data(); v->sor = h->sor.data();
     v->dp = h->dp.data(); v->ad_ref = h->ad_ref.data(); v->ad_alt = h->ad_alt.data();
     v->gq = h->gq.data(); v->gt = h->gt.data(); v->tlod = h->tlod.data(); v->has_id = h->has_id.data();
+    v->n_alt = h->n_alt.data(); v->rec_off = h->rec_off.data(); v->rec_len = h->rec_len.data();
     v->order = h->order.data();
     v->header = h->header_joined.data(); v->header_bytes = (int64_t)h->header_joined.size();
     v->text = h->text.data(); v->filter_off = h->filter_off.data(); v->filter_len = h->filter_len.data();

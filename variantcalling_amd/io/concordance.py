@@ -18,7 +18,8 @@ import numpy as np
 from .. import schema as S
 from . import h5
 
-SKIP_KEYS_ALL = ("concordance", "scored_concordance", "input_args", "comparison_result")
+SKIP_KEYS_ALL = ("concordance", "scored_concordance", "input_args", "comparison_result", "labels", "training_set",
+                 "optimal_recall_precision")
 
 
 def _concat(frames):

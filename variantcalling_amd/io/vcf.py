@@ -9,7 +9,8 @@ Replaces the two per-record pysam loops that bracket the hot path in the referen
   * write: header lines + per record `LOW_SCORE|PASS`, `TREE_SCORE`, `HPOL_RUN`, `COHORT_FP`
     (docs/howto-callset-filter.md:65; ugvc/pipelines/evaluate_concordance.py:47), same order as the input;
     the in-tree example of the write pattern is ugvc/pipelines/vcfbed/calibrate_bridging_snvs.py:101-130.
-Multi-allelic records are featurised on their first ALT allele (BUILDER-DEFINED).  Output `.gz` files are
+The table row of a multi-allelic record carries its first ALT allele; io/multiallelic.py expands such records into one
+row per ALT allele before scoring and folds the verdicts back (BUILDER-DEFINED rule, stated there).  Output `.gz` files are
 BGZF (htslib-compatible blocks + EOF marker).  This module is the host reference of the native codec
 (io.vcf_native / libugvc_vcf.so), which additionally writes the tabix index."""
 from __future__ import annotations
@@ -39,8 +40,13 @@ class VcfFile:
     table: S.VariantTable           # sorted by (contig, pos)
     order: np.ndarray               # table row k came from records[order[k]]
     ids: np.ndarray = field(default_factory=lambda: np.zeros(0, bool))    # ID column != '.', table order
+    n_alt: np.ndarray = field(default_factory=lambda: np.zeros(0, np.uint8))   # ALT alleles per record, table order
     orig_filter: list = field(default_factory=list)
     tlod: np.ndarray | None = None
+
+    def record_line(self, k: int) -> bytes:
+        """The text of the record behind table row k."""
+        return self.records[int(self.order[k])]
 
 
 def _open(path: str):
@@ -72,6 +78,7 @@ def read_vcf(path: str, contig_names: list, is_mutect: bool = False, sample: int
     gq = np.zeros(n, np.uint8); gt = np.zeros(n, np.uint8)
     tlod = np.zeros(n, np.float32)
     has_id = np.zeros(n, bool)
+    n_alt = np.zeros(n, np.uint8)
     refs, alts, flt = [], [], []
     for k, line in enumerate(records):
         f = line.split(b"\t")
@@ -84,6 +91,7 @@ def read_vcf(path: str, contig_names: list, is_mutect: bool = False, sample: int
         has_id[k] = f[2] != b"."
         refs.append(f[3])
         alts.append(f[4].split(b",")[0])
+        n_alt[k] = min(255, f[4].count(b",") + 1)
         qual[k] = _fnum(f[5])
         flt.append(f[6].decode())
         for kv in f[7].split(b";"):
@@ -120,7 +128,7 @@ def read_vcf(path: str, contig_names: list, is_mutect: bool = False, sample: int
         alleles=S._ASCII_TO_CODE[pool], qual=np.ascontiguousarray(qual[order]), sor=np.ascontiguousarray(sor[order]),
         dp=dp[order], ad_ref=adr[order], ad_alt=ada[order], gq=gq[order], gt=gt[order])
     table.validate()
-    return VcfFile(header, records, table, order, has_id[order], [flt[j] for j in order],
+    return VcfFile(header, records, table, order, has_id[order], n_alt[order], [flt[j] for j in order],
                    tlod[order] if is_mutect else None)
 
 

@@ -25,7 +25,8 @@ class _View(C.Structure):
                 ("ad_alt", C.c_void_p), ("gq", C.c_void_p), ("gt", C.c_void_p), ("tlod", C.c_void_p),
                 ("has_id", C.c_void_p), ("order", C.c_void_p),
                 ("header", C.c_void_p), ("header_bytes", C.c_int64),
-                ("text", C.c_void_p), ("filter_off", C.c_void_p), ("filter_len", C.c_void_p)]
+                ("text", C.c_void_p), ("filter_off", C.c_void_p), ("filter_len", C.c_void_p),
+                ("n_alt", C.c_void_p), ("rec_off", C.c_void_p), ("rec_len", C.c_void_p)]
 
 
 class _FastaView(C.Structure):
@@ -110,6 +111,14 @@ class NativeVcfFile:
             ad_alt=_arr(v.ad_alt, n, np.int32), gq=_arr(v.gq, n, np.uint8), gt=_arr(v.gt, n, np.uint8))
         self.table.validate()
         self._orig_filter = None
+        self.n_alt = _arr(v.n_alt, n, np.uint8)
+        self._rec_off, self._rec_len = _arr(v.rec_off, n, np.int64), _arr(v.rec_len, n, np.int32)
+
+    def record_line(self, k: int) -> bytes:
+        """The text of the record behind table row k (multi-allelic expansion reads the few rows it needs)."""
+        v = _View()
+        self._lib.ugvc_vcf_get_view(self._h, C.byref(v))
+        return C.string_at(v.text + int(self._rec_off[k]), int(self._rec_len[k]))
 
     @property
     def orig_filter(self) -> list:
@@ -164,6 +173,15 @@ def format_f32(x: float) -> str:
     if n < 0:
         raise RuntimeError("format_f32 failed")
     return buf.value.decode()
+
+
+def read_fasta_names(path: str) -> list:
+    """Contig names in file order: from the .fai index beside the FASTA when there is one, else from the file."""
+    fai = path + ".fai"
+    if os.path.exists(fai):
+        with open(fai) as fh:
+            return [ln.split("\t")[0] for ln in fh if ln.strip()]
+    return list(read_fasta(path).names)
 
 
 def read_fasta(path: str, contigs: list | None = None, n_threads: int = 0) -> S.Reference:

@@ -12,6 +12,7 @@ import logging
 import sys
 
 from .. import model_io
+from ..io import multiallelic
 from ..io import vcf_native as vcfio      # native codec (libugvc_vcf.so); io.vcf is its pure-Python reference
 from . import common
 
@@ -66,7 +67,9 @@ def run(argv: list[str]):
     with Engine(args.device) as eng:
         configure(eng, ref, runs, tracks, bl, forests, args.flow_order, hp_len, hp_dist, True)
         lap("context + uploads (reference, tables, model)")
-        res = eng.filter_variants(vcf.table)
+        # one row per ALT allele (multi-allelic records, spanning deletions: io/multiallelic.py), one verdict per record
+        table, base_row = multiallelic.expand(vcf)
+        res = multiallelic.collapse(eng.filter_variants(table), base_row, vcf.table.n)
         lap("upload variants + scoring pass + download")
     cg = common.cg_insertion_mask(vcf.table) if args.blacklist_cg_insertions else None
     logger.info("writing %s", args.output_file)

@@ -57,8 +57,25 @@ def get_parser() -> argparse.ArgumentParser:
     return ap
 
 
+# FILTER entries that do not mean "a previous filtering round removed this call": evaluate_concordance ignores HPOL_RUN by
+# default (ugvc/pipelines/evaluate_concordance.py:44-48); RefCall / missing are the callers' own conventions
+_UNFILTERED = frozenset({"", ".", "PASS", "HPOL_RUN", "None", "nan"})
+
+
+def _was_filtered(strings) -> np.ndarray:
+    """True where a FILTER / `filter` entry carries a tag other than PASS / HPOL_RUN (e.g. LOW_SCORE, COHORT_FP)."""
+    out = np.zeros(len(strings), bool)
+    for i, s in enumerate(strings):
+        if s is None or (isinstance(s, float) and s != s):
+            continue
+        out[i] = any(t not in _UNFILTERED for t in str(s).replace(",", ";").split(";"))
+    return out
+
+
 def _read_labelled(args, ref, bl):
-    """-> (VariantTable, label i8: 1 tp / 0 fp / -1 unlabelled)."""
+    """-> (VariantTable, label i8: 1 tp / 0 fp / -1 unlabelled).  Calls an earlier filtering round already removed
+    (`filter` column / FILTER field with LOW_SCORE, COHORT_FP, ...) are left unlabelled unless --ignore_filter_status
+    ("Ignore the `filter` and `tree_score` columns", docs/train_models_pipeline.md:74-76)."""
     if args.input_file.endswith(".npz"):
         z = np.load(args.input_file)
         vt = S.VariantTable(**{c: np.ascontiguousarray(z[c]) for c in S.VariantTable.COLS}, alleles=z["alleles"])
@@ -66,7 +83,11 @@ def _read_labelled(args, ref, bl):
         return vt, z["label"].astype(np.int8)
     if args.input_file.endswith((".h5", ".hdf", ".hdf5")):
         fr = concordance.read_concordance(args.input_file, key="all", contigs=args.list_of_contigs_to_read or None)
-        vt, _, label = concordance.frame_to_table(fr, ref.names, is_mutect=args.mutect)
+        vt, rows, label = concordance.frame_to_table(fr, ref.names, is_mutect=args.mutect)
+        if not args.ignore_filter_status and "filter" in fr:
+            gone = _was_filtered(np.asarray(fr["filter"], dtype=object)[rows])
+            logger.info("%d calls carry a FILTER of an earlier round: not used for training (--ignore_filter_status keeps them)", int(gone.sum()))
+            label = np.where(gone, -1, label).astype(np.int8)
         return vt, label
     vcf = vcfio.read_vcf(args.input_file, ref.names, is_mutect=args.mutect)
     vt = vcf.table
@@ -76,7 +97,27 @@ def _read_labelled(args, ref, bl):
         k = vt.keys()
         i = np.minimum(np.searchsorted(bl, k), bl.size - 1)
         label[bl[i] == k] = 0                             # blacklist => FP
+    if not args.ignore_filter_status:
+        gone = _was_filtered(vcf.orig_filter)
+        if gone.any():
+            logger.info("%d records carry a FILTER of an earlier round: not used for training (--ignore_filter_status keeps them)", int(gone.sum()))
+            label = np.where(gone, -1, label).astype(np.int8)
     return vt, label
+
+
+def _inside_intervals(track: S.IntervalTrack, contig: np.ndarray, pos: np.ndarray) -> np.ndarray:
+    """start < pos <= end of some interval of the row's contig (BED coordinates against the 1-based POS, as the
+    annotation tracks are read); intervals are merged, so the last start below pos decides."""
+    out = np.zeros(pos.size, bool)
+    for c in np.unique(contig):
+        m = np.flatnonzero(contig == c)
+        a, b = int(track.contig_ptr[c]), int(track.contig_ptr[c + 1])
+        if b == a:
+            continue
+        s = np.searchsorted(track.starts[a:b], pos[m], side="left") - 1
+        ok = s >= 0
+        out[m[ok]] = track.ends[a:b][s[ok]] >= pos[m[ok]]
+    return out
 
 
 def fit_models(X, group, label, weights, hpol_flag):
@@ -117,8 +158,20 @@ def run(argv: list[str]):
         raise ValueError("--input_file is required")
     from ..engine import Engine, configure     # fails loudly if the library or the GPU is missing
 
+    if args.vcf_type != "single_sample":
+        # `--vcf_type joint` (docs/train_models_pipeline.md:72-73) trains on a multi-sample callset; how the reference folds
+        # the samples into one feature row is in the absent submodule, so it is refused rather than guessed
+        raise NotImplementedError(f'--vcf_type {args.vcf_type!r}: only "single_sample" callsets are supported')
     ref, runs, tracks, bl = common.load_side_tables(args.reference, args.runs_intervals, args.annotate_intervals, args.blacklist)
     vt, label = _read_labelled(args, ref, bl)
+    if args.input_interval:
+        # "bed file of intersected intervals from run_comparison pipeline" (docs :55-57): only calls inside the compared
+        # (high-confidence) region carry a trustworthy label
+        from ..io import vcf_native
+        region = vcf_native.read_intervals(args.input_interval, ref.names, merge=True)
+        inside = _inside_intervals(region, vt.contig, vt.pos)
+        logger.info("--input_interval: %d of %d calls inside the intervals", int(inside.sum()), vt.n)
+        label = np.where(inside, label, -1).astype(np.int8)
     if args.list_of_contigs_to_read:
         keep = np.isin(vt.contig, [ref.names.index(c) for c in args.list_of_contigs_to_read if c in ref.names])
         rows = np.flatnonzero(keep)
