@@ -164,7 +164,7 @@ int ugvc_ctx_destroy(ugvc_ctx* ctx) {
                         &ctx->v_contig, &ctx->v_pos, &ctx->v_rl, &ctx->v_al, &ctx->v_ro, &ctx->v_ao,
                         &ctx->v_alleles, &ctx->v_qual, &ctx->v_sor, &ctx->v_dp, &ctx->v_adr, &ctx->v_ada,
                         &ctx->v_gq, &ctx->r_score, &ctx->r_filter, &ctx->r_flags, &ctx->x_mat, &ctx->x_group,
-                        &ctx->pl_off, &ctx->pl_obsb, &ctx->pl_out, &ctx->sec_keys, &ctx->sec_coarse, &ctx->sec_exp, &ctx->sec_lgtab, &ctx->g_score[0], &ctx->g_filter[0], &ctx->g_flags[0],
+                        &ctx->pl_off, &ctx->pl_off32, &ctx->pl_obsb, &ctx->pl_out, &ctx->sec_keys, &ctx->sec_coarse, &ctx->sec_exp, &ctx->sec_lgtab, &ctx->g_score[0], &ctx->g_filter[0], &ctx->g_flags[0],
                         &ctx->g_score[1], &ctx->g_filter[1], &ctx->g_flags[1]};
     for (auto* b : all) release(*b);
     for (int t = 0; t < UGVC_MAX_TRACKS; ++t) {

@@ -1,6 +1,9 @@
 // Auxiliary hot-path kernels: pileup tally (a11), SEC multinomial likelihood ratio (a8),
 // bridging-homopolymer SNV un-filter (a12).  gfx950 only.
 #include <math.h>
+#include <string.h>
+
+#include <algorithm>
 
 #include "ugvc_device.hpp"
 
@@ -29,11 +32,18 @@ constexpr int kPlDeep = 2048;
 struct PileupArgs {
     int64_t n_loci;
     const int64_t* off;
+    const uint32_t* off32;     // compact layout: 4-byte offsets (fewer than 2^32 observations)
     const uint16_t* obs;
     int32_t* ref_fwd; int32_t* ref_rev; int32_t* alt_fwd; int32_t* alt_rev;
     int32_t* other; int32_t* dp; int32_t* bq_ref; int32_t* bq_alt;
     float* vaf; float* sor;
+    uint16_t* c16[5];          // compact layout: the four strand counts and `other` as u16 (no locus deeper than 65535)
 };
+// Device-side layouts.  Wide: ten 4-byte columns (ref/alt x fwd/rev, other, dp, bq sums, vaf, sor) and 8-byte offsets:
+// 108 bytes of traffic per locus at 30 observations.  Compact - the layout SURVEY.md 8(d) prices at 84 B/locus: 4-byte
+// offsets, four u16 strand counts + `other` + two u32 base-quality sums + f32 SOR = 22 bytes out; dp (an offset
+// difference) and vaf are derived on the host when the columns are downloaded.  Chosen at upload:
+// compact whenever no locus is deeper than 65535 and the table holds fewer than 2^32 observations.
 
 __device__ __forceinline__ float sor_from_table(int rf, int rr, int af, int ar) {
     // GATK StrandOddsRatio on the +1 table (oracle.pileup_tally)
@@ -56,6 +66,8 @@ __device__ __forceinline__ void pl_walk(Src src, Idx k0, Idx k1, Idx step, PlAcc
     while (k < k1) {
         uint32_t f8 = 0, r8 = 0;                              // four 8-bit class counters each
         const Idx stop = k + 255 * step < k1 ? k + 255 * step : k1;
+        // (four reads per trip, issued together, measured slower: 149 vs 141 us per 5 M loci - the walk is bound by
+        // instruction issue at 24 waves per CU, not by the LDS round trip)
         for (; k < stop; k += step) {
             const uint32_t o = src(k);
             const uint32_t inc = 1u << ((o & 3u) << 3);
@@ -71,23 +83,31 @@ __device__ __forceinline__ void pl_walk(Src src, Idx k0, Idx k1, Idx step, PlAcc
     }
 }
 
+template <bool COMPACT>
 __device__ __forceinline__ void pl_store(const PileupArgs& a, int64_t l, const PlAcc& c, int dp) {
     const int rf = c.cf[0], rr = c.cr[0], af = c.cf[1], ar = c.cr[1];
-    a.ref_fwd[l] = rf; a.ref_rev[l] = rr; a.alt_fwd[l] = af; a.alt_rev[l] = ar;
-    a.other[l] = c.cf[2] + c.cr[2];
-    a.dp[l] = dp;
+    if (COMPACT) {
+        a.c16[0][l] = (uint16_t)rf; a.c16[1][l] = (uint16_t)rr; a.c16[2][l] = (uint16_t)af; a.c16[3][l] = (uint16_t)ar;
+        a.c16[4][l] = (uint16_t)(c.cf[2] + c.cr[2]);
+    } else {
+        a.ref_fwd[l] = rf; a.ref_rev[l] = rr; a.alt_fwd[l] = af; a.alt_rev[l] = ar;
+        a.other[l] = c.cf[2] + c.cr[2];
+        a.dp[l] = dp;
+        a.vaf[l] = dp > 0 ? __fdiv_rn((float)(af + ar), (float)dp) : 0.0f;
+    }
     a.bq_ref[l] = c.bq0; a.bq_alt[l] = c.bq1;
-    a.vaf[l] = dp > 0 ? __fdiv_rn((float)(af + ar), (float)dp) : 0.0f;
     a.sor[l] = sor_from_table(rf, rr, af, ar);
 }
 
+template <bool COMPACT>
 __global__ __launch_bounds__(kPlBlock) void pileup_kernel(const PileupArgs a) {
+    auto off_at = [&](int64_t l) -> int64_t { return COMPACT ? (int64_t)a.off32[l] : a.off[l]; };
     __shared__ __attribute__((aligned(16))) uint16_t stage[kPlCap + 8];
     __shared__ int red[10];
     const int tid = threadIdx.x;
     const int64_t l0 = (int64_t)blockIdx.x * kPlLociPerBlock;
     const int nl = (int)((a.n_loci - l0) < kPlLociPerBlock ? (a.n_loci - l0) : kPlLociPerBlock);
-    const int64_t o0 = a.off[l0], o1 = a.off[l0 + nl];
+    const int64_t o0 = off_at(l0), o1 = off_at(l0 + nl);
     const int64_t base = o0 & ~(int64_t)7;                    // 16-byte aligned start of the staged span
     const bool staged = o1 - base <= kPlCap;
     if (staged) {
@@ -98,13 +118,13 @@ __global__ __launch_bounds__(kPlBlock) void pileup_kernel(const PileupArgs a) {
     }
     __syncthreads();
     const bool mine = tid < nl;
-    const int64_t s = mine ? a.off[l0 + tid] : 0, e = mine ? a.off[l0 + tid + 1] : 0;
+    const int64_t s = mine ? off_at(l0 + tid) : 0, e = mine ? off_at(l0 + tid + 1) : 0;
     const bool deep = mine && (e - s) > kPlDeep;
     if (mine && !deep) {
         PlAcc acc = {{0, 0, 0, 0}, {0, 0, 0, 0}, 0, 0};
         if (staged) pl_walk<int>([&](int k) -> uint32_t { return stage[k]; }, (int)(s - base), (int)(e - base), 1, acc);
         else pl_walk<int64_t>([&](int64_t k) -> uint32_t { return a.obs[k]; }, s, e, (int64_t)1, acc);
-        pl_store(a, l0 + tid, acc, (int)(e - s));
+        pl_store<COMPACT>(a, l0 + tid, acc, (int)(e - s));
     }
     // deep loci: one after the other, the whole workgroup strides over the observations
     unsigned long long dm = __ballot(deep);
@@ -116,7 +136,7 @@ __global__ __launch_bounds__(kPlBlock) void pileup_kernel(const PileupArgs a) {
         while (m) {
             const int j = w * 64 + __ffsll((long long)m) - 1;
             m &= m - 1;
-            const int64_t ds = a.off[l0 + j], de = a.off[l0 + j + 1];
+            const int64_t ds = off_at(l0 + j), de = off_at(l0 + j + 1);
             if (tid < 10) red[tid] = 0;
             __syncthreads();
             PlAcc acc = {{0, 0, 0, 0}, {0, 0, 0, 0}, 0, 0};
@@ -132,7 +152,7 @@ __global__ __launch_bounds__(kPlBlock) void pileup_kernel(const PileupArgs a) {
             __syncthreads();
             if (tid == 0) {
                 PlAcc t = {{red[0], red[2], red[4], red[6]}, {red[1], red[3], red[5], red[7]}, red[8], red[9]};
-                pl_store(a, l0 + j, t, (int)(de - ds));
+                pl_store<COMPACT>(a, l0 + j, t, (int)(de - ds));
             }
             __syncthreads();
         }
@@ -142,17 +162,28 @@ __global__ __launch_bounds__(kPlBlock) void pileup_kernel(const PileupArgs a) {
 int launch_pileup(ugvc_ctx* ctx) {
     if (ctx->pl_n == 0) return 0;
     PileupArgs a;
+    memset(&a, 0, sizeof(a));
     a.n_loci = ctx->pl_n;
     a.off = ctx->pl_off.as<int64_t>();
+    a.off32 = ctx->pl_off32.as<uint32_t>();
     a.obs = ctx->pl_obsb.as<uint16_t>();
     int32_t* o = ctx->pl_out.as<int32_t>();
     const int64_t n = ctx->pl_n;
-    a.ref_fwd = o; a.ref_rev = o + n; a.alt_fwd = o + 2 * n; a.alt_rev = o + 3 * n;
-    a.other = o + 4 * n; a.dp = o + 5 * n; a.bq_ref = o + 6 * n; a.bq_alt = o + 7 * n;
-    a.vaf = reinterpret_cast<float*>(o + 8 * n);
-    a.sor = reinterpret_cast<float*>(o + 9 * n);
     const unsigned grid = (unsigned)((n + kPlLociPerBlock - 1) / kPlLociPerBlock);
-    hipLaunchKernelGGL(pileup_kernel, dim3(grid), dim3(kPlBlock), 0, ctx->stream, a);
+    if (ctx->pl_compact) {
+        // [bq_ref u32 | bq_alt u32 | sor f32 | five u16 count columns]: 22 bytes per locus
+        a.bq_ref = o; a.bq_alt = o + n;
+        a.sor = reinterpret_cast<float*>(o + 2 * n);
+        uint16_t* h = reinterpret_cast<uint16_t*>(o + 3 * n);
+        for (int q = 0; q < 5; ++q) a.c16[q] = h + (size_t)q * n;
+        hipLaunchKernelGGL(pileup_kernel<true>, dim3(grid), dim3(kPlBlock), 0, ctx->stream, a);
+    } else {
+        a.ref_fwd = o; a.ref_rev = o + n; a.alt_fwd = o + 2 * n; a.alt_rev = o + 3 * n;
+        a.other = o + 4 * n; a.dp = o + 5 * n; a.bq_ref = o + 6 * n; a.bq_alt = o + 7 * n;
+        a.vaf = reinterpret_cast<float*>(o + 8 * n);
+        a.sor = reinterpret_cast<float*>(o + 9 * n);
+        hipLaunchKernelGGL(pileup_kernel<false>, dim3(grid), dim3(kPlBlock), 0, ctx->stream, a);
+    }
     UGVC_HIP(hipGetLastError());
     return 0;
 }
@@ -274,7 +305,16 @@ int ugvc_pileup_upload(ugvc_ctx* ctx, const int64_t* offsets, const uint16_t* ob
         if (offsets[i + 1] < offsets[i]) return fail("offsets must be non-decreasing");
     const int64_t m = offsets[n_loci];
     if (m > 0 && !obs) return fail("NULL observations");
-    if (upload(ctx, ctx->pl_off, offsets, (size_t)(n_loci + 1) * 8)) return -1;
+    // compact device layout (4-byte offsets, u16 counts) unless a locus is deeper than 65535 or the table is huge
+    int64_t deepest = 0;
+    for (int64_t i = 0; i < n_loci; ++i) deepest = std::max(deepest, offsets[i + 1] - offsets[i]);
+    ctx->pl_compact = (deepest <= 65535 && m < ((int64_t)1 << 32)) ? 1 : 0;
+    if (ctx->pl_compact) {
+        std::vector<uint32_t> o32((size_t)n_loci + 1);
+        for (int64_t i = 0; i <= n_loci; ++i) o32[(size_t)i] = (uint32_t)offsets[i];
+        if (upload(ctx, ctx->pl_off32, o32.data(), o32.size() * 4)) return -1;
+        UGVC_HIP(hipStreamSynchronize(ctx->stream));          // (o32 goes out of scope)
+    } else if (upload(ctx, ctx->pl_off, offsets, (size_t)(n_loci + 1) * 8)) return -1;
     if (ensure(ctx->pl_obsb, (size_t)m * 2 + 32)) return -1;            // padded: the kernel stages with 16-byte loads
     if (upload(ctx, ctx->pl_obsb, obs, (size_t)m * 2)) return -1;
     if (ensure(ctx->pl_out, (size_t)n_loci * 10 * 4)) return -1;
@@ -291,6 +331,28 @@ int ugvc_pileup_tally(ugvc_ctx* ctx, const int64_t* offsets, const uint16_t* obs
     if (launch_pileup(ctx)) return -1;
     const size_t n = (size_t)n_loci;
     int32_t* o = ctx->pl_out.as<int32_t>();
+    if (ctx->pl_compact) {
+        // 20 bytes per locus come back; dp, other and vaf are derived here (the caller's columns are 4 bytes wide)
+        std::vector<uint16_t> c16(5 * n);
+        if (n) {
+            if (out->bq_ref) UGVC_HIP(hipMemcpyAsync(out->bq_ref, o, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+            if (out->bq_alt) UGVC_HIP(hipMemcpyAsync(out->bq_alt, o + n, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+            if (out->sor) UGVC_HIP(hipMemcpyAsync(out->sor, o + 2 * n, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+            UGVC_HIP(hipMemcpyAsync(c16.data(), o + 3 * n, n * 10, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        UGVC_HIP(hipStreamSynchronize(ctx->stream));
+        int32_t* cols[4] = {out->ref_fwd, out->ref_rev, out->alt_fwd, out->alt_rev};
+        for (size_t i = 0; i < n; ++i) {
+            const int rf = c16[i], rr = c16[n + i], af = c16[2 * n + i], ar = c16[3 * n + i];
+            const int dp = (int)(offsets[i + 1] - offsets[i]);
+            const int v[4] = {rf, rr, af, ar};
+            for (int q = 0; q < 4; ++q) if (cols[q]) cols[q][i] = v[q];
+            if (out->dp) out->dp[i] = dp;
+            if (out->other) out->other[i] = c16[4 * n + i];
+            if (out->vaf) out->vaf[i] = dp > 0 ? (float)(af + ar) / (float)dp : 0.0f;
+        }
+        return 0;
+    }
     void* dst[10] = {out->ref_fwd, out->ref_rev, out->alt_fwd, out->alt_rev, out->other,
                      out->dp, out->bq_ref, out->bq_alt, out->vaf, out->sor};
     for (int k = 0; k < 10; ++k)

@@ -125,7 +125,8 @@ struct ugvc_ctx {
     int scored = 0;                    // the resident result columns hold a scoring pass over the resident variants
     // pileup
     int64_t pl_n = 0, pl_obs = 0;
-    ugvc::DeviceBuf pl_off, pl_obsb, pl_out;
+    ugvc::DeviceBuf pl_off, pl_off32, pl_obsb, pl_out;
+    int pl_compact = 0;              // device layout of the pileup table (kernels_aux.hip)
     // SEC database (kernels_sec.hip): sorted locus keys, every 64th key, k expected counts per locus
     ugvc::DeviceBuf sec_keys, sec_coarse, sec_exp, sec_lgtab;
     int64_t n_sec = 0;
