@@ -20,7 +20,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             k = r["Kernel_Name"].split("(")[0].replace("void ", "")       # template instantiations print a return type
             if k.startswith("ugvc::"):
                 per.setdefault(k, {}).setdefault(c, []).append(float(r["Counter_Value"]))
-out = {"source": d, "unit": "bytes per scoring pass (5 M variants, 1 GPU)", "fetch_correction": 2.0, "kernels": {}}
+head = os.path.join(os.path.dirname(__file__), "..", "profiles", "HEAD")
+out = {"source": d, "commit": open(head).read().strip() if os.path.exists(head) else None,
+       "unit": "bytes per scoring pass (5 M variants, 1 GPU)", "fetch_correction": 2.0, "kernels": {}}
 tot = 0.0
 for k, cs in sorted(per.items()):
     fk = sum(cs.get("FETCH_SIZE", [0])) / max(1, len(cs.get("FETCH_SIZE", [0])))

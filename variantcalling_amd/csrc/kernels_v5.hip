@@ -972,8 +972,12 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
     // top of the previous tile, columns just before its walk), so a tile starts with its window / allele / slice
     // gathers instead of two dependent round trips.  Work slots are wave-major over the workgroups: a short last
     // round leaves a few waves busy on every CU.
-    const int n_iw = v.n_indel_waves, n_sw = n_waves - n_iw;
-    sc.base = L.scratch_b + (uint32_t)(wave < n_sw ? wave * v.scratch_bytes : n_sw * v.scratch_bytes + (wave - n_sw) * v.scratch_indel);
+    // the LDS layout gives the last `n_indel_waves` waves the larger (window-row) scratch; how many of them actually work
+    // on indel tiles follows the callset's class mix (an SNV-only callset has none: every wave runs the SNP pipeline)
+    const int n_big = v.n_indel_waves, n_small = n_waves - n_big;
+    sc.base = L.scratch_b + (uint32_t)(wave < n_small ? wave * v.scratch_bytes : n_small * v.scratch_bytes + (wave - n_small) * v.scratch_indel);
+    const int want_iw = ni > 0 ? (int)((n_waves * ni * 13 + (ns + ni) * 10 - 1) / ((ns + ni) * 10)) : 0;      // ceil(1.3 x share of tiles)
+    const int n_iw = want_iw < n_big ? want_iw : n_big, n_sw = n_waves - n_iw;
     const uint32_t planes_lane_b = sc.base + 2u * (uint32_t)hslot;
     // A featurize phase is a short instruction stream between long memory waits; the walk is a long stream that waits
     // on LDS.  Featurize runs at raised priority (kernel variant bit 29 turns that off): it wins the SIMD's issue
