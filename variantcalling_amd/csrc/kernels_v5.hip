@@ -136,16 +136,16 @@ __global__ __launch_bounds__(256) void bracket5_kernel(const V5Args v) {
     const FilterArgs& f = v.f;
     // active tables, in order: runs (if any), tracks, blacklist (if any)
     const int n_act = (f.has_runs ? 1 : 0) + f.n_tracks + (f.n_bl > 0 ? 1 : 0);
-    if (n_act == 0) return;
+    const int n_thr = n_act > 0 ? n_act : 1;                            // (no table at all: the SNP tiles still get their contig word)
     const int64_t ns = incl[0][kTileShards5 - 1], ni = incl[1][kTileShards5 - 1];
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + tid;
     int64_t rank;                       // rank of the tile among the real tiles of its class
     int k, last;
     bool is_indel;
-    if (gid < ns * n_act) { rank = gid / n_act; k = (int)(gid - rank * n_act); last = 0; is_indel = false; }
+    if (gid < ns * n_thr) { rank = gid / n_thr; k = (int)(gid - rank * n_thr); last = 0; is_indel = false; }
     else {
-        const int64_t g2 = gid - ns * n_act;
-        if (g2 >= ni * 2 * n_act) return;
+        const int64_t g2 = gid - ns * n_thr;
+        if (n_act == 0 || g2 >= ni * 2 * n_act) return;
         rank = g2 / (2 * n_act);
         const int r = (int)(g2 - rank * 2 * n_act);
         last = r >= n_act;
@@ -168,14 +168,31 @@ __global__ __launch_bounds__(256) void bracket5_kernel(const V5Args v) {
     const int slot = last ? (int)v.tile_n[(size_t)v.max_tiles + tile] - 1 : 0;
     const uint32_t i = list[tile * 64 + slot];
     const int c = f.contig[i], pos = f.pos[i];
-    int out;
-    if (t == kJoin5 - 1) out = lb_two_level_g<uint64_t>(f.bl, f.bl_coarse, 0, (int)f.n_bl, ((uint64_t)c << 32) | (uint32_t)pos);
+    int out = 0;
+    if (n_act == 0) {
+    } else if (t == kJoin5 - 1) out = lb_two_level_g<uint64_t>(f.bl, f.bl_coarse, 0, (int)f.n_bl, ((uint64_t)c << 32) | (uint32_t)pos);
     else {
         const TrackView& tv = table_view(f, t);
         out = lb_two_level_g<int32_t>(tv.starts, tv.coarse, tv.ptr[c], tv.ptr[c + 1], pos);
     }
     if (is_indel) v.br_indel[tile * 16 + (last ? 8 : 0) + t] = out;
-    else v.br_snp[tile * 8 + t] = out;
+    else {
+        // SNP tile record (kRecS5 ints): [t] lower bound per table, [7] contig of the tile (bit 31: the tile spans
+        // contigs), [8 + 2t], [9 + 2t] the contig's row range of table t - everything the fused kernel needs to fetch
+        // the tile's slices BEFORE it has seen the tile's columns
+        int32_t* rec = v.br_snp + tile * kRecS5;
+        if (n_act > 0) rec[t] = out;
+        if (n_act > 0 && t != kJoin5 - 1) {
+            const TrackView& tv = table_view(f, t);
+            rec[8 + 2 * t] = tv.ptr[c];
+            rec[9 + 2 * t] = tv.ptr[c + 1];
+        }
+        if (k == 0) {
+            const int n = (int)v.tile_n[tile];
+            const int c_last = f.contig[list[tile * 64 + (n > 0 ? n - 1 : 0)]];
+            rec[7] = c | (c_last != c ? INT32_MIN : 0);
+        }
+    }
 }
 
 // ---- joins ---------------------------------------------------------------------------------------
@@ -352,6 +369,14 @@ __device__ __forceinline__ void rank3_eyt(const float (&fx)[3], const uint32_t (
     for (int e = 0; e < 3; ++e) cd[e] = fx[e] != fx[e] ? len[e] : i[e] - (1u << bits[e]);
 }
 
+#ifdef UGVC_PHASE_CLOCK
+struct PhaseClk { uint64_t last; uint64_t acc[8]; };
+#define CLK(pc, k) do { const uint64_t now_ = __builtin_readcyclecounter(); (pc).acc[k] += now_ - (pc).last; (pc).last = now_; } while (0)
+#else
+struct PhaseClk {};
+#define CLK(pc, k) do { } while (0)
+#endif
+
 struct SnpCols {                    // the columns of one substitution (fetched one tile ahead of their use)
     int c, pos, rl;
     uint32_t ro, ao;
@@ -368,17 +393,52 @@ __device__ __forceinline__ SnpCols load_snp_cols(const FilterArgs& a, uint32_t i
     return k;
 }
 
+// The side-table slices of one SNP tile, in registers: fetched from the tile record alone, one tile ahead (they are
+// in flight during the previous tile's walk and are written to the wave's LDS scratch when that walk has finished
+// with its code planes).
+template <int NT>
+struct SlicePre {
+    int sv[NT][2], ev[NT][2];
+    uint64_t bl;
+};
+
+template <int NT>
+__device__ __forceinline__ void issue_slices(const V5Args& v, uint32_t rec, int lane, SlicePre<NT>& s) {
+    const FilterArgs& a = v.f;
+    s.bl = ~0ull;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        s.sv[t][0] = s.sv[t][1] = s.ev[t][0] = s.ev[t][1] = 0;
+        if (t == 0 && !a.has_runs) continue;
+        const TrackView& tv = table_view(a, t);
+        const int Lt = __builtin_amdgcn_readlane((int)rec, t) - 2;
+        const int top = max(v.na[t] - 1, 0);
+        {
+            const uint32_t gs = (uint32_t)max(min(Lt + lane, top), 0);
+            s.sv[t][0] = tv.starts[gs]; s.ev[t][0] = tv.ends[gs];
+        }
+        if (v.jcap[t] > 64) {
+            const uint32_t gs = (uint32_t)max(min(Lt + 64 + lane, top), 0);
+            s.sv[t][1] = tv.starts[gs]; s.ev[t][1] = tv.ends[gs];
+        }
+    }
+    if (a.n_bl > 0) {
+        const int64_t gi = (int64_t)__builtin_amdgcn_readlane((int)rec, kJoin5 - 1) + lane;
+        if (gi < a.n_bl) s.bl = a.bl[gi];
+    }
+}
+
 // ---- SNP / MNP tile: features of 64 substitutions (ref_len == alt_len) ---------------------------------
 // Writes the flags column, leaves the 16-bit codes of the group-0 forest in the wave's code planes.
 template <int NTRK>
 __device__ __forceinline__ void featurize_snp_tile(const V5Args& v, const Scratch& sc, int64_t tile, int lane, uint32_t i, bool live, bool has_model,
-                                                   const SnpCols& k) {
+                                                   const SnpCols& k, uint32_t rec, const SlicePre<1 + NTRK>& pre, PhaseClk& pc) {
     constexpr int NT = 1 + NTRK;                               // interval tables: runs + tracks
     const FilterArgs& a = v.f;
     const int c = k.c, pos = k.pos, rl = k.rl;
     const uint32_t ro = k.ro, ao = k.ao;
     const int c0 = rfl(c);
-    const bool uni = __ballot(c != c0) == 0;                    // one contig (all but a handful of tiles)
+    const bool uni = __builtin_amdgcn_readlane((int)rec, 7) >= 0;   // one contig (all but a handful of tiles): from K0's record
     int64_t clo, chi;
     if (uni) { clo = cload(a.contig_off + c0); chi = cload(a.contig_off + c0 + 1); }   // scalar loads: no round trip in front of the window
     else { clo = a.contig_off[c]; chi = a.contig_off[c + 1]; }
@@ -398,90 +458,52 @@ __device__ __forceinline__ void featurize_snp_tile(const V5Args& v, const Scratc
     const uint64_t key = ((uint64_t)(uint32_t)c << 32) | (uint32_t)pos;
     const bool joins_on = !(a.ablate & 524288);
     int L[NT], plo[NT], phi[NT];
-    if (uni && joins_on) {
+    const bool stage = uni && joins_on;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        L[t] = __builtin_amdgcn_readlane((int)rec, t) - 2;
+        plo[t] = __builtin_amdgcn_readlane((int)rec, 8 + 2 * t);
+        phi[t] = __builtin_amdgcn_readlane((int)rec, 9 + 2 * t);
+    }
+    CLK(pc, 6);
+    const float qual = k.qual, sor = k.sor;
+    const int dp = k.dp, adr = k.adr, ada = k.ada, gq = k.gq;
+    const float vaf = dp > 0 ? __fdiv_rn((float)ada, (float)dp) : 0.0f;
+    uint32_t cd[3] = {0, 0, 0};
+    if (has_model) {
+        const float fx[3] = {qual, sor, vaf};
+        const int fj[3] = {0, 1, 5};
+        uint32_t base[3], len[3];
+        int bits[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            base[q] = sc.eyt_b + 4u * (uint32_t)v.eyt_off[q];
+            bits[q] = v.eyt_bits[q];
+            len[q] = cload2(v.desc3 + fj[q]).y & 0xFFFFu;             // group 0
+        }
+        rank3_eyt(fx, base, bits, len, cd);
+    }
+    CLK(pc, 7);
+    if (stage) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            L[t] = plo[t] = phi[t] = 0;
             if (t == 0 && !a.has_runs) continue;
-            const TrackView& tv = table_view(a, t);
             const int cap = v.jcap[t];
-            L[t] = cload(v.br_snp + tile * 8 + t) - 2;
-            plo[t] = cload(tv.ptr + c0);
-            phi[t] = cload(tv.ptr + c0 + 1);
-            const int top = max(v.na[t] - 1, 0);
             const uint32_t dS = sc.base + 4u * (uint32_t)v.joff[t], dE = dS + 4u * (uint32_t)cap;
             {
                 const int gi = L[t] + lane;
-                const uint32_t gs = (uint32_t)max(min(gi, top), 0);
-                const int sv = tv.starts[gs], ev = tv.ends[gs];
-                lds_st32(dS + 4u * lane, gi < plo[t] ? INT32_MIN : (gi >= phi[t] ? INT32_MAX : sv));
-                lds_st32(dE + 4u * lane, ev);
+                lds_st32(dS + 4u * lane, gi < plo[t] ? INT32_MIN : (gi >= phi[t] ? INT32_MAX : pre.sv[t][0]));
+                lds_st32(dE + 4u * lane, pre.ev[t][0]);
             }
             if (cap > 64) {
                 const int gi = L[t] + 64 + lane;
-                const uint32_t gs = (uint32_t)max(min(gi, top), 0);
-                const int sv = tv.starts[gs], ev = tv.ends[gs];
-                lds_st32(dS + 256u + 4u * lane, gi < plo[t] ? INT32_MIN : (gi >= phi[t] ? INT32_MAX : sv));
-                lds_st32(dE + 256u + 4u * lane, ev);
+                lds_st32(dS + 256u + 4u * lane, gi < plo[t] ? INT32_MIN : (gi >= phi[t] ? INT32_MAX : pre.sv[t][1]));
+                lds_st32(dE + 256u + 4u * lane, pre.ev[t][1]);
             }
         }
-        if (a.n_bl > 0) {
-            const int64_t gi = (int64_t)cload(v.br_snp + tile * 8 + kJoin5 - 1) + lane;
-            lds_st64(sc.base + 4u * (uint32_t)v.joff[kJoin5 - 1] + 8u * lane, gi < a.n_bl ? a.bl[gi] : ~0ull);
-        }
+        if (a.n_bl > 0) lds_st64(sc.base + 4u * (uint32_t)v.joff[kJoin5 - 1] + 8u * lane, pre.bl);
     }
-    const float qual = k.qual, sor = k.sor;
-    const int dp = k.dp, adr = k.adr, ada = k.ada, gq = k.gq;
-
-    // ---- window: bases pos-5 .. pos+5 in bytes 0..10 of (w0, w1, w2)
-    uint32_t w0 = __builtin_amdgcn_alignbyte(xw.y, xw.x, sh);
-    uint32_t w1 = __builtin_amdgcn_alignbyte(xw.z, xw.y, sh);
-    uint32_t w2 = __builtin_amdgcn_alignbyte(xw.w, xw.z, sh) & 0x00FFFFFFu;
-    uint32_t gc_len = kGcWindow;
-    if (__ballot(p0 < 5u || p0 + 6u > clen) != 0) {             // a lane near a contig edge: bases outside read as N
-        uint32_t m[3] = {0, 0, 0};
-        gc_len = 0;
-#pragma unroll
-        for (int q = 0; q < 11; ++q) {
-            const bool inb = (uint32_t)(p0 - 5u + (uint32_t)q) < clen;        // wraps below 0 -> fails
-            m[q >> 2] |= inb ? 0xFFu << (8 * (q & 3)) : 0u;
-            if (q >= 1) gc_len += inb ? 1u : 0u;
-        }
-        w0 &= m[0]; w1 &= m[1]; w2 &= m[2];
-    }
-    // get_motif_around (5): left = pos-5 .. pos-1, right = pos+1 .. pos+5 (substitutions), base-5 codes
-    const uint32_t b4 = w1 & 0xFFu, b6 = (w1 >> 16) & 0xFFu;
-    const int lm = (int)(__builtin_amdgcn_udot4(w0, 0x00010519u, 0u, false) * 25u + __builtin_amdgcn_udot4(w0, 0x05000000u, b4, false));
-    const int rm = (int)(__builtin_amdgcn_udot4(w1, 0x05190000u, w2 & 0xFFu, false) * 25u + __builtin_amdgcn_udot4(w2, 0x00010500u, 0u, false));
-    const bool motif_n = any_zero_byte(w0) || any_zero_byte(w1 | 0x0000FF00u) || any_zero_byte(w2 | 0xFF000000u);
-    // gc_content (10): bases pos-4 .. pos+5; everything that is not A / T counts (N included, as the reference's string test)
-    const uint32_t n_at = (uint32_t)__popc(at_bytes(w0) & 0x01010100u) + (uint32_t)__popc(at_bytes(w1)) + (uint32_t)__popc(at_bytes(w2) & 0x00010101u);
-    const uint32_t gc_code = lds_u16(sc.gcr_b + 2u * (gc_len * 11u + (gc_len - n_at)));       // group 0
-    // cycle skip
-    int css = 0;
-    if (!(motif_n || rbase == 0 || abase == 0)) css = (int)lds_u8(sc.css_b + (((b4 - 1) << 6) | ((rbase - 1) << 4) | ((abase - 1) << 2) | (b6 - 1)));
-    if (__ballot(rl > 1) != 0) {                                 // MNPs: the full flow-space walk
-        if (rl > 1) {
-            const uint8_t* __restrict__ apool = a.alleles;
-            bool has_n = motif_n;
-            for (int q = 0; q < rl; ++q) has_n |= apool[ro + q] == 0 || apool[ao + q] == 0;
-            if (has_n) css = 0;
-            else {
-                auto wbyte = [&](int q) -> int { return (int)(((q < 4 ? w0 : (q < 8 ? w1 : w2)) >> (8 * (q & 3))) & 0xFFu); };
-                auto seq_r = [&](int q) -> int {
-                    if (q < kMotif) return wbyte(q);
-                    if (q < kMotif + rl) return apool[ro + q - kMotif];
-                    return wbyte(q - rl + 1);
-                };
-                auto seq_a = [&](int q) -> int {
-                    if (q < kMotif) return wbyte(q);
-                    if (q < kMotif + rl) return apool[ao + q - kMotif];
-                    return wbyte(q - rl + 1);
-                };
-                css = cycle_skip_walk(rl + 2 * kMotif, a.flow, seq_r, seq_a);
-            }
-        }
-    }
+    CLK(pc, 0);
 
     // ---- joins
     JoinOut jo{false, false, false, 0u};
@@ -555,24 +577,62 @@ __device__ __forceinline__ void featurize_snp_tile(const V5Args& v, const Scratc
     if (jo.cohort) flags |= UGVC_FLAG_COHORT_FP;
     if (a.mark_hpol && (jo.inside_run || jo.close_run)) flags |= UGVC_FLAG_HPOL_RUN;
     if (live) a.flags[i] = flags;
+    CLK(pc, 2);
     if (!has_model) return;
+    // (the window gather is consumed here, behind the joins: its round trip hides under the rank / join work)
+    // ---- window: bases pos-5 .. pos+5 in bytes 0..10 of (w0, w1, w2)
+    uint32_t w0 = __builtin_amdgcn_alignbyte(xw.y, xw.x, sh);
+    uint32_t w1 = __builtin_amdgcn_alignbyte(xw.z, xw.y, sh);
+    uint32_t w2 = __builtin_amdgcn_alignbyte(xw.w, xw.z, sh) & 0x00FFFFFFu;
+    uint32_t gc_len = kGcWindow;
+    if (__ballot(p0 < 5u || p0 + 6u > clen) != 0) {             // a lane near a contig edge: bases outside read as N
+        uint32_t m[3] = {0, 0, 0};
+        gc_len = 0;
+#pragma unroll
+        for (int q = 0; q < 11; ++q) {
+            const bool inb = (uint32_t)(p0 - 5u + (uint32_t)q) < clen;        // wraps below 0 -> fails
+            m[q >> 2] |= inb ? 0xFFu << (8 * (q & 3)) : 0u;
+            if (q >= 1) gc_len += inb ? 1u : 0u;
+        }
+        w0 &= m[0]; w1 &= m[1]; w2 &= m[2];
+    }
+    // get_motif_around (5): left = pos-5 .. pos-1, right = pos+1 .. pos+5 (substitutions), base-5 codes
+    const uint32_t b4 = w1 & 0xFFu, b6 = (w1 >> 16) & 0xFFu;
+    const int lm = (int)(__builtin_amdgcn_udot4(w0, 0x00010519u, 0u, false) * 25u + __builtin_amdgcn_udot4(w0, 0x05000000u, b4, false));
+    const int rm = (int)(__builtin_amdgcn_udot4(w1, 0x05190000u, w2 & 0xFFu, false) * 25u + __builtin_amdgcn_udot4(w2, 0x00010500u, 0u, false));
+    const bool motif_n = any_zero_byte(w0) || any_zero_byte(w1 | 0x0000FF00u) || any_zero_byte(w2 | 0xFF000000u);
+    // gc_content (10): bases pos-4 .. pos+5; everything that is not A / T counts (N included, as the reference's string test)
+    const uint32_t n_at = (uint32_t)__popc(at_bytes(w0) & 0x01010100u) + (uint32_t)__popc(at_bytes(w1)) + (uint32_t)__popc(at_bytes(w2) & 0x00010101u);
+    const uint32_t gc_code = lds_u16(sc.gcr_b + 2u * (gc_len * 11u + (gc_len - n_at)));       // group 0
+    // cycle skip
+    int css = 0;
+    if (!(motif_n || rbase == 0 || abase == 0)) css = (int)lds_u8(sc.css_b + (((b4 - 1) << 6) | ((rbase - 1) << 4) | ((abase - 1) << 2) | (b6 - 1)));
+    if (__ballot(rl > 1) != 0) {                                 // MNPs: the full flow-space walk
+        if (rl > 1) {
+            const uint8_t* __restrict__ apool = a.alleles;
+            bool has_n = motif_n;
+            for (int q = 0; q < rl; ++q) has_n |= apool[ro + q] == 0 || apool[ao + q] == 0;
+            if (has_n) css = 0;
+            else {
+                auto wbyte = [&](int q) -> int { return (int)(((q < 4 ? w0 : (q < 8 ? w1 : w2)) >> (8 * (q & 3))) & 0xFFu); };
+                auto seq_r = [&](int q) -> int {
+                    if (q < kMotif) return wbyte(q);
+                    if (q < kMotif + rl) return apool[ro + q - kMotif];
+                    return wbyte(q - rl + 1);
+                };
+                auto seq_a = [&](int q) -> int {
+                    if (q < kMotif) return wbyte(q);
+                    if (q < kMotif + rl) return apool[ao + q - kMotif];
+                    return wbyte(q - rl + 1);
+                };
+                css = cycle_skip_walk(rl + 2 * kMotif, a.flow, seq_r, seq_a);
+            }
+        }
+    }
+
+    CLK(pc, 1);
 
     // ---- codes -> the wave's code planes (the staged slices are dead: LDS executes a wave's accesses in order)
-    const float vaf = dp > 0 ? __fdiv_rn((float)ada, (float)dp) : 0.0f;
-    uint32_t cd[3];
-    {
-        const float fx[3] = {qual, sor, vaf};
-        const int fj[3] = {0, 1, 5};
-        uint32_t base[3], len[3];
-        int bits[3];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            base[q] = sc.eyt_b + 4u * (uint32_t)v.eyt_off[q];
-            bits[q] = v.eyt_bits[q];
-            len[q] = cload2(v.desc3 + fj[q]).y & 0xFFFFu;             // group 0
-        }
-        rank3_eyt(fx, base, bits, len, cd);
-    }
     __builtin_amdgcn_wave_barrier();
     const int hslot = ((lane & 31) << 1) | (lane >> 5);
     const uint32_t pl_b = sc.base + 2u * (uint32_t)hslot;
@@ -594,6 +654,7 @@ __device__ __forceinline__ void featurize_snp_tile(const V5Args& v, const Scratc
     lds_st16(pl_b + 128u * 16, jo.close_run ? 2u : 1u);
 #pragma unroll
     for (int t = 0; t < UGVC_MAX_TRACKS; ++t) lds_st16(pl_b + 128u * (17 + t), (jo.trk >> t) & 1u ? 2u : 1u);
+    CLK(pc, 3);
 }
 
 // ---- indel tile: features of 64 length-changing variants -> raw-code records of groups 1 / 2 -------------
@@ -1010,21 +1071,39 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
     bool live;
     fetch_ids(ts, id, i, live);
     SnpCols cols = load_snp_cols(v.f, i);
+    constexpr int NT = 1 + NTRK;
+    const bool joins_on = !(v.f.ablate & 524288);
+    uint32_t rec = (uint32_t)v.br_snp[tile_of(ts, incl_s, v.shard_tiles) * kRecS5 + (lane & (kRecS5 - 1))];
+    SlicePre<NT> pre;
+    issue_slices<NT>(v, joins_on && (int)__builtin_amdgcn_readlane((int)rec, 7) >= 0 ? rec : 0u, lane, pre);
+    PhaseClk pc{};
+#ifdef UGVC_PHASE_CLOCK
+    pc.last = __builtin_readcyclecounter();
+    const uint64_t t_begin = pc.last;
+    int n_done = 0;
+#endif
     for (; ts < ns; ts += stride) {
         const int64_t tile = tile_of(ts, incl_s, v.shard_tiles);
         const bool more = ts + stride < ns;
         uint32_t id_n = 0, i_n = 0;
         bool live_n = false;
         if (prio) __builtin_amdgcn_s_setprio(2);
-        if (more) id_n = v.snp_idx[tile_of(ts + stride, incl_s, v.shard_tiles) * 64 + lane];     // consumed after the joins
-        featurize_snp_tile<NTRK>(v, sc, tile, lane, i, live, has0, cols);
+        uint32_t rec_n = 0;
+        if (more) {
+            const int64_t tile_n = tile_of(ts + stride, incl_s, v.shard_tiles);
+            id_n = v.snp_idx[tile_n * 64 + lane];                                                // consumed after the joins
+            rec_n = (uint32_t)v.br_snp[tile_n * kRecS5 + (lane & (kRecS5 - 1))];
+        }
+        featurize_snp_tile<NTRK>(v, sc, tile, lane, i, live, has0, cols, rec, pre, pc);
         SnpCols cols_n = cols;
         if (more) {
             live_n = id_n != ~0u;
             const uint32_t id0 = (uint32_t)rfl((int)id_n);
             i_n = live_n ? id_n : id0;
             cols_n = load_snp_cols(v.f, i_n);                   // in flight during the walk
+            if (joins_on && (int)__builtin_amdgcn_readlane((int)rec_n, 7) >= 0) issue_slices<NT>(v, rec_n, lane, pre);   // likewise
         }
+        CLK(pc, 4);
         if (prio) __builtin_amdgcn_s_setprio(0);
         if (has0) {
             float score = 0.f;
@@ -1038,9 +1117,20 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
             v.f.score[i] = 0.f;
             v.f.filter[i] = UGVC_FILTER_PASS;
         }
-        cols = cols_n; i = i_n; live = live_n;
+        cols = cols_n; i = i_n; live = live_n; rec = rec_n;
         __builtin_amdgcn_wave_barrier();
+        CLK(pc, 5);
+#ifdef UGVC_PHASE_CLOCK
+        ++n_done;
+#endif
     }
+#ifdef UGVC_PHASE_CLOCK
+    if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 133) && (wave == 0 || wave == 7))
+        printf("clk b%d w%d tiles %d total %llu | stage %llu window %llu joins %llu codes %llu cols_n %llu walk %llu\n", (int)blockIdx.x, wave, n_done,
+               (unsigned long long)(pc.last - t_begin), (unsigned long long)pc.acc[0], (unsigned long long)pc.acc[1], (unsigned long long)pc.acc[2],
+               (unsigned long long)pc.acc[3], (unsigned long long)pc.acc[4], (unsigned long long)pc.acc[5]);
+    if (lane == 0 && blockIdx.x == 0 && wave == 0) printf("  issue %llu eyt %llu\n", (unsigned long long)pc.acc[6], (unsigned long long)pc.acc[7]);
+#endif
 }
 
 // ---- K2: the indel groups' forests over the raw-code records ---------------------------------------------
