@@ -175,10 +175,24 @@ __global__ __launch_bounds__(256) void bracket5_kernel(const V5Args v) {
         const TrackView& tv = table_view(f, t);
         out = lb_two_level_g<int32_t>(tv.starts, tv.coarse, tv.ptr[c], tv.ptr[c + 1], pos);
     }
-    if (is_indel) v.br_indel[tile * 16 + (last ? 8 : 0) + t] = out;
-    else {
+    if (is_indel) {
+        // indel tile record (kRecI5 ints): [t] / [8 + t] lower bounds of the first / last variant per table,
+        // [16 + 2t], [17 + 2t] the contig's row range, [28] contig (bit 31: the tile spans contigs)
+        int32_t* rec = v.br_indel + tile * kRecI5;
+        rec[(last ? 8 : 0) + t] = out;
+        if (!last && t != kJoin5 - 1) {
+            const TrackView& tv = table_view(f, t);
+            rec[16 + 2 * t] = tv.ptr[c];
+            rec[17 + 2 * t] = tv.ptr[c + 1];
+        }
+        if (!last && k == 0) {
+            const int n = (int)v.tile_n[(size_t)v.max_tiles + tile];
+            const int c_last = f.contig[list[tile * 64 + (n > 0 ? n - 1 : 0)]];
+            rec[28] = c | (c_last != c ? INT32_MIN : 0);
+        }
+    } else {
         // SNP tile record (kRecS5 ints): [t] lower bound per table, [7] contig of the tile (bit 31: the tile spans
-        // contigs), [8 + 2t], [9 + 2t] the contig's row range of table t - everything the fused kernel needs to fetch
+        // contigs), [8 + 2t], [9 + 2t] the contig's row range of table t, [20..23] its span of the reference - everything the fused kernel needs to fetch
         // the tile's slices BEFORE it has seen the tile's columns
         int32_t* rec = v.br_snp + tile * kRecS5;
         if (n_act > 0) rec[t] = out;
@@ -191,9 +205,20 @@ __global__ __launch_bounds__(256) void bracket5_kernel(const V5Args v) {
             const int n = (int)v.tile_n[tile];
             const int c_last = f.contig[list[tile * 64 + (n > 0 ? n - 1 : 0)]];
             rec[7] = c | (c_last != c ? INT32_MIN : 0);
+            const int64_t clo = f.contig_off[c], chi = f.contig_off[c + 1];      // [20..23]: the contig's span of the reference
+            rec[20] = (int32_t)(uint32_t)clo; rec[21] = (int32_t)(clo >> 32);
+            rec[22] = (int32_t)(uint32_t)chi; rec[23] = (int32_t)(chi >> 32);
         }
     }
 }
+
+#ifdef UGVC_PHASE_CLOCK
+struct PhaseClk { uint64_t last; uint64_t acc[8]; };
+#define CLK(pc, k) do { const uint64_t now_ = __builtin_readcyclecounter(); (pc).acc[k] += now_ - (pc).last; (pc).last = now_; } while (0)
+#else
+struct PhaseClk {};
+#define CLK(pc, k) do { } while (0)
+#endif
 
 // ---- joins ---------------------------------------------------------------------------------------
 struct JoinOut {
@@ -249,58 +274,85 @@ __device__ __forceinline__ void join_one_global(const FilterArgs* ap, int t, int
     *op = o;
 }
 
-// Bracketed searches of an indel tile on the resident tables themselves, all tables in lock-step (rows
-// [lo, hi) of every table, wave-uniform).
-template <int NTRK>
-__device__ __forceinline__ void join_bracketed(const FilterArgs& a, const int (&lo)[kJoin5], const int (&hi)[kJoin5],
-                                               const int (&plo)[kJoin5 - 1], const int (&phi)[kJoin5 - 1], int pos, uint64_t key, JoinOut& o) {
-    constexpr int NT = 1 + NTRK;
-    int base[NT], len[NT];
-    int bbase = lo[kJoin5 - 1], blen = a.n_bl > 0 ? hi[kJoin5 - 1] - lo[kJoin5 - 1] : 0;
+// Indel tiles cover ~5x the span of an SNP tile, so their slices are staged per table: rows [lo - 2, hi + 2) between
+// the lower bounds of the tile's first and last variant (K0's record) - at most kIndelRows - in registers first
+// (fetched from the record alone, under the column / window chain of the tile), then into the wave's scratch two
+// tables at a time once the window rows are dead.  A bracket wider than that is searched in HBM (join_one_global).
+// (Measured and dropped: the same searches as dependent gathers on the resident tables - binary: nine round trips per
+// tile; 8-ary: three, but 105 scattered 64-lane gathers instead of 45, no faster.)
+constexpr int kIndelRows = 128;                     // staged rows per table (two per lane); 127 searchable + sentinel
+constexpr uint32_t kIndelSlotB = kIndelRows * 8;    // starts | ends, or 128 blacklist keys
+
+template <int NT>
+struct IndelPre {
+    int sv[NT][2], ev[NT][2];
+    uint64_t bl[2];
+};
+
+// rank of `pos` among the 127 searchable staged starts at A (ascending, sentinel padded): seven branch-free steps
+__device__ __forceinline__ uint32_t staged_rank(uint32_t A, int pos) {
+    uint32_t p = A - 4u;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        base[t] = lo[t];
-        len[t] = (t > 0 || a.has_runs) ? hi[t] - lo[t] : 0;
+    for (int sb = 256; sb >= 4; sb >>= 1) {
+        const uint32_t cand = p + (uint32_t)sb;
+        p = lds_i32(cand) < pos ? cand : p;
     }
-    for (;;) {
-        int x[NT];
-        uint64_t xk = 0;
-        bool more = false;
+    return (p + 4u - A) >> 2;
+}
+
+__device__ __forceinline__ void stage_rows(uint32_t slot_b, int L0, int plo, int phi, const int (&sv)[2], const int (&ev)[2], int lane) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            x[t] = 0;
-            if (len[t] > 0) x[t] = table_view(a, t).starts[base[t] + (len[t] >> 1)];
-        }
-        if (blen > 0) xk = a.bl[bbase + (blen >> 1)];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (len[t] > 0) {
-                const int half = len[t] >> 1;
-                const bool lt = x[t] < pos;
-                base[t] = lt ? base[t] + half + 1 : base[t];
-                len[t] = lt ? len[t] - half - 1 : half;
-                more |= len[t] > 0;
-            }
-        }
-        if (blen > 0) {
-            const int half = blen >> 1;
-            const bool lt = xk < key;
-            bbase = lt ? bbase + half + 1 : bbase;
-            blen = lt ? blen - half - 1 : half;
-            more |= blen > 0;
-        }
-        if (__ballot(more) == 0) break;
+    for (int h = 0; h < 2; ++h) {
+        const int gi = L0 + 64 * h + lane;
+        lds_st32(slot_b + 256u * h + 4u * lane, gi < plo ? INT32_MIN : (gi >= phi ? INT32_MAX : sv[h]));
+        lds_st32(slot_b + 512u + 256u * h + 4u * lane, ev[h]);
     }
+}
+
+__device__ __forceinline__ void staged_verdict(const FilterArgs& a, uint32_t slot_b, int t, int L0, int plo, int phi, int pos, JoinOut& o) {
+    if (phi <= plo) return;
+    const int sg = L0 + (int)staged_rank(slot_b, pos);
+    auto S = [&](int gi) { return lds_i32(slot_b + 4u * (uint32_t)(gi - L0)); };
+    auto E = [&](int gi) { return lds_i32(slot_b + 512u + 4u * (uint32_t)(gi - L0)); };
+    interval_verdict(t, sg, plo, phi, pos, a.hpol_dist, S, E, o);
+}
+
+// A table too dense for the two-rows-per-lane slice (a 3 M-interval track under a 220 kb indel tile: ~210 rows):
+// six rows per lane, the whole scratch, a round of its own; the descent clamps its probes to the last staged row
+// (rows past the searched range compare like the padding would).
+constexpr int kWideChunks = 6, kWideRows = 64 * kWideChunks;          // 384 rows: starts | ends = 3072 B
+
+__device__ __forceinline__ void wide_load(const TrackView& tv, int L0, int top, int lane, int (&wv)[kWideChunks], int (&we)[kWideChunks]) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        if ((t == 0 && !a.has_runs) || phi[t] <= plo[t]) continue;
-        const TrackView& tv = table_view(a, t);
-        const int top = phi[t] - 1, bot = plo[t];
-        auto S = [&](int i) { return tv.starts[i < bot ? bot : (i > top ? top : i)]; };
-        auto E = [&](int i) { return tv.ends[i < bot ? bot : (i > top ? top : i)]; };
-        interval_verdict(t, base[t], plo[t], phi[t], pos, a.hpol_dist, S, E, o);
+    for (int h = 0; h < kWideChunks; ++h) {
+        const uint32_t gs = (uint32_t)max(min(L0 + 64 * h + lane, top), 0);
+        wv[h] = tv.starts[gs]; we[h] = tv.ends[gs];
     }
-    if (a.n_bl > 0 && bbase < (int)a.n_bl && a.bl[bbase] == key) o.cohort = true;
+}
+
+__device__ __forceinline__ void wide_verdict(const FilterArgs& a, uint32_t A, int t, int L0, int plo, int phi, int pos, int lane,
+                                             const int (&wv)[kWideChunks], const int (&we)[kWideChunks], JoinOut& o) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int h = 0; h < kWideChunks; ++h) {
+        const int gi = L0 + 64 * h + lane;
+        lds_st32(A + 256u * h + 4u * lane, gi < plo ? INT32_MIN : (gi >= phi ? INT32_MAX : wv[h]));
+        lds_st32(A + 4u * kWideRows + 256u * h + 4u * lane, we[h]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (phi <= plo) return;
+    uint32_t p = A - 4u;
+    const uint32_t last = A + 4u * (kWideRows - 1);
+#pragma unroll
+    for (int sb = 1024; sb >= 4; sb >>= 1) {
+        const uint32_t cand = min(p + (uint32_t)sb, last);
+        p = lds_i32(cand) < pos ? cand : p;
+    }
+    const int sg = L0 + (int)((p + 4u - A) >> 2);
+    auto S = [&](int gi) { return lds_i32(A + 4u * (uint32_t)(gi - L0)); };
+    auto E = [&](int gi) { return lds_i32(A + 4u * kWideRows + 4u * (uint32_t)(gi - L0)); };
+    interval_verdict(t, sg, plo, phi, pos, a.hpol_dist, S, E, o);
 }
 
 __device__ __forceinline__ uint32_t raw_code(int x, int cap) {          // x < 0 ? 0 : min(x, cap) + 1
@@ -317,6 +369,7 @@ struct Scratch {                    // LDS byte addresses
     uint32_t thr_b;                 // the indel groups' sorted threshold slices (skewed)
     uint32_t gcr_b;                 // gc rank codes [group][len * 11 + count], u16
     uint32_t css_b;
+    uint32_t gtab_b;                // indel groups: clamps and float-slice descriptors
 };
 
 // Indel tiles: lock-step descents of qual / sor / vaf over the lane's group's sorted threshold slices (slice of
@@ -368,14 +421,6 @@ __device__ __forceinline__ void rank3_eyt(const float (&fx)[3], const uint32_t (
 #pragma unroll
     for (int e = 0; e < 3; ++e) cd[e] = fx[e] != fx[e] ? len[e] : i[e] - (1u << bits[e]);
 }
-
-#ifdef UGVC_PHASE_CLOCK
-struct PhaseClk { uint64_t last; uint64_t acc[8]; };
-#define CLK(pc, k) do { const uint64_t now_ = __builtin_readcyclecounter(); (pc).acc[k] += now_ - (pc).last; (pc).last = now_; } while (0)
-#else
-struct PhaseClk {};
-#define CLK(pc, k) do { } while (0)
-#endif
 
 struct SnpCols {                    // the columns of one substitution (fetched one tile ahead of their use)
     int c, pos, rl;
@@ -440,7 +485,10 @@ __device__ __forceinline__ void featurize_snp_tile(const V5Args& v, const Scratc
     const int c0 = rfl(c);
     const bool uni = __builtin_amdgcn_readlane((int)rec, 7) >= 0;   // one contig (all but a handful of tiles): from K0's record
     int64_t clo, chi;
-    if (uni) { clo = cload(a.contig_off + c0); chi = cload(a.contig_off + c0 + 1); }   // scalar loads: no round trip in front of the window
+    if (uni) {                                                  // from the record: no round trip in front of the window
+        clo = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)rec, 21) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)rec, 20));
+        chi = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)rec, 23) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)rec, 22));
+    }
     else { clo = a.contig_off[c]; chi = a.contig_off[c + 1]; }
     const uint32_t clen = (uint32_t)(chi - clo);
     const uint32_t p0 = (uint32_t)(pos - 1);
@@ -659,12 +707,47 @@ __device__ __forceinline__ void featurize_snp_tile(const V5Args& v, const Scratc
 
 // ---- indel tile: features of 64 length-changing variants -> raw-code records of groups 1 / 2 -------------
 template <int NTRK>
-__device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scratch& sc, int64_t tile, int lane, uint32_t i, bool live) {
+__device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scratch& sc, int64_t tile, int lane, uint32_t i, bool live, PhaseClk& pc) {
     constexpr int NT = 1 + NTRK;
     const FilterArgs& a = v.f;
     const uint8_t* __restrict__ apool = a.alleles;
+    // ---- the tile's record and its table slices (independent of the columns: issued first)
+    const bool joins_on = !(a.ablate & 524288);
+    const int32_t* trec = v.br_indel + tile * kRecI5;
+    const bool uni = cload(trec + 28) >= 0;
+    int lo_[kJoin5], hi_[kJoin5], pl[NT], ph[NT];
+    IndelPre<NT> pre;
+    if (uni && joins_on) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            lo_[t] = hi_[t] = pl[t] = ph[t] = 0;
+            pre.sv[t][0] = pre.sv[t][1] = pre.ev[t][0] = pre.ev[t][1] = 0;
+            if (t == 0 && !a.has_runs) continue;
+            const TrackView& tv = table_view(a, t);
+            lo_[t] = cload(trec + t); hi_[t] = cload(trec + 8 + t);
+            pl[t] = cload(trec + 16 + 2 * t); ph[t] = cload(trec + 17 + 2 * t);
+            const int top = max(v.na[t] - 1, 0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t gs = (uint32_t)max(min(lo_[t] - 2 + 64 * h + lane, top), 0);
+                pre.sv[t][h] = tv.starts[gs]; pre.ev[t][h] = tv.ends[gs];
+            }
+        }
+        lo_[kJoin5 - 1] = cload(trec + kJoin5 - 1); hi_[kJoin5 - 1] = cload(trec + 8 + kJoin5 - 1);
+        pre.bl[0] = pre.bl[1] = ~0ull;
+        if (a.n_bl > 0) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int64_t gi = (int64_t)lo_[kJoin5 - 1] + 64 * h + lane;
+                if (gi < a.n_bl) pre.bl[h] = a.bl[gi];
+            }
+        }
+    }
     const int c = a.contig[i], pos = a.pos[i], rl = a.ref_len[i], al = a.alt_len[i];
     const uint32_t ro = a.ref_off[i], ao = a.alt_off[i];
+    // the model's own columns: needed last, issued first (every round trip of this tile is a dependent one)
+    const float qual = a.qual[i], sor = a.sor[i];
+    const int dp = a.dp[i], adr = a.ad_ref[i], ada = a.ad_alt[i], gq = a.gq[i];
     const bool ins = rl < al;
     const int classify = ins ? 1 : 2;
     const int indel_length = ins ? al - rl : rl - al;
@@ -705,6 +788,7 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
     for (int q = 2; q < 8; ++q) ab[q] = apool[lo_off + (q + 1 < ln ? q + 1 : ln - 1)];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    CLK(pc, 0);
     auto wb = [&](int o) -> int { return (int)lds_u8(wrow_b + (uint32_t)o); };
     auto ref_at = [&](int d) -> int {                         // reference base at contig offset p0 + d (0 outside the contig)
         const int o = o0 + d;
@@ -749,6 +833,21 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
     }
     const bool is_h = hmer_len > 0;
     const int group = is_h ? 1 : 2;
+    const bool pg_ok = group == 1 ? v.pg[1].ok != 0 : v.pg[2].ok != 0;
+    if (live && !pg_ok) {                                      // no model for this variant type: score 0, PASS
+        a.score[i] = 0.f;
+        a.filter[i] = UGVC_FILTER_PASS;
+    }
+    // ---- record slots: one returning atomic per wave and group (issued here: its round trip runs under the joins)
+    const bool mine = live && pg_ok;
+    const unsigned long long m1 = __ballot(mine && group == 1), m2 = __ballot(mine && group == 2);
+    const int shard = (int)(tile & (kShards - 1));
+    unsigned got = 0;
+    if (lane == 1 && m1 != 0) got = atomicAdd(&v.counters[(1 * kShards + shard) * kCounterStride], (unsigned)__popcll(m1));
+    if (lane == 2 && m2 != 0) got = atomicAdd(&v.counters[(2 * kShards + shard) * kCounterStride], (unsigned)__popcll(m2));
+    const unsigned long long below = (1ull << lane) - 1;
+    const unsigned grank = (unsigned)__popcll((group == 1 ? m1 : m2) & below);
+
     // ---- get_motif_around (5), gc_content (10)
     int W[11];
 #pragma unroll
@@ -776,34 +875,76 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
     }
     const uint32_t gc_idx = (uint32_t)(gc_len * 11 + gc_cnt);
 
-    // ---- joins on the resident tables, inside the tile's brackets
-    const int c0 = rfl(c);
-    const bool uni = __ballot(c != c0) == 0;
+    CLK(pc, 1);
+    // ---- joins: the staged slices, two tables at a time in the scratch the window rows have left
     const uint64_t key = ((uint64_t)(uint32_t)c << 32) | (uint32_t)pos;
     JoinOut jo{false, false, false, 0u};
-    if (a.ablate & 524288) {
+    if (!joins_on) {
     } else if (uni) {
-        int lo_[kJoin5], hi_[kJoin5], pl[kJoin5 - 1], ph[kJoin5 - 1];
+        const uint32_t s0 = sc.base, s1 = sc.base + kIndelSlotB;
+        auto fits = [&](int t) { return hi_[t] - lo_[t] + 4 <= kIndelRows - 1; };
+        auto wide = [&](int t) { return !fits(t) && hi_[t] - lo_[t] + 4 <= kWideRows - 1; };
+        // the first table that needs the wide slice: its rows are requested now and arrive under the narrow rounds
+        int tw = -1;
+        int wv[kWideChunks], we[kWideChunks];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if (tw < 0 && !(t == 0 && !a.has_runs) && wide(t)) {
+                tw = t;
+                wide_load(table_view(a, t), lo_[t] - 2, max(v.na[t] - 1, 0), lane, wv, we);
+            }
+        // round A: runs | blacklist
+        const bool runs_on = a.has_runs != 0, bl_on = a.n_bl > 0;
+        const bool bl_fit = hi_[kJoin5 - 1] - lo_[kJoin5 - 1] + 1 <= kIndelRows - 1;
+        __builtin_amdgcn_wave_barrier();
+        if (runs_on && fits(0)) stage_rows(s0, lo_[0] - 2, pl[0], ph[0], pre.sv[0], pre.ev[0], lane);
+        if (bl_on && bl_fit) {
+            lds_st64(s1 + 8u * lane, pre.bl[0]);
+            lds_st64(s1 + 512u + 8u * lane, pre.bl[1]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (runs_on) {
+            if (fits(0)) staged_verdict(a, s0, 0, lo_[0] - 2, pl[0], ph[0], pos, jo);
+        }
+        if (bl_on) {
+            if (bl_fit) {
+                uint32_t pb = s1 - 8u;
+#pragma unroll
+                for (int sb = 512; sb >= 8; sb >>= 1) {
+                    const uint32_t cand = pb + (uint32_t)sb;
+                    pb = lds_u64(cand) < key ? cand : pb;
+                }
+                if (lds_u64(pb + 8u) == key) jo.cohort = true;
+            } else join_one_global(&a, kJoin5 - 1, lo_[kJoin5 - 1], hi_[kJoin5 - 1], 0, 0, pos, key, &jo);
+        }
+        // tracks, in pairs
+#pragma unroll
+        for (int t = 1; t < NT; t += 2) {
+            __builtin_amdgcn_wave_barrier();
+            if (fits(t)) stage_rows(s0, lo_[t] - 2, pl[t], ph[t], pre.sv[t], pre.ev[t], lane);
+            if (t + 1 < NT && fits(t + 1)) stage_rows(s1, lo_[t + 1] - 2, pl[t + 1], ph[t + 1], pre.sv[t + 1 < NT ? t + 1 : t], pre.ev[t + 1 < NT ? t + 1 : t], lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (fits(t)) staged_verdict(a, s0, t, lo_[t] - 2, pl[t], ph[t], pos, jo);
+            if (t + 1 < NT && fits(t + 1)) staged_verdict(a, s1, t + 1, lo_[t + 1] - 2, pl[t + 1 < NT ? t + 1 : t], ph[t + 1 < NT ? t + 1 : t], pos, jo);
+        }
+        // the tables the narrow slices could not hold
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            pl[t] = ph[t] = lo_[t] = hi_[t] = 0;
-            if (t == 0 && !a.has_runs) continue;
-            const TrackView& tv = table_view(a, t);
-            pl[t] = cload(tv.ptr + c0);
-            ph[t] = cload(tv.ptr + c0 + 1);
-            lo_[t] = cload(v.br_indel + tile * 16 + t);
-            hi_[t] = cload(v.br_indel + tile * 16 + 8 + t);
+            if ((t == 0 && !a.has_runs) || fits(t)) continue;
+            if (wide(t)) {
+                if (t != tw) wide_load(table_view(a, t), lo_[t] - 2, max(v.na[t] - 1, 0), lane, wv, we);
+                wide_verdict(a, s0, t, lo_[t] - 2, pl[t], ph[t], pos, lane, wv, we, jo);
+            } else join_one_global(&a, t, lo_[t], hi_[t], pl[t], ph[t], pos, key, &jo);
         }
-        lo_[kJoin5 - 1] = cload(v.br_indel + tile * 16 + kJoin5 - 1);
-        hi_[kJoin5 - 1] = cload(v.br_indel + tile * 16 + 8 + kJoin5 - 1);
-        join_bracketed<NTRK>(a, lo_, hi_, pl, ph, pos, key, jo);
     } else {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             if (t == 0 && !a.has_runs) continue;
             const TrackView& tv = table_view(a, t);
-            const int pl = tv.ptr[c], ph = tv.ptr[c + 1];
-            join_one_global(&a, t, pl, ph, pl, ph, pos, key, &jo);
+            const int pl_ = tv.ptr[c], ph_ = tv.ptr[c + 1];
+            join_one_global(&a, t, pl_, ph_, pl_, ph_, pos, key, &jo);
         }
         if (a.n_bl > 0) join_one_global(&a, kJoin5 - 1, 0, (int)a.n_bl, 0, 0, pos, key, &jo);
     }
@@ -811,41 +952,26 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
     if (jo.cohort) flags |= UGVC_FLAG_COHORT_FP;
     if (a.mark_hpol && (jo.inside_run || jo.close_run)) flags |= UGVC_FLAG_HPOL_RUN;
     if (live) a.flags[i] = flags;
-    const bool pg_ok = group == 1 ? v.pg[1].ok != 0 : v.pg[2].ok != 0;
-    if (live && !pg_ok) {                                      // no model for this variant type: score 0, PASS
-        a.score[i] = 0.f;
-        a.filter[i] = UGVC_FILTER_PASS;
-    }
-    // ---- record slots: one returning atomic per wave and group
-    const bool mine = live && pg_ok;
-    const unsigned long long m1 = __ballot(mine && group == 1), m2 = __ballot(mine && group == 2);
-    const int shard = (int)(tile & (kShards - 1));
-    unsigned got = 0;
-    if (lane == 1 && m1 != 0) got = atomicAdd(&v.counters[(1 * kShards + shard) * kCounterStride], (unsigned)__popcll(m1));
-    if (lane == 2 && m2 != 0) got = atomicAdd(&v.counters[(2 * kShards + shard) * kCounterStride], (unsigned)__popcll(m2));
-    const unsigned long long below = (1ull << lane) - 1;
-    const unsigned grank = (unsigned)__popcll((group == 1 ? m1 : m2) & below);
-
+    CLK(pc, 2);
     // ---- codes of the lane's own group
-    const float qual = a.qual[i], sor = a.sor[i];
-    const int dp = a.dp[i], adr = a.ad_ref[i], ada = a.ad_alt[i], gq = a.gq[i];
     const float vaf = dp > 0 ? __fdiv_rn((float)ada, (float)dp) : 0.0f;
     uint32_t cd[4] = {0, 0, 0, 0};
     if (__ballot(mine) != 0) {
         const float fx[3] = {qual, sor, vaf};
-        const int fj[3] = {0, 1, 5};
         uint32_t off3[3], len3[3], c3[3];
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-            const uint2 d1 = cload2(v.desc3 + 1 * kMaxFeatures + fj[s]), d2 = cload2(v.desc3 + 2 * kMaxFeatures + fj[s]);
-            off3[s] = ((group == 1 ? d1.x : d2.x) & 0xFFFFFu) - (uint32_t)v.thr0_len;       // the staged table starts at group 1
-            len3[s] = (group == 1 ? d1.y : d2.y) & 0xFFFFu;
+            const uint2 d = lds_u32x2(sc.gtab_b + 64u + (uint32_t)(group - 1) * 24u + 8u * s);
+            off3[s] = d.x;
+            len3[s] = d.y;
         }
         rank3_sorted(fx, sc.thr_b, off3, len3, v.thr_bits, c3);
         cd[0] = c3[0]; cd[1] = c3[1]; cd[2] = c3[2];
         cd[3] = lds_u16(sc.gcr_b + 2u * ((uint32_t)group * kGcRank + gc_idx));
     }
-    auto rc = [&](int f, int x) -> uint32_t { return raw_code(x, group == 1 ? v.cap5[1][f] : v.cap5[2][f]); };
+    CLK(pc, 6);
+    const uint32_t gcap_b = sc.gtab_b + (uint32_t)(group - 1) * 32u;
+    auto rc = [&](int f, int x) -> uint32_t { return raw_code(x, (int)lds_u16(gcap_b + 2u * f)); };
     uint32_t r[kRec5Dwords];
     r[0] = cd[0] | (cd[1] << 16);                                        // qual, sor
     r[1] = rc(2, dp) | (rc(3, adr) << 16);
@@ -866,6 +992,7 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
         dst[1] = make_uint4(r[4], r[5], r[6], r[7]);
         dst[2] = make_uint4(r[8], r[9], r[10], r[11]);
     }
+    CLK(pc, 3);
 }
 
 // ---- single-sum walk of one forest over the wave's code planes -> (tree_score, FILTER) -------------------
@@ -923,7 +1050,7 @@ __device__ __forceinline__ void walk_forest(const PackedGroupView& pg, uint32_t 
 // LDS of a workgroup: group forest (hi | last | p1, 16-byte padded) | group 0's level-order threshold trees | the
 // indel groups' sorted thresholds (skewed) | gc rank codes | css | wave scratch
 struct Lds5 {
-    uint32_t hi_b, last_b, p1_b, eyt_b, thr_b, gcr_b, css_b, scratch_b;
+    uint32_t hi_b, last_b, p1_b, eyt_b, thr_b, gcr_b, css_b, gtab_b, scratch_b;
 };
 
 __device__ __forceinline__ Lds5 lds5_fill(unsigned char* smem, const V5Args& v, bool with_forest, int tid, int nthreads) {
@@ -977,6 +1104,19 @@ __device__ __forceinline__ Lds5 lds5_fill(unsigned char* smem, const V5Args& v, 
     for (int q = tid; q < 256; q += nthreads) css[q] = v.css_lut[q];
     L.css_b = lds_addr(css);
     off += 256;
+    // per indel group: the clamps of the integer features (u16 [2][16]) and the (offset, length) of the three float
+    // features' threshold slices in the staged table - read per lane by its group instead of scalar loads + selects
+    unsigned char* gtab = smem + off;
+    if (tid < 32) reinterpret_cast<uint16_t*>(gtab)[tid] = (uint16_t)v.cap5[1 + (tid >> 4)][tid & 15];
+    if (tid >= 64 && tid < 70) {
+        const int q = tid - 64, g = 1 + q / 3, sfeat = q % 3;
+        const int fj = sfeat == 0 ? 0 : (sfeat == 1 ? 1 : 5);
+        const uint2 d = v.desc3[g * kMaxFeatures + fj];
+        reinterpret_cast<uint32_t*>(gtab + 64)[2 * q] = (d.x & 0xFFFFFu) - (uint32_t)v.thr0_len;      // the staged table starts at group 1
+        reinterpret_cast<uint32_t*>(gtab + 64)[2 * q + 1] = d.y & 0xFFFFu;
+    }
+    L.gtab_b = lds_addr(gtab);
+    off += kGtabBytes;
     L.scratch_b = lds_addr(smem + off);
     return L;
 }
@@ -990,7 +1130,7 @@ static size_t lds5_bytes(const V5Args& v, int n_waves) {
     b += (size_t)v.eyt_len * 4;
     const int n_thr = v.thr_lds_len - v.thr0_len;
     b += ((size_t)(n_thr + (n_thr >> 5) + 1) * 4 + 15) & ~(size_t)15;
-    b += kGcRankBytes + 256;
+    b += kGcRankBytes + 256 + kGtabBytes;
     const int n_iw = std::min(v.n_indel_waves, n_waves - 1);
     return b + (size_t)(n_waves - n_iw) * v.scratch_bytes + (size_t)n_iw * v.scratch_indel;
 }
@@ -1017,7 +1157,7 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
     const Lds5 L = lds5_fill(smem, v, has0, tid, blockDim.x);
     __syncthreads();
     Scratch sc;
-    sc.eyt_b = L.eyt_b; sc.thr_b = L.thr_b; sc.gcr_b = L.gcr_b; sc.css_b = L.css_b;
+    sc.eyt_b = L.eyt_b; sc.thr_b = L.thr_b; sc.gcr_b = L.gcr_b; sc.css_b = L.css_b; sc.gtab_b = L.gtab_b;
     const int hslot = ((lane & 31) << 1) | (lane >> 5);
     // inclusive scans of the shard counters of both classes
     unsigned incl_s = v.tile_cnt[lane * kTileCntStride5], incl_i = v.tile_cnt[(kTileShards5 + lane) * kTileCntStride5];
@@ -1048,14 +1188,29 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
     if (wave >= n_sw) {
         if (prio) __builtin_amdgcn_s_setprio(2);
         const int64_t stride = (int64_t)gridDim.x * n_iw;
+        PhaseClk pc{};
+#ifdef UGVC_PHASE_CLOCK
+        pc.last = __builtin_readcyclecounter();
+        const uint64_t t_begin = pc.last;
+        int n_done = 0;
+#endif
         for (int64_t ti = (int64_t)(wave - n_sw) * gridDim.x + blockIdx.x; ti < ni; ti += stride) {
             const int64_t tile = tile_of(ti, incl_i, v.shard_tiles);
             const uint32_t id = v.indel_idx[tile * 64 + lane];
             const bool live = id != ~0u;
             const uint32_t id0 = (uint32_t)rfl((int)id);       // (outside the select: a ternary would read the first PADDING lane)
-            featurize_indel_tile<NTRK>(v, sc, tile, lane, live ? id : id0, live);
+            featurize_indel_tile<NTRK>(v, sc, tile, lane, live ? id : id0, live, pc);
             __builtin_amdgcn_wave_barrier();
+#ifdef UGVC_PHASE_CLOCK
+            ++n_done;
+#endif
         }
+#ifdef UGVC_PHASE_CLOCK
+        if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 133) && wave == n_waves - 1)
+            printf("iclk b%d w%d tiles %d total %llu | load+window %llu hmer+motif %llu joins %llu codes+record %llu (ranks %llu)\n", (int)blockIdx.x, wave, n_done,
+                   (unsigned long long)(pc.last - t_begin), (unsigned long long)pc.acc[0], (unsigned long long)pc.acc[1], (unsigned long long)pc.acc[2],
+                   (unsigned long long)pc.acc[3], (unsigned long long)pc.acc[6]);
+#endif
         return;
     }
     const int64_t stride = (int64_t)gridDim.x * n_sw;
@@ -1313,6 +1468,7 @@ int launch_filter_v5(ugvc_ctx* ctx, const FilterArgs& a) {
     hipLaunchKernelGGL(bracket5_kernel, dim3((unsigned)((nbr + 255) / 256)), dim3(256), 0, ctx->stream, v);
     if (step("bracket5")) return -1;
     const size_t lds_f = lds5_bytes(v, v.n_waves);
+    if (dbg) fprintf(stderr, "[ugvc v5] fused5: %d waves (%d indel), %zu B of LDS\n", v.n_waves, v.n_indel_waves, lds_f);
     hipLaunchKernelGGL(fused5_for(a.n_tracks, (a.ablate & (1 << 28)) != 0), dim3((unsigned)ctx->n_cus), dim3(v.n_waves * 64), lds_f, ctx->stream, v);
     if (step("fused5")) return -1;
     if (!(a.ablate & 262144) && (v.pg[1].ok || v.pg[2].ok)) {

@@ -667,7 +667,7 @@ int v5_fill_args(ugvc_ctx* ctx, V5Args& v, const FilterArgs& a) {
     v.shard_cap5 = ((v.max_tiles + kShards - 1) / kShards) * kTile5;
     if (ensure(s->snp_idx, (size_t)v.max_tiles * kTile5 * 4) || ensure(s->indel_idx, (size_t)v.max_tiles * kTile5 * 4)) return -1;
     if (ensure(s->tile_cnt, (size_t)2 * kTileShards5 * kTileCntStride5 * 4) || ensure(s->tile_n, (size_t)v.max_tiles * 2 + 64)) return -1;
-    if (ensure(s->br_snp, (size_t)v.max_tiles * kRecS5 * 4) || ensure(s->br_indel, (size_t)v.max_tiles * 16 * 4)) return -1;
+    if (ensure(s->br_snp, (size_t)v.max_tiles * kRecS5 * 4) || ensure(s->br_indel, (size_t)v.max_tiles * kRecI5 * 4)) return -1;
     if (ensure(s->counters, (size_t)UGVC_N_GROUPS * kShards * kCounterStride * 4)) return -1;
     v.snp_idx = s->snp_idx.as<uint32_t>();
     v.indel_idx = s->indel_idx.as<uint32_t>();

@@ -94,6 +94,8 @@ constexpr int kCBlock5 = 1024;                // variants per compaction workgro
 constexpr int kJoin5 = UGVC_MAX_TRACKS + 2;   // runs, tracks, blacklist
 constexpr int kTileShards5 = 64;              // tile-slot counters per variant class (one atomic per compaction block)
 constexpr int kTileCntStride5 = 16;           // dwords between counters (64 bytes)
+constexpr int kGtabBytes = 128;               // LDS: per indel group clamps + float slice descriptors
+constexpr int kRecI5 = 32;                   // ints per indel-tile record of K0
 constexpr int kRecS5 = 32;                   // ints per SNP-tile record of K0 (lower bounds, contig, row ranges)
 constexpr int kBlCap5 = 64;                   // staged blacklist keys per SNP tile
 
@@ -116,7 +118,7 @@ struct V5Args {
     int shard_tiles;                     // tile slots per shard: tile id = shard * shard_tiles + slot
     uint8_t* tile_n;                     // real entries per tile: [0, max_tiles) SNP, [max_tiles, 2 max_tiles) indel
     int32_t* br_snp;                     // [max_tiles][kRecS5]  SNP-tile records: lower bounds of the first variant, contig, row ranges
-    int32_t* br_indel;                   // [max_tiles][16] + lower bounds of its last variant
+    int32_t* br_indel;                   // [max_tiles][kRecI5] indel-tile records: bounds of the first and the last variant, row ranges, contig
     uint4* rec5[UGVC_N_GROUPS];
     uint32_t* counters;                  // [UGVC_N_GROUPS][kShards] x kCounterStride
     int shard_cap5;
