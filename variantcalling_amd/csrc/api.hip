@@ -420,7 +420,9 @@ int ugvc_variants_upload(ugvc_ctx* ctx, const ugvc_variants* v) {
     UGVC_HIP(hipSetDevice(ctx->device));
     const size_t n = (size_t)v->n;
     // host-side validation the kernel relies on (sortedness, contig range, allele bounds)
+    int64_t n_indel = 0;                                       // (sizes the indel tiles' table slices: model_pack.hip)
     for (size_t i = 0; i < n; ++i) {
+        n_indel += v->ref_len[i] != v->alt_len[i] ? 1 : 0;
         if (v->contig[i] >= ctx->n_contigs) return fail("contig index out of range at row " + std::to_string(i));
         if (v->ref_len[i] == 0 || v->alt_len[i] == 0) return fail("empty allele at row " + std::to_string(i));
         if ((int64_t)v->ref_off[i] + v->ref_len[i] > v->alleles_len ||
@@ -450,6 +452,7 @@ int ugvc_variants_upload(ugvc_ctx* ctx, const ugvc_variants* v) {
     if (ensure(ctx->r_score, n * 4) || ensure(ctx->r_filter, n) || ensure(ctx->r_flags, n)) return -1;
     UGVC_HIP(hipStreamSynchronize(ctx->stream));
     ctx->n = v->n;
+    ctx->n_indel = n_indel;
     ctx->scored = 0;
     return 0;
 }

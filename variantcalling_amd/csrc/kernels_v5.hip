@@ -1,28 +1,31 @@
-// v5 scoring pass (gfx950): featurize -> lookup -> score -> FILTER as four launches.
+// v5 scoring pass (gfx950): featurize -> lookup -> score -> FILTER as two launches.
 //
 // What v3 measured (profiles/r01_*): its featurize kernel (K1, 378 us per 5 M variants) waits on a chain of
 // dependent memory round trips per 256-variant tile at 4 waves/SIMD, with the vector ALU mostly idle; its forest
 // kernel (K2, 321 us) is bound by the LDS pipeline and runs AFTER K1; the two exchange a 16-byte record per
 // variant through HBM (160 MB per pass) and K2 stores its results scattered.  v5 puts both on the same waves:
 //
-//   compact5_kernel   every 1024-variant block splits its rows by variant class (ref_len == alt_len: the SNP
-//                     forest; else an indel) into tiles of 64 row indices; a tile is one wave's work and is pure
-//                     in class, so every lane of a wave walks the SAME forest (no lane is idle in a walk).  Tile
-//                     slots come from 64 sharded counters (one atomic per block and class).
-//   bracket5_kernel   per tile, the lower bound of its first (indel tiles: and last) variant in every searched
-//                     side table (two-level search, L2-resident 1/64 sample first).
-//   fused5_kernel     one 16-wave workgroup per CU holds the SNP forest in LDS (rank-coded complete trees,
-//                     single-sum layout) and the float thresholds.  A wave is autonomous - no workgroup barrier
-//                     after the prologue: it loads its tile's columns, an 11-base reference window per lane (one
-//                     16-byte load, realigned with v_alignbyte), stages the side-table slices its tile can touch
-//                     in wave-private LDS (sentinel padded: the lock-step descents carry no bounds test and no
-//                     branch), derives the features, writes 16-bit codes straight into its code planes and walks
-//                     the forest; score / FILTER / flags leave in variant order (coalesced).  While one wave waits
-//                     for memory the other fifteen walk: the featurize latency that bounded K1 disappears under
-//                     the LDS-bound walk.  Indel tiles (18 % of a WGS callset) are featurised by the same waves
-//                     between SNP tiles (48-byte window, homopolymer logic, bracketed searches on the L2-resident
-//                     tables) and leave as 48-byte raw-code records in their variant-type group's list.
+//   fused5_kernel     one 16-wave workgroup per CU owns a contiguous range of the callset's rows and holds the
+//                     SNP forest in LDS (rank-coded complete trees, single-sum layout) with the float thresholds.
+//                     Prologue: the rows are split by variant class (ref_len == alt_len: the SNP forest; else an
+//                     indel) into two dense, ordered lists of row indices; a tile is 64 consecutive entries - one
+//                     wave's work, pure in class, so every lane of a wave walks the SAME forest.  After that a wave
+//                     is autonomous (no workgroup barrier): it takes CONSECUTIVE tiles, so where its next tile
+//                     starts in every side table is where its last variant ended (carried ranks; a fresh search -
+//                     64 probes per step by the whole wave - only at its first tile and at contig changes).  Per
+//                     tile it loads the columns, an 11-base reference window per lane (one 16-byte load, realigned
+//                     with v_alignbyte), stages the side-table slices the tile can touch in wave-private LDS
+//                     (sentinel padded: the lock-step descents carry no bounds test and no branch), derives the
+//                     features, writes 16-bit codes straight into its code planes and walks the forest; score /
+//                     FILTER / flags leave in variant order.  Row indices, columns and slices of the NEXT tile are
+//                     in flight during the current one.  A quarter of the waves (by the class mix) work on the
+//                     indel tiles instead (48-byte window, homopolymer logic, slices of two or six rows per lane)
+//                     and leave 48-byte raw-code records in their variant-type group's list.
 //   forest5_kernel    walks the indel groups' forests over those records (the v3 forest kernel on raw records).
+//
+// (Until round 2 the class split and the per-tile lower bounds were two kernels of their own in front - atomically
+// handed-out tile slots, one search thread per tile and table: 17 + 37 us per 5 M variants and ~50 us of latency at
+// any size.  Ordered lists make both unnecessary.)
 //
 // Codes: floats (qual, sor, vaf, gc) are ranked against the group's sorted thresholds (exact, as v3); every
 // other feature is a non-negative integer and is used as it stands, clamped to one past the largest threshold
@@ -56,160 +59,88 @@ constexpr int kGcRank = 121;         // gc_content takes 121 values (count / len
 constexpr int kGcRankBytes = 768;    // 3 groups x 121 u16, padded
 constexpr int kWinRowB = kWinStride * 4;
 
-// ---- Kc: variant classes -> tiles of 64 row indices ---------------------------------------------------
-// A workgroup of four waves owns kCBlock5 = 1024 consecutive rows (256 per wave, four rounds of 64): small
-// workgroups keep thousands of them in flight, so the one returning atomic each needs is hidden.
-__global__ __launch_bounds__(256) void compact5_kernel(const V5Args v) {
-    __shared__ unsigned ws[4], wi[4];
-    __shared__ unsigned base_s, base_i;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int64_t g = (int64_t)blockIdx.x * 256 + tid; g < UGVC_N_GROUPS * kShards; g += (int64_t)gridDim.x * 256)
-        v.counters[g * kCounterStride] = 0;                            // the record lists of this pass start empty
-    const int64_t i0 = (int64_t)blockIdx.x * kCBlock5 + wave * 256 + lane;
-    unsigned long long ms[4], mi[4];
-    unsigned cs = 0, ci = 0;
+// ---- where a wave stands in the side tables -------------------------------------------------------------
+// A wave works through CONSECUTIVE tiles of its class in callset order, so the lower bounds its next tile starts
+// from are the ranks its last variant ended at: they are carried, not searched.  A fresh search happens at a wave's
+// first tile and when the contig changes, and then the whole wave does it together.
+template <int NT>
+struct Brk {
+    int c;                          // contig the state belongs to (-1: none - the next tile searches afresh)
+    int64_t clo, chi;               // its span of the reference
+    int plo[NT], phi[NT];           // its row range in every interval table
+    int L[NT];                      // # starts < pos of the last variant seen (global row index)
+    int Lb;                         // # blacklist keys < its key
+};
+
+// Lower bounds of (pos | key) in every table at once, by the whole wave: 64 evenly spaced probes per table and
+// step, one gather each, the ballot's population count picks the sub-range - a 3 M-row table closes in four round
+// trips (binary: 22).
+template <int NT>
+__device__ __forceinline__ void coop_search(const FilterArgs& a, Brk<NT>& bk, int pos, uint64_t key, int lane) {
+    int b[NT], len[NT];
+    int bb = 0, blen = a.n_bl > 0 ? (int)a.n_bl : 0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int64_t i = i0 + r * 64;
-        bool snp = false, ind = false;
-        if (i < v.f.n) {
-            snp = v.f.ref_len[i] == v.f.alt_len[i];
-            ind = !snp;
+    for (int t = 0; t < NT; ++t) {
+        b[t] = bk.plo[t];
+        len[t] = (t > 0 || a.has_runs) ? bk.phi[t] - bk.plo[t] : 0;
+    }
+    for (;;) {
+        bool any = blen > 0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) any |= len[t] > 0;
+        if (!any) break;
+        int x[NT], step[NT];
+        uint64_t xk = ~0ull;
+        int bstep = 0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            step[t] = (len[t] + 63) >> 6;
+            x[t] = INT32_MAX;
+            if (len[t] > 0 && lane * step[t] < len[t]) x[t] = table_view(a, t).starts[b[t] + lane * step[t]];
         }
-        ms[r] = __ballot(snp);
-        mi[r] = __ballot(ind);
-        cs += (unsigned)__popcll(ms[r]);
-        ci += (unsigned)__popcll(mi[r]);
-    }
-    if (lane == 0) { ws[wave] = cs; wi[wave] = ci; }
-    __syncthreads();
-    unsigned ps = 0, pi = 0, ts = 0, ti = 0;
+        if (blen > 0) {
+            bstep = (blen + 63) >> 6;
+            if (lane * bstep < blen) xk = a.bl[bb + lane * bstep];
+        }
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        const unsigned a = ws[w], b = wi[w];
-        ps += w < wave ? a : 0u;
-        pi += w < wave ? b : 0u;
-        ts += a;
-        ti += b;
+        for (int t = 0; t < NT; ++t) {
+            if (len[t] > 0) {
+                const int k = (int)__popcll(__ballot(x[t] < pos));          // probes ascend: the first k are below
+                const int end = b[t] + len[t];
+                const int nb = k > 0 ? b[t] + (k - 1) * step[t] + 1 : b[t];
+                const int ne = min(b[t] + k * step[t], end);
+                b[t] = nb;
+                len[t] = ne > nb ? ne - nb : 0;
+            }
+        }
+        if (blen > 0) {
+            const int k = (int)__popcll(__ballot(xk < key));
+            const int end = bb + blen;
+            const int nb = k > 0 ? bb + (k - 1) * bstep + 1 : bb;
+            const int ne = min(bb + k * bstep, end);
+            bb = nb;
+            blen = ne > nb ? ne - nb : 0;
+        }
     }
-    const unsigned nts = (ts + 63) >> 6, nti = (ti + 63) >> 6;
-    // tile slots: 64 shards of `shard_tiles` slots per class, one atomic per block and class on the block's shard
-    // (a single counter per class serialises ~5000 same-address atomics: 116 us per 5 M variants)
-    const unsigned shard = blockIdx.x & (kTileShards5 - 1);
-    if (tid == 0) base_s = nts ? atomicAdd(&v.tile_cnt[shard * kTileCntStride5], nts) : 0u;
-    if (tid == 64) base_i = nti ? atomicAdd(&v.tile_cnt[(kTileShards5 + shard) * kTileCntStride5], nti) : 0u;
-    __syncthreads();
-    const unsigned bs = shard * (unsigned)v.shard_tiles + base_s, bi = shard * (unsigned)v.shard_tiles + base_i;
-    const unsigned long long below = (1ull << lane) - 1;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const uint32_t i = (uint32_t)(i0 + r * 64);
-        if ((ms[r] >> lane) & 1) v.snp_idx[(size_t)bs * 64 + ps + (unsigned)__popcll(ms[r] & below)] = i;
-        if ((mi[r] >> lane) & 1) v.indel_idx[(size_t)bi * 64 + pi + (unsigned)__popcll(mi[r] & below)] = i;
-        ps += (unsigned)__popcll(ms[r]);
-        pi += (unsigned)__popcll(mi[r]);
-    }
-    if ((unsigned)tid < nts * 64 - ts) v.snp_idx[(size_t)bs * 64 + ts + tid] = ~0u;          // padding of the last tile
-    if ((unsigned)tid < nti * 64 - ti) v.indel_idx[(size_t)bi * 64 + ti + tid] = ~0u;
-    if ((unsigned)tid < nts) v.tile_n[bs + tid] = (uint8_t)((unsigned)tid + 1 < nts ? 64u : ts - 64u * (nts - 1));
-    if ((unsigned)tid < nti) v.tile_n[(size_t)v.max_tiles + bi + tid] = (uint8_t)((unsigned)tid + 1 < nti ? 64u : ti - 64u * (nti - 1));
+    for (int t = 0; t < NT; ++t) bk.L[t] = rfl(b[t]);
+    bk.Lb = rfl(bb);
 }
 
-// ---- K0: per tile, lower bounds of its first (indel tiles: and last) variant in the searched tables ---
-// One thread per (REAL tile, searched table): the tile counters of both classes are scanned in LDS, a thread finds
-// its tile by its rank among the real tiles - no lane idles on an empty slot or an absent table (the searches are
-// chains of ~22 dependent loads: what counts is how many waves the launch needs, not their instruction count).
-__global__ __launch_bounds__(256) void bracket5_kernel(const V5Args v) {
-    __shared__ unsigned incl[2][kTileShards5];
-    const int tid = threadIdx.x;
-    if (tid < 2 * kTileShards5) {
-        const int cls = tid >> 6, sh = tid & 63;
-        unsigned x = v.tile_cnt[(cls * kTileShards5 + sh) * kTileCntStride5];
+template <int NT>
+__device__ __forceinline__ void brk_refresh(const FilterArgs& a, Brk<NT>& bk, int c0, int pos0, int lane) {
+    bk.c = c0;
+    bk.clo = cload(a.contig_off + c0);
+    bk.chi = cload(a.contig_off + c0 + 1);
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const unsigned y = __shfl_up(x, d);
-            if (sh >= d) x += y;
-        }
-        incl[cls][sh] = x;
+    for (int t = 0; t < NT; ++t) {
+        bk.plo[t] = bk.phi[t] = 0;
+        if (t == 0 && !a.has_runs) continue;
+        const TrackView& tv = table_view(a, t);
+        bk.plo[t] = cload(tv.ptr + c0);
+        bk.phi[t] = cload(tv.ptr + c0 + 1);
     }
-    __syncthreads();
-    const FilterArgs& f = v.f;
-    // active tables, in order: runs (if any), tracks, blacklist (if any)
-    const int n_act = (f.has_runs ? 1 : 0) + f.n_tracks + (f.n_bl > 0 ? 1 : 0);
-    const int n_thr = n_act > 0 ? n_act : 1;                            // (no table at all: the SNP tiles still get their contig word)
-    const int64_t ns = incl[0][kTileShards5 - 1], ni = incl[1][kTileShards5 - 1];
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + tid;
-    int64_t rank;                       // rank of the tile among the real tiles of its class
-    int k, last;
-    bool is_indel;
-    if (gid < ns * n_thr) { rank = gid / n_thr; k = (int)(gid - rank * n_thr); last = 0; is_indel = false; }
-    else {
-        const int64_t g2 = gid - ns * n_thr;
-        if (n_act == 0 || g2 >= ni * 2 * n_act) return;
-        rank = g2 / (2 * n_act);
-        const int r = (int)(g2 - rank * 2 * n_act);
-        last = r >= n_act;
-        k = last ? r - n_act : r;
-        is_indel = true;
-    }
-    int t = k + (f.has_runs ? 0 : 1);                                   // table index: 0 runs, 1.. tracks, kJoin5 - 1 blacklist
-    if (t > f.n_tracks) t = kJoin5 - 1;
-    const unsigned* inc = incl[is_indel ? 1 : 0];
-    int lo = 0, len = kTileShards5;
-    while (len > 0) {                                                   // first shard whose inclusive count exceeds the rank
-        const int half = len >> 1;
-        const bool le = inc[lo + half] <= (unsigned)rank;
-        lo = le ? lo + half + 1 : lo;
-        len = le ? len - half - 1 : half;
-    }
-    const int shard = lo;
-    const int64_t tile = (int64_t)shard * v.shard_tiles + (rank - (shard > 0 ? inc[shard - 1] : 0u));
-    const uint32_t* list = is_indel ? v.indel_idx : v.snp_idx;
-    const int slot = last ? (int)v.tile_n[(size_t)v.max_tiles + tile] - 1 : 0;
-    const uint32_t i = list[tile * 64 + slot];
-    const int c = f.contig[i], pos = f.pos[i];
-    int out = 0;
-    if (n_act == 0) {
-    } else if (t == kJoin5 - 1) out = lb_two_level_g<uint64_t>(f.bl, f.bl_coarse, 0, (int)f.n_bl, ((uint64_t)c << 32) | (uint32_t)pos);
-    else {
-        const TrackView& tv = table_view(f, t);
-        out = lb_two_level_g<int32_t>(tv.starts, tv.coarse, tv.ptr[c], tv.ptr[c + 1], pos);
-    }
-    if (is_indel) {
-        // indel tile record (kRecI5 ints): [t] / [8 + t] lower bounds of the first / last variant per table,
-        // [16 + 2t], [17 + 2t] the contig's row range, [28] contig (bit 31: the tile spans contigs)
-        int32_t* rec = v.br_indel + tile * kRecI5;
-        rec[(last ? 8 : 0) + t] = out;
-        if (!last && t != kJoin5 - 1) {
-            const TrackView& tv = table_view(f, t);
-            rec[16 + 2 * t] = tv.ptr[c];
-            rec[17 + 2 * t] = tv.ptr[c + 1];
-        }
-        if (!last && k == 0) {
-            const int n = (int)v.tile_n[(size_t)v.max_tiles + tile];
-            const int c_last = f.contig[list[tile * 64 + (n > 0 ? n - 1 : 0)]];
-            rec[28] = c | (c_last != c ? INT32_MIN : 0);
-        }
-    } else {
-        // SNP tile record (kRecS5 ints): [t] lower bound per table, [7] contig of the tile (bit 31: the tile spans
-        // contigs), [8 + 2t], [9 + 2t] the contig's row range of table t, [20..23] its span of the reference - everything the fused kernel needs to fetch
-        // the tile's slices BEFORE it has seen the tile's columns
-        int32_t* rec = v.br_snp + tile * kRecS5;
-        if (n_act > 0) rec[t] = out;
-        if (n_act > 0 && t != kJoin5 - 1) {
-            const TrackView& tv = table_view(f, t);
-            rec[8 + 2 * t] = tv.ptr[c];
-            rec[9 + 2 * t] = tv.ptr[c + 1];
-        }
-        if (k == 0) {
-            const int n = (int)v.tile_n[tile];
-            const int c_last = f.contig[list[tile * 64 + (n > 0 ? n - 1 : 0)]];
-            rec[7] = c | (c_last != c ? INT32_MIN : 0);
-            const int64_t clo = f.contig_off[c], chi = f.contig_off[c + 1];      // [20..23]: the contig's span of the reference
-            rec[20] = (int32_t)(uint32_t)clo; rec[21] = (int32_t)(clo >> 32);
-            rec[22] = (int32_t)(uint32_t)chi; rec[23] = (int32_t)(chi >> 32);
-        }
-    }
+    coop_search<NT>(a, bk, pos0, ((uint64_t)(uint32_t)c0 << 32) | (uint32_t)pos0, lane);
 }
 
 #ifdef UGVC_PHASE_CLOCK
@@ -254,13 +185,15 @@ __device__ __forceinline__ void interval_verdict(int t, int sg, int plo, int phi
 
 // One table searched in HBM (rows [lo, hi) per lane): the rare paths - a tile that spans contigs, a slice that
 // outgrew its staging area.  Kept out of line so the common path stays small.
-__device__ __forceinline__ void join_one_global(const FilterArgs* ap, int t, int lo, int hi, int plo, int phi, int pos, uint64_t key,
-                                             JoinOut* op) {
+__device__ __forceinline__ int join_one_global(const FilterArgs* ap, int t, int lo, int hi, int plo, int phi, int pos, uint64_t key,
+                                            JoinOut* op) {
     const FilterArgs& a = *ap;
     JoinOut o = *op;
+    int rank = lo;                                           // the lane's lower bound (what the next tile starts from)
     if (t == kJoin5 - 1) {
         const int r = lb_u64_g(a.bl, lo, hi, key);
         o.cohort = r < (int)a.n_bl && a.bl[r] == key;
+        rank = r;
     } else if (phi > plo) {
         const TrackView& tv = table_view(a, t);
         const int sg = lb_i32_g(tv.starts, lo, hi, pos);
@@ -270,8 +203,10 @@ __device__ __forceinline__ void join_one_global(const FilterArgs* ap, int t, int
         if (t == 0) { o.inside_run = o.close_run = false; }
         else o.trk &= ~(1u << (t - 1));
         interval_verdict(t, sg, plo, phi, pos, a.hpol_dist, S, E, o);
+        rank = sg;
     }
     *op = o;
+    return rank;
 }
 
 // Indel tiles cover ~5x the span of an SNP tile, so their slices are staged per table: rows [lo - 2, hi + 2) between
@@ -309,12 +244,13 @@ __device__ __forceinline__ void stage_rows(uint32_t slot_b, int L0, int plo, int
     }
 }
 
-__device__ __forceinline__ void staged_verdict(const FilterArgs& a, uint32_t slot_b, int t, int L0, int plo, int phi, int pos, JoinOut& o) {
-    if (phi <= plo) return;
+__device__ __forceinline__ int staged_verdict(const FilterArgs& a, uint32_t slot_b, int t, int L0, int plo, int phi, int pos, JoinOut& o) {
+    if (phi <= plo) return plo;
     const int sg = L0 + (int)staged_rank(slot_b, pos);
     auto S = [&](int gi) { return lds_i32(slot_b + 4u * (uint32_t)(gi - L0)); };
     auto E = [&](int gi) { return lds_i32(slot_b + 512u + 4u * (uint32_t)(gi - L0)); };
     interval_verdict(t, sg, plo, phi, pos, a.hpol_dist, S, E, o);
+    return sg;
 }
 
 // A table too dense for the two-rows-per-lane slice (a 3 M-interval track under a 220 kb indel tile: ~210 rows):
@@ -330,8 +266,7 @@ __device__ __forceinline__ void wide_load(const TrackView& tv, int L0, int top, 
     }
 }
 
-__device__ __forceinline__ void wide_verdict(const FilterArgs& a, uint32_t A, int t, int L0, int plo, int phi, int pos, int lane,
-                                             const int (&wv)[kWideChunks], const int (&we)[kWideChunks], JoinOut& o) {
+__device__ __forceinline__ void wide_store(uint32_t A, int L0, int plo, int phi, int lane, const int (&wv)[kWideChunks], const int (&we)[kWideChunks]) {
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int h = 0; h < kWideChunks; ++h) {
@@ -341,7 +276,10 @@ __device__ __forceinline__ void wide_verdict(const FilterArgs& a, uint32_t A, in
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (phi <= plo) return;
+}
+
+__device__ __forceinline__ int wide_verdict(const FilterArgs& a, uint32_t A, int t, int L0, int plo, int phi, int pos, JoinOut& o) {
+    if (phi <= plo) return plo;
     uint32_t p = A - 4u;
     const uint32_t last = A + 4u * (kWideRows - 1);
 #pragma unroll
@@ -353,6 +291,7 @@ __device__ __forceinline__ void wide_verdict(const FilterArgs& a, uint32_t A, in
     auto S = [&](int gi) { return lds_i32(A + 4u * (uint32_t)(gi - L0)); };
     auto E = [&](int gi) { return lds_i32(A + 4u * kWideRows + 4u * (uint32_t)(gi - L0)); };
     interval_verdict(t, sg, plo, phi, pos, a.hpol_dist, S, E, o);
+    return sg;
 }
 
 __device__ __forceinline__ uint32_t raw_code(int x, int cap) {          // x < 0 ? 0 : min(x, cap) + 1
@@ -440,7 +379,7 @@ __device__ __forceinline__ SnpCols load_snp_cols(const FilterArgs& a, uint32_t i
 
 // The side-table slices of one SNP tile, in registers: fetched from the tile record alone, one tile ahead (they are
 // in flight during the previous tile's walk and are written to the wave's LDS scratch when that walk has finished
-// with its code planes).
+// with its code planes).  They start at the ranks the previous tile's last variant ended at (Brk).
 template <int NT>
 struct SlicePre {
     int sv[NT][2], ev[NT][2];
@@ -448,7 +387,7 @@ struct SlicePre {
 };
 
 template <int NT>
-__device__ __forceinline__ void issue_slices(const V5Args& v, uint32_t rec, int lane, SlicePre<NT>& s) {
+__device__ __forceinline__ void issue_slices(const V5Args& v, const Brk<NT>& bk, int lane, SlicePre<NT>& s) {
     const FilterArgs& a = v.f;
     s.bl = ~0ull;
 #pragma unroll
@@ -456,7 +395,7 @@ __device__ __forceinline__ void issue_slices(const V5Args& v, uint32_t rec, int 
         s.sv[t][0] = s.sv[t][1] = s.ev[t][0] = s.ev[t][1] = 0;
         if (t == 0 && !a.has_runs) continue;
         const TrackView& tv = table_view(a, t);
-        const int Lt = __builtin_amdgcn_readlane((int)rec, t) - 2;
+        const int Lt = bk.L[t] - 2;
         const int top = max(v.na[t] - 1, 0);
         {
             const uint32_t gs = (uint32_t)max(min(Lt + lane, top), 0);
@@ -468,7 +407,7 @@ __device__ __forceinline__ void issue_slices(const V5Args& v, uint32_t rec, int 
         }
     }
     if (a.n_bl > 0) {
-        const int64_t gi = (int64_t)__builtin_amdgcn_readlane((int)rec, kJoin5 - 1) + lane;
+        const int64_t gi = (int64_t)bk.Lb + lane;
         if (gi < a.n_bl) s.bl = a.bl[gi];
     }
 }
@@ -476,20 +415,21 @@ __device__ __forceinline__ void issue_slices(const V5Args& v, uint32_t rec, int 
 // ---- SNP / MNP tile: features of 64 substitutions (ref_len == alt_len) ---------------------------------
 // Writes the flags column, leaves the 16-bit codes of the group-0 forest in the wave's code planes.
 template <int NTRK>
-__device__ __forceinline__ void featurize_snp_tile(const V5Args& v, const Scratch& sc, int64_t tile, int lane, uint32_t i, bool live, bool has_model,
-                                                   const SnpCols& k, uint32_t rec, const SlicePre<1 + NTRK>& pre, PhaseClk& pc) {
+__device__ __forceinline__ void featurize_snp_tile(const V5Args& v, const Scratch& sc, int lane, uint32_t i, bool live, bool has_model,
+                                                   const SnpCols& k, Brk<1 + NTRK>& bk, SlicePre<1 + NTRK>& pre, PhaseClk& pc) {
     constexpr int NT = 1 + NTRK;                               // interval tables: runs + tracks
     const FilterArgs& a = v.f;
     const int c = k.c, pos = k.pos, rl = k.rl;
     const uint32_t ro = k.ro, ao = k.ao;
     const int c0 = rfl(c);
-    const bool uni = __builtin_amdgcn_readlane((int)rec, 7) >= 0;   // one contig (all but a handful of tiles): from K0's record
-    int64_t clo, chi;
-    if (uni) {                                                  // from the record: no round trip in front of the window
-        clo = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)rec, 21) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)rec, 20));
-        chi = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)rec, 23) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)rec, 22));
+    const bool uni = __ballot(c != c0) == 0;                    // one contig (all but a handful of tiles)
+    const bool joins_on = !(a.ablate & 524288);
+    const bool stage = uni && joins_on;
+    if (c0 != bk.c) {                                           // the wave's first tile, or a new contig: search afresh
+        brk_refresh<NT>(a, bk, c0, rfl(pos), lane);
+        if (stage) issue_slices<NT>(v, bk, lane, pre);
     }
-    else { clo = a.contig_off[c]; chi = a.contig_off[c + 1]; }
+    const int64_t clo = uni ? bk.clo : a.contig_off[c], chi = uni ? bk.chi : a.contig_off[c + 1];
     const uint32_t clen = (uint32_t)(chi - clo);
     const uint32_t p0 = (uint32_t)(pos - 1);
     const int64_t g0 = clo + p0;
@@ -504,15 +444,14 @@ __device__ __forceinline__ void featurize_snp_tile(const V5Args& v, const Scratc
     const int n_live = (int)__popcll(__ballot(live));
     const int pos_max = __builtin_amdgcn_readlane(pos, n_live - 1);
     const uint64_t key = ((uint64_t)(uint32_t)c << 32) | (uint32_t)pos;
-    const bool joins_on = !(a.ablate & 524288);
     int L[NT], plo[NT], phi[NT];
-    const bool stage = uni && joins_on;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        L[t] = __builtin_amdgcn_readlane((int)rec, t) - 2;
-        plo[t] = __builtin_amdgcn_readlane((int)rec, 8 + 2 * t);
-        phi[t] = __builtin_amdgcn_readlane((int)rec, 9 + 2 * t);
+        L[t] = bk.L[t] - 2;
+        plo[t] = bk.plo[t];
+        phi[t] = bk.phi[t];
     }
+    const int Lb0 = bk.Lb;
     CLK(pc, 6);
     const float qual = k.qual, sor = k.sor;
     const int dp = k.dp, adr = k.adr, ada = k.ada, gq = k.gq;
@@ -590,11 +529,15 @@ __device__ __forceinline__ void featurize_snp_tile(const V5Args& v, const Scratc
             for (int t = 0; t < NT; ++t) p[t] = x[t] < pos ? cand[t] : p[t];
             pb = xk < key ? cb : pb;
         }
+        int sg_l[NT];
+        int rb_l = Lb0 + (int)((pb + 8u - Ab) >> 3);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
+            sg_l[t] = bk.L[t];
             if (t == 0 && !a.has_runs) continue;
             const uint32_t dE = 4u * (uint32_t)v.jcap[t];
             const int sg = L[t] + (int)((p[t] + 4u - A[t]) >> 2);   // staged starts below pos
+            sg_l[t] = sg;
             const uint32_t ps = p[t];                               // LDS address of starts[sg - 1]
             auto S = [&](int gi) { return lds_i32(ps + 4u * (uint32_t)(gi - sg + 1)); };
             auto E = [&](int gi) { return lds_i32(ps + dE + 4u * (uint32_t)(gi - sg + 1)); };
@@ -605,11 +548,16 @@ __device__ __forceinline__ void featurize_snp_tile(const V5Args& v, const Scratc
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 if (t == 0 && !a.has_runs) continue;
-                if (__ballot(lds_i32(A[t] + maskB[t]) < pos_max) != 0) join_one_global(&a, t, plo[t], phi[t], plo[t], phi[t], pos, key, &jo);
+                if (__ballot(lds_i32(A[t] + maskB[t]) < pos_max) != 0)
+                    sg_l[t] = join_one_global(&a, t, max(L[t] + 2, plo[t]), phi[t], plo[t], phi[t], pos, key, &jo);
             }
             if (a.n_bl > 0 && __ballot(lds_u64(Ab + 8u * (kBlCap5 - 1)) < key_max) != 0)
-                join_one_global(&a, kJoin5 - 1, 0, (int)a.n_bl, 0, 0, pos, key, &jo);
+                rb_l = join_one_global(&a, kJoin5 - 1, Lb0, (int)a.n_bl, 0, 0, pos, key, &jo);
         }
+        // the next tile of this wave starts where this tile's last variant ended
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bk.L[t] = __builtin_amdgcn_readlane(sg_l[t], n_live - 1);
+        bk.Lb = __builtin_amdgcn_readlane(rb_l, n_live - 1);
     } else {
         // a tile that spans contigs: every lane searches its own contig's rows
 #pragma unroll
@@ -620,6 +568,7 @@ __device__ __forceinline__ void featurize_snp_tile(const V5Args& v, const Scratc
             join_one_global(&a, t, pl, ph, pl, ph, pos, key, &jo);
         }
         if (a.n_bl > 0) join_one_global(&a, kJoin5 - 1, 0, (int)a.n_bl, 0, 0, pos, key, &jo);
+        bk.c = -1;                                              // the next tile searches afresh
     }
     uint8_t flags = (uint8_t)(jo.trk << UGVC_FLAG_TRACK0_SHIFT);
     if (jo.cohort) flags |= UGVC_FLAG_COHORT_FP;
@@ -707,51 +656,70 @@ __device__ __forceinline__ void featurize_snp_tile(const V5Args& v, const Scratc
 
 // ---- indel tile: features of 64 length-changing variants -> raw-code records of groups 1 / 2 -------------
 template <int NTRK>
-__device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scratch& sc, int64_t tile, int lane, uint32_t i, bool live, PhaseClk& pc) {
+__device__ __forceinline__ void issue_indel_slices(const V5Args& v, const Brk<1 + NTRK>& bk, int lane, IndelPre<1 + NTRK>& pre) {
+    constexpr int NT = 1 + NTRK;
+    const FilterArgs& a = v.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        pre.sv[t][0] = pre.sv[t][1] = pre.ev[t][0] = pre.ev[t][1] = 0;
+        if ((t == 0 && !a.has_runs) || ((v.iwide >> t) & 1)) continue;      // (dense tables: six rows per lane, fetched at the joins)
+        const TrackView& tv = table_view(a, t);
+        const int top = max(v.na[t] - 1, 0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t gs = (uint32_t)max(min(bk.L[t] - 2 + 64 * h + lane, top), 0);
+            pre.sv[t][h] = tv.starts[gs]; pre.ev[t][h] = tv.ends[gs];
+        }
+    }
+    pre.bl[0] = pre.bl[1] = ~0ull;
+    if (a.n_bl > 0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t gi = (int64_t)bk.Lb + 64 * h + lane;
+            if (gi < a.n_bl) pre.bl[h] = a.bl[gi];
+        }
+    }
+}
+
+struct IndelCols {                  // the columns of one indel (fetched one tile ahead of their use)
+    int c, pos, rl, al;
+    uint32_t ro, ao;
+    float qual, sor;
+    int dp, adr, ada, gq;
+};
+
+__device__ __forceinline__ IndelCols load_indel_cols(const FilterArgs& a, uint32_t i) {
+    IndelCols k;
+    k.c = a.contig[i]; k.pos = a.pos[i]; k.rl = a.ref_len[i]; k.al = a.alt_len[i];
+    k.ro = a.ref_off[i]; k.ao = a.alt_off[i];
+    k.qual = a.qual[i]; k.sor = a.sor[i];
+    k.dp = a.dp[i]; k.adr = a.ad_ref[i]; k.ada = a.ad_alt[i]; k.gq = a.gq[i];
+    return k;
+}
+
+template <int NTRK>
+__device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scratch& sc, uint32_t rshard, int lane, uint32_t i, bool live,
+                                                     const IndelCols& k, Brk<1 + NTRK>& bk, IndelPre<1 + NTRK>& pre, PhaseClk& pc) {
     constexpr int NT = 1 + NTRK;
     const FilterArgs& a = v.f;
     const uint8_t* __restrict__ apool = a.alleles;
-    // ---- the tile's record and its table slices (independent of the columns: issued first)
     const bool joins_on = !(a.ablate & 524288);
-    const int32_t* trec = v.br_indel + tile * kRecI5;
-    const bool uni = cload(trec + 28) >= 0;
-    int lo_[kJoin5], hi_[kJoin5], pl[NT], ph[NT];
-    IndelPre<NT> pre;
-    if (uni && joins_on) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            lo_[t] = hi_[t] = pl[t] = ph[t] = 0;
-            pre.sv[t][0] = pre.sv[t][1] = pre.ev[t][0] = pre.ev[t][1] = 0;
-            if (t == 0 && !a.has_runs) continue;
-            const TrackView& tv = table_view(a, t);
-            lo_[t] = cload(trec + t); hi_[t] = cload(trec + 8 + t);
-            pl[t] = cload(trec + 16 + 2 * t); ph[t] = cload(trec + 17 + 2 * t);
-            const int top = max(v.na[t] - 1, 0);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const uint32_t gs = (uint32_t)max(min(lo_[t] - 2 + 64 * h + lane, top), 0);
-                pre.sv[t][h] = tv.starts[gs]; pre.ev[t][h] = tv.ends[gs];
-            }
-        }
-        lo_[kJoin5 - 1] = cload(trec + kJoin5 - 1); hi_[kJoin5 - 1] = cload(trec + 8 + kJoin5 - 1);
-        pre.bl[0] = pre.bl[1] = ~0ull;
-        if (a.n_bl > 0) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int64_t gi = (int64_t)lo_[kJoin5 - 1] + 64 * h + lane;
-                if (gi < a.n_bl) pre.bl[h] = a.bl[gi];
-            }
-        }
+    const int c = k.c, pos = k.pos, rl = k.rl, al = k.al;
+    const uint32_t ro = k.ro, ao = k.ao;
+    const float qual = k.qual, sor = k.sor;
+    const int dp = k.dp, adr = k.adr, ada = k.ada, gq = k.gq;
+    const int c0 = rfl(c);
+    const bool uni = __ballot(c != c0) == 0;
+    if (c0 != bk.c) {                                           // the wave's first tile, or a new contig: search afresh
+        brk_refresh<NT>(a, bk, c0, rfl(pos), lane);
+        if (uni && joins_on) issue_indel_slices<NTRK>(v, bk, lane, pre);
     }
-    const int c = a.contig[i], pos = a.pos[i], rl = a.ref_len[i], al = a.alt_len[i];
-    const uint32_t ro = a.ref_off[i], ao = a.alt_off[i];
-    // the model's own columns: needed last, issued first (every round trip of this tile is a dependent one)
-    const float qual = a.qual[i], sor = a.sor[i];
-    const int dp = a.dp[i], adr = a.ad_ref[i], ada = a.ad_alt[i], gq = a.gq[i];
+    const int n_live = (int)__popcll(__ballot(live));
+    const int pos_max = __builtin_amdgcn_readlane(pos, n_live - 1);
     const bool ins = rl < al;
     const int classify = ins ? 1 : 2;
     const int indel_length = ins ? al - rl : rl - al;
-    const int64_t clo = a.contig_off[c], chi = a.contig_off[c + 1];
+    const int64_t clo = uni ? bk.clo : a.contig_off[c], chi = uni ? bk.chi : a.contig_off[c + 1];
     const uint32_t clen = (uint32_t)(chi - clo);
     const uint32_t p0 = (uint32_t)(pos - 1);
     const int64_t g0 = clo + p0;
@@ -841,7 +809,7 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
     // ---- record slots: one returning atomic per wave and group (issued here: its round trip runs under the joins)
     const bool mine = live && pg_ok;
     const unsigned long long m1 = __ballot(mine && group == 1), m2 = __ballot(mine && group == 2);
-    const int shard = (int)(tile & (kShards - 1));
+    const int shard = (int)(rshard & (kShards - 1));
     unsigned got = 0;
     if (lane == 1 && m1 != 0) got = atomicAdd(&v.counters[(1 * kShards + shard) * kCounterStride], (unsigned)__popcll(m1));
     if (lane == 2 && m2 != 0) got = atomicAdd(&v.counters[(2 * kShards + shard) * kCounterStride], (unsigned)__popcll(m2));
@@ -882,33 +850,43 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
     if (!joins_on) {
     } else if (uni) {
         const uint32_t s0 = sc.base, s1 = sc.base + kIndelSlotB;
-        auto fits = [&](int t) { return hi_[t] - lo_[t] + 4 <= kIndelRows - 1; };
-        auto wide = [&](int t) { return !fits(t) && hi_[t] - lo_[t] + 4 <= kWideRows - 1; };
-        // the first table that needs the wide slice: its rows are requested now and arrive under the narrow rounds
+        auto on = [&](int t) { return t > 0 || a.has_runs; };
+        auto is_wide = [&](int t) { return ((v.iwide >> t) & 1) != 0; };
+        // a staged slice reaches the tile's last variant if its last row does (or is padding); else that table is
+        // searched in HBM from the carried rank
+        auto covers = [&](uint32_t last_row_b) { return rfl(lds_i32(last_row_b)) >= pos_max; };
+        int sg_l[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) sg_l[t] = bk.L[t];
+        int rb_l = bk.Lb;
+        // the first dense table: its rows are requested now and arrive under the narrow rounds
         int tw = -1;
         int wv[kWideChunks], we[kWideChunks];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
-            if (tw < 0 && !(t == 0 && !a.has_runs) && wide(t)) {
+            if (tw < 0 && on(t) && is_wide(t)) {
                 tw = t;
-                wide_load(table_view(a, t), lo_[t] - 2, max(v.na[t] - 1, 0), lane, wv, we);
+                wide_load(table_view(a, t), bk.L[t] - 2, max(v.na[t] - 1, 0), lane, wv, we);
             }
+        auto narrow = [&](uint32_t slot, int t) {
+            if (covers(slot + 4u * (kIndelRows - 1))) sg_l[t] = staged_verdict(a, slot, t, bk.L[t] - 2, bk.plo[t], bk.phi[t], pos, jo);
+            else sg_l[t] = join_one_global(&a, t, max(bk.L[t], bk.plo[t]), bk.phi[t], bk.plo[t], bk.phi[t], pos, key, &jo);
+        };
         // round A: runs | blacklist
-        const bool runs_on = a.has_runs != 0, bl_on = a.n_bl > 0;
-        const bool bl_fit = hi_[kJoin5 - 1] - lo_[kJoin5 - 1] + 1 <= kIndelRows - 1;
+        const bool bl_on = a.n_bl > 0;
         __builtin_amdgcn_wave_barrier();
-        if (runs_on && fits(0)) stage_rows(s0, lo_[0] - 2, pl[0], ph[0], pre.sv[0], pre.ev[0], lane);
-        if (bl_on && bl_fit) {
+        if (on(0) && !is_wide(0)) stage_rows(s0, bk.L[0] - 2, bk.plo[0], bk.phi[0], pre.sv[0], pre.ev[0], lane);
+        if (bl_on) {
             lds_st64(s1 + 8u * lane, pre.bl[0]);
             lds_st64(s1 + 512u + 8u * lane, pre.bl[1]);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (runs_on) {
-            if (fits(0)) staged_verdict(a, s0, 0, lo_[0] - 2, pl[0], ph[0], pos, jo);
-        }
+        if (on(0) && !is_wide(0)) narrow(s0, 0);
         if (bl_on) {
-            if (bl_fit) {
+            const uint64_t key_max = ((uint64_t)(uint32_t)c0 << 32) | (uint32_t)pos_max;
+            const uint64_t last_key = lds_u64(s1 + 8u * (kIndelRows - 1));
+            if (__ballot(last_key < key_max) == 0) {
                 uint32_t pb = s1 - 8u;
 #pragma unroll
                 for (int sb = 512; sb >= 8; sb >>= 1) {
@@ -916,28 +894,34 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
                     pb = lds_u64(cand) < key ? cand : pb;
                 }
                 if (lds_u64(pb + 8u) == key) jo.cohort = true;
-            } else join_one_global(&a, kJoin5 - 1, lo_[kJoin5 - 1], hi_[kJoin5 - 1], 0, 0, pos, key, &jo);
+                rb_l = bk.Lb + (int)((pb + 8u - s1) >> 3);
+            } else rb_l = join_one_global(&a, kJoin5 - 1, bk.Lb, (int)a.n_bl, 0, 0, pos, key, &jo);
         }
         // tracks, in pairs
 #pragma unroll
         for (int t = 1; t < NT; t += 2) {
+            const int t2 = t + 1 < NT ? t + 1 : t;
             __builtin_amdgcn_wave_barrier();
-            if (fits(t)) stage_rows(s0, lo_[t] - 2, pl[t], ph[t], pre.sv[t], pre.ev[t], lane);
-            if (t + 1 < NT && fits(t + 1)) stage_rows(s1, lo_[t + 1] - 2, pl[t + 1], ph[t + 1], pre.sv[t + 1 < NT ? t + 1 : t], pre.ev[t + 1 < NT ? t + 1 : t], lane);
+            if (!is_wide(t)) stage_rows(s0, bk.L[t] - 2, bk.plo[t], bk.phi[t], pre.sv[t], pre.ev[t], lane);
+            if (t + 1 < NT && !is_wide(t2)) stage_rows(s1, bk.L[t2] - 2, bk.plo[t2], bk.phi[t2], pre.sv[t2], pre.ev[t2], lane);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (fits(t)) staged_verdict(a, s0, t, lo_[t] - 2, pl[t], ph[t], pos, jo);
-            if (t + 1 < NT && fits(t + 1)) staged_verdict(a, s1, t + 1, lo_[t + 1] - 2, pl[t + 1 < NT ? t + 1 : t], ph[t + 1 < NT ? t + 1 : t], pos, jo);
+            if (!is_wide(t)) narrow(s0, t);
+            if (t + 1 < NT && !is_wide(t2)) narrow(s1, t2);
         }
-        // the tables the narrow slices could not hold
+        // the dense tables: six rows per lane, the whole scratch, one at a time
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            if ((t == 0 && !a.has_runs) || fits(t)) continue;
-            if (wide(t)) {
-                if (t != tw) wide_load(table_view(a, t), lo_[t] - 2, max(v.na[t] - 1, 0), lane, wv, we);
-                wide_verdict(a, s0, t, lo_[t] - 2, pl[t], ph[t], pos, lane, wv, we, jo);
-            } else join_one_global(&a, t, lo_[t], hi_[t], pl[t], ph[t], pos, key, &jo);
+            if (!on(t) || !is_wide(t)) continue;
+            if (t != tw) wide_load(table_view(a, t), bk.L[t] - 2, max(v.na[t] - 1, 0), lane, wv, we);
+            wide_store(s0, bk.L[t] - 2, bk.plo[t], bk.phi[t], lane, wv, we);
+            if (covers(s0 + 4u * (kWideRows - 1))) sg_l[t] = wide_verdict(a, s0, t, bk.L[t] - 2, bk.plo[t], bk.phi[t], pos, jo);
+            else sg_l[t] = join_one_global(&a, t, max(bk.L[t], bk.plo[t]), bk.phi[t], bk.plo[t], bk.phi[t], pos, key, &jo);
         }
+        // the next tile of this wave starts where this tile's last variant ended
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bk.L[t] = __builtin_amdgcn_readlane(sg_l[t], n_live - 1);
+        bk.Lb = __builtin_amdgcn_readlane(rb_l, n_live - 1);
     } else {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -947,6 +931,7 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
             join_one_global(&a, t, pl_, ph_, pl_, ph_, pos, key, &jo);
         }
         if (a.n_bl > 0) join_one_global(&a, kJoin5 - 1, 0, (int)a.n_bl, 0, 0, pos, key, &jo);
+        bk.c = -1;                                              // the next tile searches afresh
     }
     uint8_t flags = (uint8_t)(jo.trk << UGVC_FLAG_TRACK0_SHIFT);
     if (jo.cohort) flags |= UGVC_FLAG_COHORT_FP;
@@ -1135,71 +1120,146 @@ static size_t lds5_bytes(const V5Args& v, int n_waves) {
     return b + (size_t)(n_waves - n_iw) * v.scratch_bytes + (size_t)n_iw * v.scratch_indel;
 }
 
-// Tile of a wave's k-th unit of work: the 64 shard counters of a class are scanned once per wave (lane s holds
-// the inclusive count of shards 0..s); virtual index -> (shard, slot in the shard).
-__device__ __forceinline__ int64_t tile_of(int64_t vidx, unsigned incl, int shard_tiles) {
-    const int shard = (int)__popcll(__ballot(incl <= (unsigned)vidx));
-    const unsigned excl = shard > 0 ? (unsigned)__builtin_amdgcn_readlane((int)incl, shard - 1) : 0u;
-    return (int64_t)shard * shard_tiles + ((unsigned)vidx - excl);
-}
-
 // ---- Kf: persistent, one workgroup per CU; every wave works through tiles on its own --------------------
+// A workgroup owns `rows_wg` consecutive rows of the callset.  Prologue (the only workgroup barriers): the forest
+// and the threshold tables go to LDS while every wave counts the variant classes of its sixteenth of the rows; the
+// wave counts are scanned and the rows are written as two dense lists of row indices - substitutions (ref_len ==
+// alt_len: the SNP forest) and indels - in callset order.  A tile is 64 consecutive entries of a list: pure in
+// class (every lane of a wave walks the SAME forest), ascending in position.  Waves then take CONSECUTIVE tiles:
+// the first `n_sw` waves share the SNP tiles, the others the indel tiles, in proportion to the tile counts.
 template <int NTRK, int NTW>
 __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned wcnt[2][kK2Threads / 64];
+    constexpr int NT = 1 + NTRK;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = rfl(tid >> 6);
     const int n_waves = blockDim.x >> 6;
+    const FilterArgs& a = v.f;
+    const int64_t r0 = (int64_t)blockIdx.x * v.rows_wg;
+    if (r0 >= a.n) return;                                       // (uniform: before the first barrier)
+    const int64_t r1 = min(r0 + (int64_t)v.rows_wg, a.n);
     const PackedGroupView& pg0 = v.pg[0];
     const bool has0 = pg0.ok != 0;
     // the thresholds of every group: SNP tiles rank against group 0's slices (the head of the table), indel
     // tiles against their own group's
     const Lds5 L = lds5_fill(smem, v, has0, tid, blockDim.x);
+    // ---- classes of this wave's rows (eight groups of 64 in flight)
+    const int64_t m = (r1 - r0 + n_waves - 1) / n_waves;
+    const int64_t w0 = r0 + (int64_t)wave * m, w1 = min(w0 + m, r1);
+    constexpr int U = 8;
+    unsigned cs = 0, ci = 0;
+    for (int64_t g = w0; g < w1; g += 64 * U) {
+        int rl[U], al[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t r = g + 64 * u + lane;
+            rl[u] = al[u] = -1;
+            if (r < w1) { rl[u] = a.ref_len[r]; al[u] = a.alt_len[r]; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            cs += (unsigned)__popcll(__ballot(rl[u] >= 0 && rl[u] == al[u]));
+            ci += (unsigned)__popcll(__ballot(rl[u] >= 0 && rl[u] != al[u]));
+        }
+    }
+    if (lane == 0) { wcnt[0][wave] = cs; wcnt[1][wave] = ci; }
+    __syncthreads();
+    unsigned ps = 0, pi = 0, ns_l = 0, ni_l = 0;
+    for (int w = 0; w < n_waves; ++w) {
+        const unsigned x = wcnt[0][w], y = wcnt[1][w];
+        ps += w < wave ? x : 0u;
+        pi += w < wave ? y : 0u;
+        ns_l += x;
+        ni_l += y;
+    }
+    uint32_t* __restrict__ ls = v.snp_idx + (size_t)blockIdx.x * v.list_stride;
+    uint32_t* __restrict__ li = v.indel_idx + (size_t)blockIdx.x * v.list_stride;
+    {
+        const unsigned long long below = (1ull << lane) - 1;
+        for (int64_t g = w0; g < w1; g += 64 * U) {
+            int rl[U], al[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t r = g + 64 * u + lane;
+                rl[u] = al[u] = -1;
+                if (r < w1) { rl[u] = a.ref_len[r]; al[u] = a.alt_len[r]; }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool snp = rl[u] >= 0 && rl[u] == al[u], ind = rl[u] >= 0 && rl[u] != al[u];
+                const unsigned long long ms = __ballot(snp), mi = __ballot(ind);
+                const uint32_t r = (uint32_t)(g + 64 * u + lane);
+                if (snp) ls[ps + (unsigned)__popcll(ms & below)] = r;
+                if (ind) li[pi + (unsigned)__popcll(mi & below)] = r;
+                ps += (unsigned)__popcll(ms);
+                pi += (unsigned)__popcll(mi);
+            }
+        }
+        if (wave == n_waves - 1) {                               // padding of the last tile of either list
+            ls[ns_l + lane] = ~0u;
+            li[ni_l + lane] = ~0u;
+        }
+    }
+    __threadfence_block();
     __syncthreads();
     Scratch sc;
     sc.eyt_b = L.eyt_b; sc.thr_b = L.thr_b; sc.gcr_b = L.gcr_b; sc.css_b = L.css_b; sc.gtab_b = L.gtab_b;
     const int hslot = ((lane & 31) << 1) | (lane >> 5);
-    // inclusive scans of the shard counters of both classes
-    unsigned incl_s = v.tile_cnt[lane * kTileCntStride5], incl_i = v.tile_cnt[(kTileShards5 + lane) * kTileCntStride5];
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const unsigned ys = __shfl_up(incl_s, d), yi = __shfl_up(incl_i, d);
-        if (lane >= d) { incl_s += ys; incl_i += yi; }
-    }
-    const int64_t ns = (unsigned)__builtin_amdgcn_readlane((int)incl_s, 63);
-    const int64_t ni = (v.f.ablate & 262144) ? 0 : (unsigned)__builtin_amdgcn_readlane((int)incl_i, 63);
-    // Wave roles: the last `n_iw` waves of a workgroup featurise the indel tiles (memory-latency bound, no walk),
-    // the others run the SNP pipeline: a tile's row indices and columns are fetched ONE TILE AHEAD (indices at the
-    // top of the previous tile, columns just before its walk), so a tile starts with its window / allele / slice
-    // gathers instead of two dependent round trips.  Work slots are wave-major over the workgroups: a short last
-    // round leaves a few waves busy on every CU.
-    // the LDS layout gives the last `n_indel_waves` waves the larger (window-row) scratch; how many of them actually work
-    // on indel tiles follows the callset's class mix (an SNV-only callset has none: every wave runs the SNP pipeline)
+    const int64_t nst = (ns_l + 63) >> 6;
+    const int64_t nit = (a.ablate & 262144) ? 0 : (ni_l + 63) >> 6;
+    // Wave roles.  The LDS layout gives the last `n_indel_waves` waves the larger (window-row) scratch; how many of
+    // them actually work on indel tiles follows the class mix of the workgroup's rows (an SNV-only callset has none:
+    // every wave runs the SNP pipeline).  A wave fetches its next tile's row indices, columns and table slices while
+    // it works on the current one.
     const int n_big = v.n_indel_waves, n_small = n_waves - n_big;
     sc.base = L.scratch_b + (uint32_t)(wave < n_small ? wave * v.scratch_bytes : n_small * v.scratch_bytes + (wave - n_small) * v.scratch_indel);
-    const int want_iw = ni > 0 ? (int)((n_waves * ni * 13 + (ns + ni) * 10 - 1) / ((ns + ni) * 10)) : 0;      // ceil(1.3 x share of tiles)
-    const int n_iw = want_iw < n_big ? want_iw : n_big, n_sw = n_waves - n_iw;
+    int n_iw = nit > 0 ? (int)((n_waves * nit + (nst + nit) - 1) / (nst + nit)) : 0;
+    n_iw = n_iw < n_big ? n_iw : n_big;
+    if (nst == 0) n_iw = n_big;
+    const int n_sw = n_waves - n_iw;
     const uint32_t planes_lane_b = sc.base + 2u * (uint32_t)hslot;
-    // A featurize phase is a short instruction stream between long memory waits; the walk is a long stream that waits
-    // on LDS.  Featurize runs at raised priority (kernel variant bit 29 turns that off): it wins the SIMD's issue
-    // arbitration against the walking waves, gets back to walking sooner, and the walkers lose slots they would
-    // mostly have spent waiting.
-    const bool prio = !(v.f.ablate & (1 << 29));
+    const bool joins_on = !(a.ablate & 524288);
     if (wave >= n_sw) {
-        if (prio) __builtin_amdgcn_s_setprio(2);
-        const int64_t stride = (int64_t)gridDim.x * n_iw;
+        const int64_t q = (nit + n_iw - 1) / n_iw;
+        const int64_t t0 = (int64_t)(wave - n_sw) * q, t1 = min(t0 + q, nit);
+        if (t0 >= t1) return;
         PhaseClk pc{};
 #ifdef UGVC_PHASE_CLOCK
         pc.last = __builtin_readcyclecounter();
         const uint64_t t_begin = pc.last;
         int n_done = 0;
 #endif
-        for (int64_t ti = (int64_t)(wave - n_sw) * gridDim.x + blockIdx.x; ti < ni; ti += stride) {
-            const int64_t tile = tile_of(ti, incl_i, v.shard_tiles);
-            const uint32_t id = v.indel_idx[tile * 64 + lane];
-            const bool live = id != ~0u;
+        Brk<NT> bk{};
+        bk.c = -1;
+        IndelPre<NT> pre{};
+        auto ids_of = [&](int64_t t, uint32_t& i, bool& live) {
+            const uint32_t id = li[t * 64 + lane];
+            live = id != ~0u;
             const uint32_t id0 = (uint32_t)rfl((int)id);       // (outside the select: a ternary would read the first PADDING lane)
-            featurize_indel_tile<NTRK>(v, sc, tile, lane, live ? id : id0, live, pc);
+            i = live ? id : id0;
+        };
+        uint32_t i, i_n = 0;
+        bool live, live_n = false;
+        ids_of(t0, i, live);
+        IndelCols cols = load_indel_cols(a, i);
+        if (t0 + 1 < t1) ids_of(t0 + 1, i_n, live_n);
+        for (int64_t t = t0; t < t1; ++t) {
+            // two tiles ahead: row indices; one tile ahead: columns (both in flight during this tile)
+            uint32_t i_n2 = 0;
+            bool live_n2 = false;
+            IndelCols cols_n = cols;
+            if (t + 1 < t1) cols_n = load_indel_cols(a, i_n);
+            uint32_t id_n2 = ~0u;
+            if (t + 2 < t1) id_n2 = li[(t + 2) * 64 + lane];
+            featurize_indel_tile<NTRK>(v, sc, (uint32_t)(blockIdx.x * 7 + t), lane, i, live, cols, bk, pre, pc);
+            if (t + 1 < t1 && joins_on && bk.c >= 0) issue_indel_slices<NTRK>(v, bk, lane, pre);
+            if (t + 2 < t1) {
+                live_n2 = id_n2 != ~0u;
+                const uint32_t id0 = (uint32_t)rfl((int)id_n2);
+                i_n2 = live_n2 ? id_n2 : id0;
+            }
+            cols = cols_n; i = i_n; live = live_n; i_n = i_n2; live_n = live_n2;
             __builtin_amdgcn_wave_barrier();
 #ifdef UGVC_PHASE_CLOCK
             ++n_done;
@@ -1213,66 +1273,61 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
 #endif
         return;
     }
-    const int64_t stride = (int64_t)gridDim.x * n_sw;
-    int64_t ts = (int64_t)wave * gridDim.x + blockIdx.x;
-    if (ts >= ns) return;
-    auto fetch_ids = [&](int64_t vidx, uint32_t& id, uint32_t& i, bool& live) {
-        id = v.snp_idx[tile_of(vidx, incl_s, v.shard_tiles) * 64 + lane];
+    const int64_t q = (nst + n_sw - 1) / n_sw;
+    const int64_t t0 = (int64_t)wave * q, t1 = min(t0 + q, nst);
+    if (t0 >= t1) return;
+    auto ids_of = [&](int64_t t, uint32_t& i, bool& live) {
+        const uint32_t id = ls[t * 64 + lane];
         live = id != ~0u;
         const uint32_t id0 = (uint32_t)rfl((int)id);
         i = live ? id : id0;
     };
-    uint32_t id, i;
+    uint32_t i;
     bool live;
-    fetch_ids(ts, id, i, live);
-    SnpCols cols = load_snp_cols(v.f, i);
-    constexpr int NT = 1 + NTRK;
-    const bool joins_on = !(v.f.ablate & 524288);
-    uint32_t rec = (uint32_t)v.br_snp[tile_of(ts, incl_s, v.shard_tiles) * kRecS5 + (lane & (kRecS5 - 1))];
-    SlicePre<NT> pre;
-    issue_slices<NT>(v, joins_on && (int)__builtin_amdgcn_readlane((int)rec, 7) >= 0 ? rec : 0u, lane, pre);
+    ids_of(t0, i, live);
+    SnpCols cols = load_snp_cols(a, i);
+    Brk<NT> bk{};
+    bk.c = -1;
+    SlicePre<NT> pre{};
     PhaseClk pc{};
 #ifdef UGVC_PHASE_CLOCK
     pc.last = __builtin_readcyclecounter();
     const uint64_t t_begin = pc.last;
     int n_done = 0;
 #endif
-    for (; ts < ns; ts += stride) {
-        const int64_t tile = tile_of(ts, incl_s, v.shard_tiles);
-        const bool more = ts + stride < ns;
+    // A featurize phase is a short instruction stream between long memory waits; the walk is a long stream that waits
+    // on LDS.  (Raised priority for the featurize phase - s_setprio - made no measurable difference: variant bit 29.)
+    const bool prio = !(a.ablate & (1 << 29));
+    for (int64_t t = t0; t < t1; ++t) {
+        const bool more = t + 1 < t1;
         uint32_t id_n = 0, i_n = 0;
         bool live_n = false;
         if (prio) __builtin_amdgcn_s_setprio(2);
-        uint32_t rec_n = 0;
-        if (more) {
-            const int64_t tile_n = tile_of(ts + stride, incl_s, v.shard_tiles);
-            id_n = v.snp_idx[tile_n * 64 + lane];                                                // consumed after the joins
-            rec_n = (uint32_t)v.br_snp[tile_n * kRecS5 + (lane & (kRecS5 - 1))];
-        }
-        featurize_snp_tile<NTRK>(v, sc, tile, lane, i, live, has0, cols, rec, pre, pc);
+        if (more) id_n = ls[(t + 1) * 64 + lane];                // consumed after the joins
+        featurize_snp_tile<NTRK>(v, sc, lane, i, live, has0, cols, bk, pre, pc);
         SnpCols cols_n = cols;
         if (more) {
             live_n = id_n != ~0u;
             const uint32_t id0 = (uint32_t)rfl((int)id_n);
             i_n = live_n ? id_n : id0;
-            cols_n = load_snp_cols(v.f, i_n);                   // in flight during the walk
-            if (joins_on && (int)__builtin_amdgcn_readlane((int)rec_n, 7) >= 0) issue_slices<NT>(v, rec_n, lane, pre);   // likewise
+            cols_n = load_snp_cols(a, i_n);                     // in flight during the walk
+            if (joins_on && bk.c >= 0) issue_slices<NT>(v, bk, lane, pre);   // likewise: from where this tile's last variant ended
         }
         CLK(pc, 4);
         if (prio) __builtin_amdgcn_s_setprio(0);
         if (has0) {
             float score = 0.f;
             uint8_t filt = UGVC_FILTER_PASS;
-            if (!(v.f.ablate & 131072)) walk_forest<NTW>(pg0, L.hi_b, L.last_b, L.p1_b, planes_lane_b, score, filt);
+            if (!(a.ablate & 131072)) walk_forest<NTW>(pg0, L.hi_b, L.last_b, L.p1_b, planes_lane_b, score, filt);
             if (live) {
-                v.f.score[i] = score;
-                v.f.filter[i] = filt;
+                a.score[i] = score;
+                a.filter[i] = filt;
             }
         } else if (live) {                                     // no model for substitutions: score 0, PASS
-            v.f.score[i] = 0.f;
-            v.f.filter[i] = UGVC_FILTER_PASS;
+            a.score[i] = 0.f;
+            a.filter[i] = UGVC_FILTER_PASS;
         }
-        cols = cols_n; i = i_n; live = live_n; rec = rec_n;
+        cols = cols_n; i = i_n; live = live_n;
         __builtin_amdgcn_wave_barrier();
         CLK(pc, 5);
 #ifdef UGVC_PHASE_CLOCK
@@ -1301,6 +1356,7 @@ __global__ __launch_bounds__(kK2Threads) void forest5_kernel(const V5Args v) {
     for (int q = tid; q < UGVC_N_GROUPS * kShards; q += blockDim.x) {
         const unsigned cshard = v.counters[q * kCounterStride];
         if (cshard && q >= kShards) atomicAdd(&totals[q / kShards], cshard);
+        if (blockIdx.x == 0) v.counters_next[q * kCounterStride] = 0;      // the NEXT pass's record lists start empty (two sets, alternating)
     }
     __syncthreads();
     // workgroups are split over the two indel groups in proportion to count x trees x depth
@@ -1459,17 +1515,10 @@ int launch_filter_v5(ugvc_ctx* ctx, const FilterArgs& a) {
         fprintf(stderr, "ok\n");
         return 0;
     };
-    UGVC_HIP(hipMemsetAsync(v.tile_cnt, 0, 2 * kTileShards5 * kTileCntStride5 * 4, ctx->stream));
-    hipLaunchKernelGGL(compact5_kernel, dim3((unsigned)v.n_cblocks), dim3(256), 0, ctx->stream, v);
-    if (step("compact5")) return -1;
-    // real tiles of both classes together: at most one per 64 rows plus one per class and compaction block
-    const int n_act = (a.has_runs ? 1 : 0) + a.n_tracks + (a.n_bl > 0 ? 1 : 0);
-    const int64_t nbr = ((a.n + 63) / 64 + 2 * (int64_t)v.n_cblocks) * 2 * std::max(n_act, 1);
-    hipLaunchKernelGGL(bracket5_kernel, dim3((unsigned)((nbr + 255) / 256)), dim3(256), 0, ctx->stream, v);
-    if (step("bracket5")) return -1;
     const size_t lds_f = lds5_bytes(v, v.n_waves);
     if (dbg) fprintf(stderr, "[ugvc v5] fused5: %d waves (%d indel), %zu B of LDS\n", v.n_waves, v.n_indel_waves, lds_f);
-    hipLaunchKernelGGL(fused5_for(a.n_tracks, (a.ablate & (1 << 28)) != 0), dim3((unsigned)ctx->n_cus), dim3(v.n_waves * 64), lds_f, ctx->stream, v);
+    const unsigned n_wg = (unsigned)((a.n + v.rows_wg - 1) / v.rows_wg);
+    hipLaunchKernelGGL(fused5_for(a.n_tracks, (a.ablate & (1 << 28)) != 0), dim3(n_wg), dim3(v.n_waves * 64), lds_f, ctx->stream, v);
     if (step("fused5")) return -1;
     if (!(a.ablate & 262144) && (v.pg[1].ok || v.pg[2].ok)) {
         int n_waves = 0;

@@ -44,7 +44,9 @@ struct V2Group {
 struct V2State {
     V2Group g[UGVC_N_GROUPS];
     DeviceBuf desc, desc3, lut, thr, css, brackets, brackets3, counters, prof;
-    DeviceBuf snp_idx, indel_idx, tile_cnt, tile_n, br_snp, br_indel, rec5[UGVC_N_GROUPS], eyt;   // v5
+    DeviceBuf snp_idx, indel_idx, counters5, rec5[UGVC_N_GROUPS], eyt;   // v5
+    int c5_set = 0;                          // v5 record counters: two sets, alternating passes
+    bool c5_dirty[2] = {true, true};
     int eyt_off[3] = {0, 0, 0}, eyt_bits[3] = {0, 0, 0}, eyt_len = 0;
     int thr0_len = 0, thr0_bits4[4] = {0, 0, 0, 0};
     std::vector<uint2> h_desc3;
@@ -67,7 +69,7 @@ void v2_destroy(ugvc_ctx* ctx) {
     if (!ctx->v2) return;
     V2State* s = static_cast<V2State*>(ctx->v2);
     DeviceBuf* bufs[] = {&s->desc, &s->desc3, &s->lut, &s->thr, &s->css, &s->brackets, &s->brackets3, &s->counters, &s->prof,
-                         &s->snp_idx, &s->indel_idx, &s->tile_cnt, &s->tile_n, &s->br_snp, &s->br_indel, &s->eyt};
+                         &s->snp_idx, &s->indel_idx, &s->counters5, &s->eyt};
     for (auto* b : bufs) if (b->p) (void)hipFree(b->p);
     for (auto& r : s->rec) if (r.p) (void)hipFree(r.p);
     for (auto& r : s->rec5) if (r.p) (void)hipFree(r.p);
@@ -660,22 +662,35 @@ int v5_fill_args(ugvc_ctx* ctx, V5Args& v, const FilterArgs& a) {
     v.eyt_len = s->eyt_len;
     for (int k = 0; k < 3; ++k) { v.eyt_off[k] = s->eyt_off[k]; v.eyt_bits[k] = s->eyt_bits[k]; }
     v.css_lut = s->css.as<uint8_t>();
-    v.n_cblocks = (int)((n + kCBlock5 - 1) / kCBlock5);
-    // tile slots: every compaction block hands out at most kCBlock5 / 64 + 1 tiles per class, to its own shard
-    v.shard_tiles = ((v.n_cblocks + kTileShards5 - 1) / kTileShards5) * (kCBlock5 / kTile5 + 1);
-    v.max_tiles = kTileShards5 * v.shard_tiles;
-    v.shard_cap5 = ((v.max_tiles + kShards - 1) / kShards) * kTile5;
-    if (ensure(s->snp_idx, (size_t)v.max_tiles * kTile5 * 4) || ensure(s->indel_idx, (size_t)v.max_tiles * kTile5 * 4)) return -1;
-    if (ensure(s->tile_cnt, (size_t)2 * kTileShards5 * kTileCntStride5 * 4) || ensure(s->tile_n, (size_t)v.max_tiles * 2 + 64)) return -1;
-    if (ensure(s->br_snp, (size_t)v.max_tiles * kRecS5 * 4) || ensure(s->br_indel, (size_t)v.max_tiles * kRecI5 * 4)) return -1;
-    if (ensure(s->counters, (size_t)UGVC_N_GROUPS * kShards * kCounterStride * 4)) return -1;
+    // rows per workgroup of the fused kernel: the callset split evenly over the CUs (at least kMinRowsWg5 rows each)
+    v.rows_wg = (int)std::max<int64_t>((n + ctx->n_cus - 1) / ctx->n_cus, kMinRowsWg5);
+    const int64_t n_wg = (n + v.rows_wg - 1) / v.rows_wg;
+    v.list_stride = (v.rows_wg + kTile5 - 1) / kTile5 * kTile5 + kTile5;
+    // record lists: a workgroup's indel tiles go round-robin over the kShards lists of their group
+    const int64_t tiles_wg = v.list_stride / kTile5;
+    v.shard_cap5 = (int)(n_wg * ((tiles_wg + kShards - 1) / kShards) * kTile5);
+    if (ensure(s->snp_idx, (size_t)n_wg * v.list_stride * 4) || ensure(s->indel_idx, (size_t)n_wg * v.list_stride * 4)) return -1;
+    const size_t c5_bytes = (size_t)UGVC_N_GROUPS * kShards * kCounterStride * 4;
+    {
+        const void* before = s->counters5.p;
+        if (ensure(s->counters5, 2 * c5_bytes)) return -1;
+        if (s->counters5.p != before) s->c5_dirty[0] = s->c5_dirty[1] = true;
+    }
     v.snp_idx = s->snp_idx.as<uint32_t>();
     v.indel_idx = s->indel_idx.as<uint32_t>();
-    v.tile_cnt = s->tile_cnt.as<uint32_t>();
-    v.tile_n = s->tile_n.as<uint8_t>();
-    v.br_snp = s->br_snp.as<int32_t>();
-    v.br_indel = s->br_indel.as<int32_t>();
-    v.counters = s->counters.as<uint32_t>();
+    {
+        // the forest kernel of a pass zeroes the set the NEXT pass counts into; a set that missed that (the first two
+        // passes, a pass without indel models in between) is cleared here
+        const int cur = s->c5_set;
+        s->c5_set ^= 1;
+        uint8_t* base = static_cast<uint8_t*>(s->counters5.p);
+        if (s->c5_dirty[cur]) UGVC_HIP(hipMemsetAsync(base + cur * c5_bytes, 0, c5_bytes, ctx->stream));
+        v.counters = reinterpret_cast<uint32_t*>(base + cur * c5_bytes);
+        v.counters_next = reinterpret_cast<uint32_t*>(base + (cur ^ 1) * c5_bytes);
+        const bool forest = !(a.ablate & 262144) && (v.pg[1].ok || v.pg[2].ok);
+        s->c5_dirty[cur] = true;
+        if (forest) s->c5_dirty[cur ^ 1] = false;
+    }
     for (int gi = 1; gi < UGVC_N_GROUPS; ++gi) {
         v.rec5[gi] = nullptr;
         if (!v.pg[gi].ok) continue;
@@ -707,6 +722,15 @@ int v5_fill_args(ugvc_ctx* ctx, V5Args& v, const FilterArgs& a) {
         v.scratch_bytes = (std::max(used * 4, kMaxFeatures * 128) + 63) & ~63;                 // staged slices, then the code planes
         v.scratch_indel = kTile5 * 13 * 4;                                                      // 48-byte window rows, stride 13 dwords
     }
+    // indel tiles span ~64 / (indel share) rows of the callset: a table that puts more than ~100 rows under one gets
+    // the six-rows-per-lane slice (kernels_v5.hip: wide_load)
+    v.iwide = 0;
+    {
+        const double tiles = std::max<double>((double)std::max<int64_t>(ctx->n_indel, 1) / kTile5, 1.0);
+        for (int t = 0; t < 1 + ctx->n_tracks; ++t)
+            if ((double)v.na[t] / tiles > 100.0) v.iwide |= 1u << t;
+        if (const char* e = getenv("UGVC_IWIDE")) v.iwide = (uint32_t)atoi(e);        // (profiling)
+    }
     v.n_indel_waves = 0;
     v.n_waves = v5_fused_waves(v);
     if (v.n_waves == 0) return fail("internal: the SNP forest does not fit the fused kernel's LDS");
@@ -734,7 +758,7 @@ bool v5_available(ugvc_ctx* ctx) {
     if (ctx->has_runs && !ctx->runs_fast) return false;
     for (int t = 0; t < ctx->n_tracks; ++t)
         if (!ctx->trk_fast[t]) return false;
-    if (ctx->n >= ((int64_t)1 << 31) - 4 * kCBlock5 || ctx->n_bl >= ((int64_t)1 << 31)) return false;
+    if (ctx->n >= ((int64_t)1 << 31) - 4096 || ctx->n_bl >= ((int64_t)1 << 31)) return false;
     // LDS: group 0's forest + the thresholds + at least 8 waves of scratch
     const V2Group& g0 = s->g[0];
     size_t forest = 0;

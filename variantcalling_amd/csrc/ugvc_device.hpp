@@ -119,6 +119,7 @@ struct ugvc_ctx {
     } model[UGVC_N_GROUPS];
     // resident variants + results
     int64_t n = 0;
+    int64_t n_indel = 0;          // rows with ref_len != alt_len (counted at upload)
     ugvc::DeviceBuf v_contig, v_pos, v_rl, v_al, v_ro, v_ao, v_alleles, v_qual, v_sor, v_dp,
         v_adr, v_ada, v_gq;
     ugvc::DeviceBuf r_score, r_filter, r_flags, x_mat, x_group;

@@ -90,13 +90,9 @@ struct V2Args {
 // Node word = rank[0:16) | (f * 128)[16:32); forests in the single-sum layout (hi / last / p1).
 constexpr int kRec5Dwords = 12;               // raw record: 20 codes (u16, by feature) | pad | variant index (dword 11)
 constexpr int kTile5 = 64;                    // variants per tile = one wave
-constexpr int kCBlock5 = 1024;                // variants per compaction workgroup
+constexpr int kMinRowsWg5 = 1024;             // a workgroup of the fused kernel owns at least this many rows
 constexpr int kJoin5 = UGVC_MAX_TRACKS + 2;   // runs, tracks, blacklist
-constexpr int kTileShards5 = 64;              // tile-slot counters per variant class (one atomic per compaction block)
-constexpr int kTileCntStride5 = 16;           // dwords between counters (64 bytes)
 constexpr int kGtabBytes = 128;               // LDS: per indel group clamps + float slice descriptors
-constexpr int kRecI5 = 32;                   // ints per indel-tile record of K0
-constexpr int kRecS5 = 32;                   // ints per SNP-tile record of K0 (lower bounds, contig, row ranges)
 constexpr int kBlCap5 = 64;                   // staged blacklist keys per SNP tile
 
 struct V5Args {
@@ -112,21 +108,18 @@ struct V5Args {
     int cap5[UGVC_N_GROUPS][kMaxFeatures];
     uint32_t used5[UGVC_N_GROUPS];       // features a group's forest tests
     const uint8_t* css_lut;
-    uint32_t* snp_idx;                   // tiles of 64 variant indices, ~0u = padding
-    uint32_t* indel_idx;
-    uint32_t* tile_cnt;                  // [class][kTileShards5] x kTileCntStride5: tiles handed out per shard (zeroed before every pass)
-    int shard_tiles;                     // tile slots per shard: tile id = shard * shard_tiles + slot
-    uint8_t* tile_n;                     // real entries per tile: [0, max_tiles) SNP, [max_tiles, 2 max_tiles) indel
-    int32_t* br_snp;                     // [max_tiles][kRecS5]  SNP-tile records: lower bounds of the first variant, contig, row ranges
-    int32_t* br_indel;                   // [max_tiles][kRecI5] indel-tile records: bounds of the first and the last variant, row ranges, contig
+    uint32_t* snp_idx;                   // [workgroup][list_stride] row indices of the workgroup's substitutions, in order; ~0u = padding
+    uint32_t* indel_idx;                 // ... of its indels
+    int rows_wg;                         // consecutive rows a workgroup owns
+    int list_stride;                     // entries per workgroup list (rows_wg rounded up to 64, + 64 of padding)
+    uint32_t iwide;                      // bit t: interval table t is dense enough for the six-rows-per-lane slice under an indel tile
     uint4* rec5[UGVC_N_GROUPS];
-    uint32_t* counters;                  // [UGVC_N_GROUPS][kShards] x kCounterStride
+    uint32_t* counters;                  // [UGVC_N_GROUPS][kShards] x kCounterStride: this pass's record counts
+    uint32_t* counters_next;             // the other set: zeroed by this pass's forest kernel for the next pass
     int shard_cap5;
     int jcap[kJoin5];                    // staged elements per table in the SNP path: 64 or 128 (blacklist: kBlCap5)
     int joff[kJoin5];                    // dword offset of the staged starts (ends follow at + jcap); keys: 2 dwords each
     int na[kJoin5];                      // table lengths
-    int max_tiles;                       // tile slots per class = kTileShards5 * shard_tiles
-    int n_cblocks;
     int scratch_bytes;                   // per-wave LDS scratch of the fused kernel's SNP waves
     int scratch_indel;                   // ... of its indel waves (48-byte window rows)
     int n_waves;
