@@ -2,7 +2,7 @@
 """Headline benchmark: variants/sec filtered on a 5 M-call WGS-shaped callset (BASELINE.json).
 
 Default workload `filter` (config C3): one "step" = one scoring pass over the whole callset - featurize ->
-lookup -> score -> FILTER: the four launches of csrc/kernels_v5.hip (compact5 -> bracket5 -> fused5 -> forest5) -
+lookup -> score -> FILTER: the two launches of csrc/kernels_v5.hip (fused5 -> forest5) -
 on 5 M SNV+indel, 3.1 Gb genome, runs + 3 annotation tracks, 1 M-locus blacklist, 40-tree depth-8 forest per
 variant-type group, inputs already resident in HBM.  With --gpus N > 1 (launched by torch.distributed.run, one
 process per GPU; the ranks rendezvous over plain TCP, variantcalling_amd/dist.py) the SAME callset is cut into N
@@ -38,8 +38,8 @@ ALG_BYTES_SEC = 26.0       # B/call: key 8 + counts 12 + depth columns / flags 6
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_I8_PEAK_TOPS = 5000.0  # dense int8 = the fp8 rate (MI355X_MICROARCH.md)
 MODEL = "rf_model_ignore_gt_incl_hpol_runs"
-PASS_KERNELS = ("one scoring pass = compact5_kernel + bracket5_kernel + fused5_kernel + forest5_kernel "
-                "(csrc/kernels_v5.hip; HIP events around the four launches on the context stream)")
+PASS_KERNELS = ("one scoring pass = fused5_kernel + forest5_kernel "
+                "(csrc/kernels_v5.hip; HIP events around the two launches on the context stream)")
 
 _CPU_JOB = {}
 

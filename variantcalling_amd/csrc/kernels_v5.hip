@@ -209,10 +209,11 @@ __device__ __forceinline__ int join_one_global(const FilterArgs* ap, int t, int 
     return rank;
 }
 
-// Indel tiles cover ~5x the span of an SNP tile, so their slices are staged per table: rows [lo - 2, hi + 2) between
-// the lower bounds of the tile's first and last variant (K0's record) - at most kIndelRows - in registers first
-// (fetched from the record alone, under the column / window chain of the tile), then into the wave's scratch two
-// tables at a time once the window rows are dead.  A bracket wider than that is searched in HBM (join_one_global).
+// Indel tiles cover ~5x the span of an SNP tile, so their slices are staged per table, from two rows before the
+// carried rank: two rows per lane (kIndelRows), fetched into registers one tile ahead and written to the wave's
+// scratch two tables at a time once the window rows are dead; six rows per lane for a table the host marks dense
+// (V5Args::iwide), fetched at the joins.  A slice whose last row does not reach the tile's last variant is searched
+// in HBM instead (join_one_global).
 // (Measured and dropped: the same searches as dependent gathers on the resident tables - binary: nine round trips per
 // tile; 8-ary: three, but 105 scattered 64-lane gathers instead of 45, no faster.)
 constexpr int kIndelRows = 128;                     // staged rows per table (two per lane); 127 searchable + sentinel

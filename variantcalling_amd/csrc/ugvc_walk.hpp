@@ -61,7 +61,7 @@ __device__ __forceinline__ bool table_present(const FilterArgs& f, int t) {
 
 // Two-level lower bound: the 1/64 sample `coarse` (coarse[k] = a[64 k], L2-resident) narrows [lo, hi) to one
 // 64-element block, the block itself is finished by binary search: ~16 L2-hit steps + 6 steps on two cache lines
-// instead of 22 steps of HBM latency.  (8-ary steps - seven probes issued together - measured in K0 of the v5 pass:
+// instead of 22 steps of HBM latency.  (8-ary steps - seven probes issued together - measured in the per-tile bracket kernel the v5 pass had in round 2:
 // 48 us instead of 33; the searches are bound by the number of scattered gathers, not by the length of the chain.)
 template <class T>
 __device__ __forceinline__ int lb_two_level_g(const T* __restrict__ a, const T* __restrict__ coarse, int lo, int hi, T key) {
