@@ -103,7 +103,8 @@ def test_train_then_filter(tmp_path):
     h5.write_hdf(str(tmp_path / "labelled.h5"), {"chr_a": scored})
     prefix2 = str(tmp_path / "test.model2")
     rc = train_models_pipeline.run(["train_models_pipeline", "--input_file", str(tmp_path / "labelled.h5"), "--reference", d["fa"],
-                                    "--runs_intervals", d["runs"], "--flow_order", "TGCA", "--output_file_prefix", prefix2] + d["ann"])
+                                    "--runs_intervals", d["runs"], "--flow_order", "TGCA", "--output_file_prefix", prefix2,
+                                    "--ignore_filter_status"] + d["ann"])        # (the frame carries round one's FILTER tags)
     assert rc == 0
     res2 = h5.read_hdf(prefix2 + ".h5", "training_set")
     assert np.array_equal(res2["label"], res["label"]) and np.array_equal(res2["pos"], res["pos"])
