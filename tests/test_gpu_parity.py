@@ -184,6 +184,36 @@ def test_sliced_context_equals_full(engine, small_callset, frozen_models, world)
         assert np.array_equal(got.tree_score, whole.tree_score[lo:hi])
 
 
+def test_v5_many_small_contigs_and_row_counts(engine, frozen_models):
+    """The v5 pass carries a wave's table ranks from tile to tile and searches afresh at contig changes: 400 contigs of a
+    few dozen variants each (most tiles span contigs), and callset sizes around the workgroup / tile granularity."""
+    from variantcalling_amd import synth
+    O = _oracle()
+    cs = synth.make_callset(24_000, genome_len=6_000_000, n_contigs=400, seed=77)
+    _configure(engine, cs.ref, cs.runs, cs.tracks, cs.blacklist, frozen_models[RF])
+    exp = O.filter_variants(cs.variants, cs.ref, cs.runs, cs.tracks, cs.blacklist, frozen_models[RF])
+    _assert_same(engine.filter_variants(cs.variants), exp, "400 contigs")
+    for n in (1, 63, 64, 65, 1023, 1024, 1025, 2049, 4097):
+        sub = cs.variants.slice(5000, 5000 + n)
+        got = engine.filter_variants(sub)
+        assert np.array_equal(got.flags, exp.flags[5000:5000 + n]) and np.array_equal(got.filter, exp.filter[5000:5000 + n]), n
+        assert np.array_equal(got.tree_score, exp.tree_score[5000:5000 + n]), n
+
+
+@pytest.mark.parametrize("iwide", ["0", "15"], ids=["narrow-slices", "wide-slices"])
+def test_v5_indel_slice_widths_agree(engine, small_callset, frozen_models, iwide, monkeypatch):
+    """Indel tiles stage two rows per lane of a sparse table and six of a dense one (chosen from the table sizes); a
+    slice that does not reach the tile's last variant falls back to a search in HBM.  Forcing every table narrow (the
+    dense track then takes the fallback on most tiles) or wide must not change a bit."""
+    O = _oracle()
+    cs = small_callset
+    _configure(engine, cs.ref, cs.runs, cs.tracks, cs.blacklist, frozen_models[RF])
+    exp = O.filter_variants(cs.variants, cs.ref, cs.runs, cs.tracks, cs.blacklist, frozen_models[RF])
+    monkeypatch.setenv("UGVC_IWIDE", iwide)
+    _assert_same(engine.filter_variants(cs.variants), exp, f"UGVC_IWIDE={iwide}")
+    assert engine.filter_variants(cs.variants).filter.tobytes() == exp.filter.tobytes()      # second pass: the other counter set
+
+
 def test_empty_no_tables_and_ragged(engine, small_callset, frozen_models):
     from variantcalling_amd.engine import Engine
     O = _oracle()
