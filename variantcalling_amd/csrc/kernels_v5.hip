@@ -1347,6 +1347,11 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
 // ---- K2: the indel groups' forests over the raw-code records ---------------------------------------------
 __global__ __launch_bounds__(kK2Threads) void forest5_kernel(const V5Args v) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef UGVC_PHASE_CLOCK
+    const uint64_t f_begin = __builtin_readcyclecounter();
+    uint64_t f_ready = 0, f_walk = 0, f_last = 0;
+    int f_chunks = 0;
+#endif
     __shared__ unsigned shard_off[kShards + 1];
     __shared__ unsigned totals[UGVC_N_GROUPS];
     const int tid = threadIdx.x;
@@ -1442,6 +1447,9 @@ __global__ __launch_bounds__(kK2Threads) void forest5_kernel(const V5Args v) {
         const uint4* src = rec + ((size_t)lo * v.shard_cap5 + (rr - shard_off[lo])) * 3;
         r0 = src[0]; r1 = src[1]; r2 = src[2];
     };
+#ifdef UGVC_PHASE_CLOCK
+    f_ready = __builtin_readcyclecounter();
+#endif
     unsigned chunk = (unsigned)rfl(wave) * (unsigned)nbg + (unsigned)lb;
     bool live_next = false;
     uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0, n2 = n0;
@@ -1459,12 +1467,24 @@ __global__ __launch_bounds__(kK2Threads) void forest5_kernel(const V5Args v) {
         }
         float score;
         uint8_t filt;
+#ifdef UGVC_PHASE_CLOCK
+        f_last = __builtin_readcyclecounter();
+#endif
         walk_forest<8>(pg, hi_b, last_b, p1_b, planes_lane_b, score, filt);
+#ifdef UGVC_PHASE_CLOCK
+        f_walk += __builtin_readcyclecounter() - f_last;
+        ++f_chunks;
+#endif
         if (live) {
             v.f.score[q2.w] = score;
             v.f.filter[q2.w] = filt;
         }
     }
+#ifdef UGVC_PHASE_CLOCK
+    if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 200) && (wave == 0 || wave == 15))
+        printf("fclk b%d w%d g%d: ready after %llu cycles, %d chunks, walk %llu, total %llu\n", (int)blockIdx.x, wave, g,
+               (unsigned long long)(f_ready - f_begin), f_chunks, (unsigned long long)f_walk, (unsigned long long)(__builtin_readcyclecounter() - f_begin));
+#endif
 }
 
 static size_t k5_forest_lds(const PackedGroupView& pg, int n_waves) {
