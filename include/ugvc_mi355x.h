@@ -172,7 +172,9 @@ int ugvc_host_css_lut(const char* flow4, uint8_t out[256]);
  *   256  v1 universal fused kernel                                       1024 pair-sum forest kernel (v3)
  *   2048 16 trees in flight in the forest kernel (v3)                    65536 v3 kernels instead of v5
  *   bits 12-13 v3 featurize workgroups per CU (1..3; 0 = 4)              bits 14-15 v3 forest waves (1: 12, 2: 8, 3: 4; 0 = 16)
- *   v5 profiling (results WRONG / partial): 131072 no SNP walk, 262144 no indel pass, 524288 no joins */
+ *   v5 profiling (results WRONG / partial): 131072 no SNP walk, 262144 no indel tiles, 524288 no side-table joins;
+ *   (results unchanged) bits 24-27: waves per workgroup that may take indel tiles (0 = a quarter), bit 28: 8 instead of
+ *   16 trees in flight (3-track kernel), bit 29: no s_setprio */
 int ugvc_set_kernel_variant(ugvc_ctx* ctx, int variant);
 /* Profiling aid: core-clock cycles wave 0 of every featurize workgroup spent between the kernel's phase
  * boundaries (kernel variant bit 6 turns the clocks on), summed over workgroups and launches since the
