@@ -105,7 +105,8 @@ def replay_filter_fixtures(root: str, out_dir: str, model_files=("exact_gt.model
                 if blacklist:
                     argv += ["--blacklist", os.path.join(d, blacklist)]
                 filter_variants_pipeline.run(argv)
-                recs = [ln.split("\\t") for ln in pyvcf.open_text(out).read().splitlines() if ln and not ln.startswith("#")]
+                with pyvcf._open(out) as fh:
+                    recs = [ln.split("\t") for ln in fh.read().decode().splitlines() if ln and not ln.startswith("#")]
                 filt = [r[6] for r in recs]
                 report["runs"].append(dict(model_file=mf, model=name, vcf=v, records=len(recs),
                                            PASS=sum(f == "PASS" for f in filt), LOW_SCORE=sum("LOW_SCORE" in f for f in filt),
