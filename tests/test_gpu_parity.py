@@ -200,16 +200,20 @@ def test_v5_many_small_contigs_and_row_counts(engine, frozen_models):
         assert np.array_equal(got.tree_score, exp.tree_score[5000:5000 + n]), n
 
 
+@pytest.mark.parametrize("rounds", [False, True], ids=["one-round", "pair-rounds"])
 @pytest.mark.parametrize("iwide", ["0", "15"], ids=["narrow-slices", "wide-slices"])
-def test_v5_indel_slice_widths_agree(engine, small_callset, frozen_models, iwide, monkeypatch):
+def test_v5_indel_slice_widths_agree(engine, small_callset, frozen_models, iwide, rounds, monkeypatch):
     """Indel tiles stage two rows per lane of a sparse table and six of a dense one (chosen from the table sizes); a
     slice that does not reach the tile's last variant falls back to a search in HBM.  Forcing every table narrow (the
-    dense track then takes the fallback on most tiles) or wide must not change a bit."""
+    dense track then takes the fallback on most tiles) or wide, and staging the narrow slices all at once or in pairs,
+    must not change a bit."""
     O = _oracle()
     cs = small_callset
     _configure(engine, cs.ref, cs.runs, cs.tracks, cs.blacklist, frozen_models[RF])
     exp = O.filter_variants(cs.variants, cs.ref, cs.runs, cs.tracks, cs.blacklist, frozen_models[RF])
     monkeypatch.setenv("UGVC_IWIDE", iwide)
+    if rounds:
+        monkeypatch.setenv("UGVC_INDEL_ROUNDS", "1")          # narrow slices staged two tables at a time (the smaller scratch)
     _assert_same(engine.filter_variants(cs.variants), exp, f"UGVC_IWIDE={iwide}")
     assert engine.filter_variants(cs.variants).filter.tobytes() == exp.filter.tobytes()      # second pass: the other counter set
 

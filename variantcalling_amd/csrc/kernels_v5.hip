@@ -245,13 +245,19 @@ __device__ __forceinline__ void stage_rows(uint32_t slot_b, int L0, int plo, int
     }
 }
 
-__device__ __forceinline__ int staged_verdict(const FilterArgs& a, uint32_t slot_b, int t, int L0, int plo, int phi, int pos, JoinOut& o) {
+__device__ __forceinline__ int staged_verdict_at(const FilterArgs& a, uint32_t slot_b, int t, int L0, int plo, int phi, int pos, uint32_t rank,
+                                                 JoinOut& o) {
     if (phi <= plo) return plo;
-    const int sg = L0 + (int)staged_rank(slot_b, pos);
+    const int sg = L0 + (int)rank;
     auto S = [&](int gi) { return lds_i32(slot_b + 4u * (uint32_t)(gi - L0)); };
     auto E = [&](int gi) { return lds_i32(slot_b + 512u + 4u * (uint32_t)(gi - L0)); };
     interval_verdict(t, sg, plo, phi, pos, a.hpol_dist, S, E, o);
     return sg;
+}
+
+__device__ __forceinline__ int staged_verdict(const FilterArgs& a, uint32_t slot_b, int t, int L0, int plo, int phi, int pos, JoinOut& o) {
+    if (phi <= plo) return plo;
+    return staged_verdict_at(a, slot_b, t, L0, plo, phi, pos, staged_rank(slot_b, pos), o);
 }
 
 // A table too dense for the two-rows-per-lane slice (a 3 M-interval track under a 220 kb indel tile: ~210 rows):
@@ -873,8 +879,60 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
             if (covers(slot + 4u * (kIndelRows - 1))) sg_l[t] = staged_verdict(a, slot, t, bk.L[t] - 2, bk.plo[t], bk.phi[t], pos, jo);
             else sg_l[t] = join_one_global(&a, t, max(bk.L[t], bk.plo[t]), bk.phi[t], bk.plo[t], bk.phi[t], pos, key, &jo);
         };
-        // round A: runs | blacklist
         const bool bl_on = a.n_bl > 0;
+        if (v.indel_one_round) {
+            // every narrow slice and the blacklist keys side by side (1 KB each), ranked in lock-step
+            uint32_t slot[NT], p[NT];
+            uint32_t nslot = 0;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                slot[t] = s0;
+                if (!on(t) || is_wide(t)) continue;
+                slot[t] = s0 + kIndelSlotB * nslot++;
+                stage_rows(slot[t], bk.L[t] - 2, bk.plo[t], bk.phi[t], pre.sv[t], pre.ev[t], lane);
+            }
+            const uint32_t sb_b = s0 + kIndelSlotB * nslot;
+            if (bl_on) {
+                lds_st64(sb_b + 8u * lane, pre.bl[0]);
+                lds_st64(sb_b + 512u + 8u * lane, pre.bl[1]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            uint32_t pb = sb_b - 8u;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) p[t] = slot[t] - 4u;
+#pragma unroll
+            for (int sb = 256; sb >= 4; sb >>= 1) {
+                uint32_t cand[NT];
+                int x[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    cand[t] = p[t] + (uint32_t)sb;
+                    x[t] = (on(t) && !is_wide(t)) ? lds_i32(cand[t]) : 0;
+                }
+                const uint32_t cb = pb + 2u * (uint32_t)sb;
+                const uint64_t xk = bl_on ? lds_u64(cb) : 0ull;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) p[t] = x[t] < pos ? cand[t] : p[t];
+                pb = xk < key ? cb : pb;
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (!on(t) || is_wide(t)) continue;
+                if (covers(slot[t] + 4u * (kIndelRows - 1)))
+                    sg_l[t] = staged_verdict_at(a, slot[t], t, bk.L[t] - 2, bk.plo[t], bk.phi[t], pos, (p[t] + 4u - slot[t]) >> 2, jo);
+                else sg_l[t] = join_one_global(&a, t, max(bk.L[t], bk.plo[t]), bk.phi[t], bk.plo[t], bk.phi[t], pos, key, &jo);
+            }
+            if (bl_on) {
+                const uint64_t key_max = ((uint64_t)(uint32_t)c0 << 32) | (uint32_t)pos_max;
+                if (__ballot(lds_u64(sb_b + 8u * (kIndelRows - 1)) < key_max) == 0) {
+                    if (lds_u64(pb + 8u) == key) jo.cohort = true;
+                    rb_l = bk.Lb + (int)((pb + 8u - sb_b) >> 3);
+                } else rb_l = join_one_global(&a, kJoin5 - 1, bk.Lb, (int)a.n_bl, 0, 0, pos, key, &jo);
+            }
+        } else {
+        // round A: runs | blacklist
         __builtin_amdgcn_wave_barrier();
         if (on(0) && !is_wide(0)) stage_rows(s0, bk.L[0] - 2, bk.plo[0], bk.phi[0], pre.sv[0], pre.ev[0], lane);
         if (bl_on) {
@@ -909,6 +967,7 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
             __builtin_amdgcn_wave_barrier();
             if (!is_wide(t)) narrow(s0, t);
             if (t + 1 < NT && !is_wide(t2)) narrow(s1, t2);
+        }
         }
         // the dense tables: six rows per lane, the whole scratch, one at a time
 #pragma unroll

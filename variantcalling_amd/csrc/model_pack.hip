@@ -741,6 +741,21 @@ int v5_fill_args(ugvc_ctx* ctx, V5Args& v, const FilterArgs& a) {
     if (v5_fused_waves(v) < v.n_waves) v.n_waves = v5_fused_waves(v);   // (the indel waves' larger scratch)
     if (v.n_waves == 0) return fail("internal: the SNP forest does not fit the fused kernel's LDS");
     if (v.n_indel_waves >= v.n_waves) v.n_indel_waves = v.n_waves - 1;
+    // indel tiles: all two-rows-per-lane slices (1 KB each) and the blacklist keys (1 KB) side by side in the wave's
+    // scratch if the LDS has room for that at the same number of waves - one staging round instead of one per pair
+    v.indel_one_round = 0;
+    {
+        int n_narrow = 0;
+        for (int t = 0; t < 1 + ctx->n_tracks; ++t)
+            if (!(t == 0 && !ctx->has_runs) && !((v.iwide >> t) & 1)) ++n_narrow;
+        const int want = 1024 * (n_narrow + (ctx->n_bl > 0 ? 1 : 0));
+        if (want > v.scratch_indel && !getenv("UGVC_INDEL_ROUNDS")) {
+            const int keep = v.scratch_indel;
+            v.scratch_indel = want;
+            if (v5_fused_waves(v) >= v.n_waves) v.indel_one_round = 1;
+            else v.scratch_indel = keep;
+        } else if (want <= v.scratch_indel && !getenv("UGVC_INDEL_ROUNDS")) v.indel_one_round = 1;
+    }
     return 0;
 }
 
