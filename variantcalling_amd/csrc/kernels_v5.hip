@@ -384,7 +384,7 @@ __device__ __forceinline__ SnpCols load_snp_cols(const FilterArgs& a, uint32_t i
     return k;
 }
 
-// The side-table slices of one SNP tile, in registers: fetched from the tile record alone, one tile ahead (they are
+// The side-table slices of one SNP tile, in registers: fetched from the carried ranks alone, one tile ahead (they are
 // in flight during the previous tile's walk and are written to the wave's LDS scratch when that walk has finished
 // with its code planes).  They start at the ranks the previous tile's last variant ended at (Brk).
 template <int NT>
