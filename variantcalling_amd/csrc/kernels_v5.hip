@@ -55,6 +55,15 @@ __device__ __forceinline__ void lds_st64(uint32_t a, uint64_t x) { *(UGVC_LDS ui
 __device__ __forceinline__ void lds_st16(uint32_t a, uint32_t x) { *(UGVC_LDS uint16_t*)(uintptr_t)a = (uint16_t)x; }
 __device__ __forceinline__ uint32_t lds_u8(uint32_t a) { return *(UGVC_LDS const uint8_t*)(uintptr_t)a; }
 
+// Element `idx` of a resident array through `SGPR base + 32-bit byte offset` addressing (one 32-bit shift instead of
+// 64-bit address arithmetic per lane): every array of this pass is shorter than 4 GiB (v5_available checks the row counts).
+template <class T> __device__ __forceinline__ T ldg32(const T* base, uint32_t idx) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (uint32_t)(idx * (uint32_t)sizeof(T)));
+}
+template <class T> __device__ __forceinline__ void stg32(T* base, uint32_t idx, T x) {
+    *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + (uint32_t)(idx * (uint32_t)sizeof(T))) = x;
+}
+
 constexpr int kGcRank = 121;         // gc_content takes 121 values (count / len, len and count in 0..10): its rank code is a table
 constexpr int kGcRankBytes = 768;    // 3 groups x 121 u16, padded
 constexpr int kWinRowB = kWinStride * 4;
@@ -269,7 +278,7 @@ __device__ __forceinline__ void wide_load(const TrackView& tv, int L0, int top, 
 #pragma unroll
     for (int h = 0; h < kWideChunks; ++h) {
         const uint32_t gs = (uint32_t)max(min(L0 + 64 * h + lane, top), 0);
-        wv[h] = tv.starts[gs]; we[h] = tv.ends[gs];
+        wv[h] = ldg32(tv.starts, gs); we[h] = ldg32(tv.ends, gs);
     }
 }
 
@@ -377,10 +386,10 @@ struct SnpCols {                    // the columns of one substitution (fetched 
 
 __device__ __forceinline__ SnpCols load_snp_cols(const FilterArgs& a, uint32_t i) {
     SnpCols k;
-    k.c = a.contig[i]; k.pos = a.pos[i]; k.rl = a.ref_len[i];
-    k.ro = a.ref_off[i]; k.ao = a.alt_off[i];
-    k.qual = a.qual[i]; k.sor = a.sor[i];
-    k.dp = a.dp[i]; k.adr = a.ad_ref[i]; k.ada = a.ad_alt[i]; k.gq = a.gq[i];
+    k.c = ldg32(a.contig, i); k.pos = ldg32(a.pos, i); k.rl = ldg32(a.ref_len, i);
+    k.ro = ldg32(a.ref_off, i); k.ao = ldg32(a.alt_off, i);
+    k.qual = ldg32(a.qual, i); k.sor = ldg32(a.sor, i);
+    k.dp = ldg32(a.dp, i); k.adr = ldg32(a.ad_ref, i); k.ada = ldg32(a.ad_alt, i); k.gq = ldg32(a.gq, i);
     return k;
 }
 
@@ -406,16 +415,16 @@ __device__ __forceinline__ void issue_slices(const V5Args& v, const Brk<NT>& bk,
         const int top = max(v.na[t] - 1, 0);
         {
             const uint32_t gs = (uint32_t)max(min(Lt + lane, top), 0);
-            s.sv[t][0] = tv.starts[gs]; s.ev[t][0] = tv.ends[gs];
+            s.sv[t][0] = ldg32(tv.starts, gs); s.ev[t][0] = ldg32(tv.ends, gs);
         }
         if (v.jcap[t] > 64) {
             const uint32_t gs = (uint32_t)max(min(Lt + 64 + lane, top), 0);
-            s.sv[t][1] = tv.starts[gs]; s.ev[t][1] = tv.ends[gs];
+            s.sv[t][1] = ldg32(tv.starts, gs); s.ev[t][1] = ldg32(tv.ends, gs);
         }
     }
     if (a.n_bl > 0) {
         const int64_t gi = (int64_t)bk.Lb + lane;
-        if (gi < a.n_bl) s.bl = a.bl[gi];
+        if (gi < a.n_bl) s.bl = ldg32(a.bl, (uint32_t)gi);
     }
 }
 
@@ -580,7 +589,7 @@ __device__ __forceinline__ void featurize_snp_tile(const V5Args& v, const Scratc
     uint8_t flags = (uint8_t)(jo.trk << UGVC_FLAG_TRACK0_SHIFT);
     if (jo.cohort) flags |= UGVC_FLAG_COHORT_FP;
     if (a.mark_hpol && (jo.inside_run || jo.close_run)) flags |= UGVC_FLAG_HPOL_RUN;
-    if (live) a.flags[i] = flags;
+    if (live) stg32(a.flags, i, flags);
     CLK(pc, 2);
     if (!has_model) return;
     // (the window gather is consumed here, behind the joins: its round trip hides under the rank / join work)
@@ -675,7 +684,7 @@ __device__ __forceinline__ void issue_indel_slices(const V5Args& v, const Brk<1 
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const uint32_t gs = (uint32_t)max(min(bk.L[t] - 2 + 64 * h + lane, top), 0);
-            pre.sv[t][h] = tv.starts[gs]; pre.ev[t][h] = tv.ends[gs];
+            pre.sv[t][h] = ldg32(tv.starts, gs); pre.ev[t][h] = ldg32(tv.ends, gs);
         }
     }
     pre.bl[0] = pre.bl[1] = ~0ull;
@@ -683,7 +692,7 @@ __device__ __forceinline__ void issue_indel_slices(const V5Args& v, const Brk<1 
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int64_t gi = (int64_t)bk.Lb + 64 * h + lane;
-            if (gi < a.n_bl) pre.bl[h] = a.bl[gi];
+            if (gi < a.n_bl) pre.bl[h] = ldg32(a.bl, (uint32_t)gi);
         }
     }
 }
@@ -697,10 +706,10 @@ struct IndelCols {                  // the columns of one indel (fetched one til
 
 __device__ __forceinline__ IndelCols load_indel_cols(const FilterArgs& a, uint32_t i) {
     IndelCols k;
-    k.c = a.contig[i]; k.pos = a.pos[i]; k.rl = a.ref_len[i]; k.al = a.alt_len[i];
-    k.ro = a.ref_off[i]; k.ao = a.alt_off[i];
-    k.qual = a.qual[i]; k.sor = a.sor[i];
-    k.dp = a.dp[i]; k.adr = a.ad_ref[i]; k.ada = a.ad_alt[i]; k.gq = a.gq[i];
+    k.c = ldg32(a.contig, i); k.pos = ldg32(a.pos, i); k.rl = ldg32(a.ref_len, i); k.al = ldg32(a.alt_len, i);
+    k.ro = ldg32(a.ref_off, i); k.ao = ldg32(a.alt_off, i);
+    k.qual = ldg32(a.qual, i); k.sor = ldg32(a.sor, i);
+    k.dp = ldg32(a.dp, i); k.adr = ldg32(a.ad_ref, i); k.ada = ldg32(a.ad_alt, i); k.gq = ldg32(a.gq, i);
     return k;
 }
 
@@ -996,7 +1005,7 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
     uint8_t flags = (uint8_t)(jo.trk << UGVC_FLAG_TRACK0_SHIFT);
     if (jo.cohort) flags |= UGVC_FLAG_COHORT_FP;
     if (a.mark_hpol && (jo.inside_run || jo.close_run)) flags |= UGVC_FLAG_HPOL_RUN;
-    if (live) a.flags[i] = flags;
+    if (live) stg32(a.flags, i, flags);
     CLK(pc, 2);
     // ---- codes of the lane's own group
     const float vaf = dp > 0 ? __fdiv_rn((float)ada, (float)dp) : 0.0f;
@@ -1380,12 +1389,12 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
             uint8_t filt = UGVC_FILTER_PASS;
             if (!(a.ablate & 131072)) walk_forest<NTW>(pg0, L.hi_b, L.last_b, L.p1_b, planes_lane_b, score, filt);
             if (live) {
-                a.score[i] = score;
-                a.filter[i] = filt;
+                stg32(a.score, i, score);
+                stg32(a.filter, i, filt);
             }
         } else if (live) {                                     // no model for substitutions: score 0, PASS
-            a.score[i] = 0.f;
-            a.filter[i] = UGVC_FILTER_PASS;
+            stg32(a.score, i, 0.f);
+            stg32(a.filter, i, (uint8_t)UGVC_FILTER_PASS);
         }
         cols = cols_n; i = i_n; live = live_n;
         __builtin_amdgcn_wave_barrier();

@@ -773,7 +773,11 @@ bool v5_available(ugvc_ctx* ctx) {
     if (ctx->has_runs && !ctx->runs_fast) return false;
     for (int t = 0; t < ctx->n_tracks; ++t)
         if (!ctx->trk_fast[t]) return false;
-    if (ctx->n >= ((int64_t)1 << 31) - 4096 || ctx->n_bl >= ((int64_t)1 << 31)) return false;
+    // 32-bit byte offsets into every resident array (ldg32): rows x element size stay below 4 GiB
+    if (ctx->n >= ((int64_t)1 << 30) || ctx->n_bl >= ((int64_t)1 << 29)) return false;
+    if (ctx->has_runs && ctx->runs_n >= ((int64_t)1 << 30)) return false;
+    for (int t = 0; t < ctx->n_tracks; ++t)
+        if (ctx->trk_n[t] >= ((int64_t)1 << 30)) return false;
     // LDS: group 0's forest + the thresholds + at least 8 waves of scratch
     const V2Group& g0 = s->g[0];
     size_t forest = 0;
