@@ -1313,16 +1313,20 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
         ids_of(t0, i, live);
         IndelCols cols = load_indel_cols(a, i);
         if (t0 + 1 < t1) ids_of(t0 + 1, i_n, live_n);
+        const UGVC_CONST V5Args* const vk = (const UGVC_CONST V5Args*)__builtin_amdgcn_kernarg_segment_ptr();
         for (int64_t t = t0; t < t1; ++t) {
+            const UGVC_CONST V5Args* vq = vk;                   // (launch arguments re-read per tile, as in the SNP loop below)
+            asm volatile("" : "+s"(vq));
+            const V5Args& vt = *(const V5Args*)vq;
             // two tiles ahead: row indices; one tile ahead: columns (both in flight during this tile)
             uint32_t i_n2 = 0;
             bool live_n2 = false;
             IndelCols cols_n = cols;
-            if (t + 1 < t1) cols_n = load_indel_cols(a, i_n);
+            if (t + 1 < t1) cols_n = load_indel_cols(vt.f, i_n);
             uint32_t id_n2 = ~0u;
             if (t + 2 < t1) id_n2 = li[(t + 2) * 64 + lane];
-            featurize_indel_tile<NTRK>(v, sc, (uint32_t)(blockIdx.x * 7 + t), lane, i, live, cols, bk, pre, pc);
-            if (t + 1 < t1 && joins_on && bk.c >= 0) issue_indel_slices<NTRK>(v, bk, lane, pre);
+            featurize_indel_tile<NTRK>(vt, sc, (uint32_t)(blockIdx.x * 7 + t), lane, i, live, cols, bk, pre, pc);
+            if (t + 1 < t1 && joins_on && bk.c >= 0) issue_indel_slices<NTRK>(vt, bk, lane, pre);
             if (t + 2 < t1) {
                 live_n2 = id_n2 != ~0u;
                 const uint32_t id0 = (uint32_t)rfl((int)id_n2);
@@ -1367,34 +1371,42 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
     // A featurize phase is a short instruction stream between long memory waits; the walk is a long stream that waits
     // on LDS.  (Raised priority for the featurize phase - s_setprio - made no measurable difference: variant bit 29.)
     const bool prio = !(a.ablate & (1 << 29));
+    const UGVC_CONST V5Args* const vk = (const UGVC_CONST V5Args*)__builtin_amdgcn_kernarg_segment_ptr();
     for (int64_t t = t0; t < t1; ++t) {
+        // The launch arguments are read afresh in every tile (the pointer passes through an empty asm): hoisted out of
+        // the loop they would sit in ~100 SGPRs, spill to VGPR lanes and come back as v_readlane - vector-ALU work, which
+        // is what this kernel is short of; scalar loads from the constant cache are not.
+        const UGVC_CONST V5Args* vq = vk;
+        asm volatile("" : "+s"(vq));
+        const V5Args& vt = *(const V5Args*)vq;
+        const FilterArgs& at = vt.f;
         const bool more = t + 1 < t1;
         uint32_t id_n = 0, i_n = 0;
         bool live_n = false;
         if (prio) __builtin_amdgcn_s_setprio(2);
         if (more) id_n = ls[(t + 1) * 64 + lane];                // consumed after the joins
-        featurize_snp_tile<NTRK>(v, sc, lane, i, live, has0, cols, bk, pre, pc);
+        featurize_snp_tile<NTRK>(vt, sc, lane, i, live, has0, cols, bk, pre, pc);
         SnpCols cols_n = cols;
         if (more) {
             live_n = id_n != ~0u;
             const uint32_t id0 = (uint32_t)rfl((int)id_n);
             i_n = live_n ? id_n : id0;
-            cols_n = load_snp_cols(a, i_n);                     // in flight during the walk
-            if (joins_on && bk.c >= 0) issue_slices<NT>(v, bk, lane, pre);   // likewise: from where this tile's last variant ended
+            cols_n = load_snp_cols(at, i_n);                    // in flight during the walk
+            if (joins_on && bk.c >= 0) issue_slices<NT>(vt, bk, lane, pre);   // likewise: from where this tile's last variant ended
         }
         CLK(pc, 4);
         if (prio) __builtin_amdgcn_s_setprio(0);
         if (has0) {
             float score = 0.f;
             uint8_t filt = UGVC_FILTER_PASS;
-            if (!(a.ablate & 131072)) walk_forest<NTW>(pg0, L.hi_b, L.last_b, L.p1_b, planes_lane_b, score, filt);
+            if (!(at.ablate & 131072)) walk_forest<NTW>(vt.pg[0], L.hi_b, L.last_b, L.p1_b, planes_lane_b, score, filt);
             if (live) {
-                stg32(a.score, i, score);
-                stg32(a.filter, i, filt);
+                stg32(at.score, i, score);
+                stg32(at.filter, i, filt);
             }
         } else if (live) {                                     // no model for substitutions: score 0, PASS
-            stg32(a.score, i, 0.f);
-            stg32(a.filter, i, (uint8_t)UGVC_FILTER_PASS);
+            stg32(at.score, i, 0.f);
+            stg32(at.filter, i, (uint8_t)UGVC_FILTER_PASS);
         }
         cols = cols_n; i = i_n; live = live_n;
         __builtin_amdgcn_wave_barrier();
