@@ -17,7 +17,9 @@
 //     resident flags column, so the gathered callset carries it.
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
 #include <cmath>
+#include <stdlib.h>
 #include <vector>
 
 #include "ugvc_device.hpp"
@@ -100,6 +102,138 @@ __global__ __launch_bounds__(256) void sec_apply_kernel(const uint16_t* __restri
     if (ratio) ratio[i] = r;
     if (is_sec) is_sec[i] = hit;
     if (flags && hit) flags[i] |= UGVC_FLAG_SEC;
+}
+
+// sec_log_pmf2 with log(x_i + 1), log(e_i + 1) and the logs of the two totals from a table of log(m) (every argument is a
+// small integer): log((e + 1) / tot) = log(e + 1) - log(tot) up to f64 rounding - eight libm logs per call become loads
+__device__ __forceinline__ double sec_log_int(const double* __restrict__ tab, long long m) {
+    return m <= kSecLgTab ? tab[kSecLgTab + 1 + m] : log((double)m);
+}
+
+__device__ __forceinline__ void sec_log_pmf2_tab(const int* x, const int* e, int k, const double* __restrict__ tab, double& lp_e, double& lp_x) {
+    long long tot_e = 0, tot_x = 0;
+    int n = 0;
+    for (int i = 0; i < k; ++i) { tot_e += (long long)e[i] + 1; tot_x += (long long)x[i] + 1; n += x[i]; }
+    const double lte = sec_log_int(tab, tot_e), ltx = sec_log_int(tab, tot_x);
+    double g = sec_log_fact(tab, n), se = 0.0, sx = 0.0;
+    for (int i = 0; i < k; ++i) {
+        if (x[i] > 0) {
+            se += (double)x[i] * (sec_log_int(tab, (long long)e[i] + 1) - lte);
+            sx += (double)x[i] * (sec_log_int(tab, (long long)x[i] + 1) - ltx);
+        }
+        g -= sec_log_fact(tab, x[i]);
+    }
+    lp_e = g + se;
+    lp_x = g + sx;
+}
+
+// The same verdicts for a callset SORTED by key (every resident callset is: ugvc_variants_upload checks it).  A wave
+// takes consecutive tiles of 64 calls; where a tile's first call stands in the database is where the previous tile's
+// last call ended, so the 22-step search per call above becomes, per tile, one coalesced fetch of the next 128 keys
+// (requested while the previous tile is worked on) and seven steps over them in LDS.  A fresh search - 64 probes per
+// step by the whole wave - happens once per wave; a tile whose calls run past the staged keys searches from the carried
+// rank in HBM.  (sec_apply_kernel stays as the checker of this one: UGVC_SEC_SIMPLE=1 selects it.)
+constexpr int kSecStage = 128;
+
+__global__ __launch_bounds__(256) void sec_apply_tiles_kernel(const uint16_t* __restrict__ contig, const int32_t* __restrict__ pos,
+                                                              const int32_t* __restrict__ dp, const int32_t* __restrict__ adr,
+                                                              const int32_t* __restrict__ ada, int64_t n,
+                                                              const uint64_t* __restrict__ keys, const int32_t* __restrict__ expected,
+                                                              const double* __restrict__ lg_tab, int64_t n_db, int k, double min_ratio, int scale,
+                                                              double* __restrict__ ratio, uint8_t* __restrict__ is_sec, uint8_t* __restrict__ flags,
+                                                              int tiles_per_wave) {
+    __shared__ uint64_t stage_all[4][kSecStage];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t* stage = stage_all[wave];
+    const int64_t n_tiles = (n + 63) >> 6;
+    const int64_t t0 = ((int64_t)blockIdx.x * 4 + wave) * tiles_per_wave;
+    const int64_t t1 = t0 + tiles_per_wave < n_tiles ? t0 + tiles_per_wave : n_tiles;
+    if (t0 >= t1) return;
+    auto key_of = [&](int64_t i) { return ((uint64_t)contig[i] << 32) | (uint32_t)pos[i]; };
+    // where the wave's first call stands: lower bound by 64 probes per step
+    int64_t Lb = 0;
+    {
+        const uint64_t key0 = key_of(t0 * 64);
+        int64_t b = 0, len = n_db;
+        while (len > 0) {
+            const int64_t step = (len + 63) >> 6;
+            uint64_t x = ~0ull;
+            if (lane * step < len) x = keys[b + lane * step];
+            const int kk = (int)__popcll(__ballot(x < key0));
+            const int64_t end = b + len;
+            const int64_t nb = kk > 0 ? b + (kk - 1) * step + 1 : b;
+            int64_t ne = b + kk * step;
+            ne = ne < end ? ne : end;
+            b = nb;
+            len = ne > nb ? ne - nb : 0;
+        }
+        Lb = b;
+    }
+    auto fetch = [&](int64_t from, uint64_t& a0, uint64_t& a1) {
+        a0 = from + lane < n_db ? keys[from + lane] : ~0ull;
+        a1 = from + 64 + lane < n_db ? keys[from + 64 + lane] : ~0ull;
+    };
+    uint64_t s0, s1;
+    fetch(Lb, s0, s1);
+    for (int64_t t = t0; t < t1; ++t) {
+        const int64_t i = t * 64 + lane;
+        const bool valid = i < n;
+        const int64_t ii = valid ? i : n - 1;
+        const uint64_t key = key_of(ii);
+        const int last = (int)((n - t * 64 < 64 ? n - t * 64 : 64) - 1);
+        stage[lane] = s0;
+        stage[64 + lane] = s1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint64_t key_max = __shfl(key, last);
+        int64_t l2;
+        bool found;
+        if (stage[kSecStage - 1] >= key_max) {                    // the staged keys reach the tile's last call
+            int p = -1;
+#pragma unroll
+            for (int sb = 64; sb >= 1; sb >>= 1) p = stage[p + sb] < key ? p + sb : p;
+            const int r = p + 1;                                   // staged keys below this call's key
+            l2 = Lb + r;
+            found = stage[r] == key;
+        } else {
+            int64_t b = Lb, len = n_db - Lb;
+            while (len > 0) {
+                const int64_t half = len >> 1;
+                if (keys[b + half] < key) { b += half + 1; len -= half + 1; }
+                else len = half;
+            }
+            l2 = b;
+            found = l2 < n_db && keys[l2] == key;
+        }
+        __builtin_amdgcn_wave_barrier();
+        Lb = __shfl(l2, last);
+        if (t + 1 < t1) fetch(Lb, s0, s1);                          // in flight during this tile's arithmetic
+        double r = __longlong_as_double(0x7ff8000000000000ll);
+        uint8_t hit = 0;
+        if (found && valid) {
+            int a[kSecMaxK], e[kSecMaxK];
+            const int r0 = adr[i] > 0 ? adr[i] : 0, a0 = ada[i] > 0 ? ada[i] : 0;
+            a[0] = r0;
+            a[1] = a0;
+            if (k > 2) { const int o = dp[i] - r0 - a0; a[2] = o > 0 ? o : 0; }
+            for (int c = 3; c < k; ++c) a[c] = 0;
+            long long s = 0, na = 0;
+            for (int c = 0; c < k; ++c) { e[c] = expected[l2 * k + c]; s += e[c]; na += a[c]; }
+            if (scale && s > 0) {
+                const double f = (double)na / (double)s;              // stats_utils.py:24-27: np.round(table * (n / sum))
+                for (int c = 0; c < k; ++c) e[c] = (int)rint((double)e[c] * f);
+            }
+            double lp_e, lp_x;
+            sec_log_pmf2_tab(a, e, k, lg_tab, lp_e, lp_x);
+            r = exp(lp_e) / exp(lp_x);
+            hit = r >= min_ratio ? 1 : 0;
+        }
+        if (valid) {
+            if (ratio) ratio[i] = r;
+            if (is_sec) is_sec[i] = hit;
+            if (flags && hit) flags[i] |= UGVC_FLAG_SEC;
+        }
+    }
 }
 
 __global__ void sec_iota_kernel(uint32_t* idx, int64_t n) {
@@ -205,8 +339,11 @@ int ugvc_sec_db_upload(ugvc_ctx* ctx, const uint64_t* keys, const int32_t* expec
     std::vector<uint64_t> c((size_t)((n_db + 63) / 64));
     for (size_t j = 0; j < c.size(); ++j) c[j] = keys[j * 64];
     if (upload(ctx, ctx->sec_coarse, c.data(), c.size() * 8)) return -1;
-    std::vector<double> lg((size_t)kSecLgTab + 1);
-    for (int m = 0; m <= kSecLgTab; ++m) lg[(size_t)m] = std::lgamma((double)m + 1.0);
+    std::vector<double> lg(2 * ((size_t)kSecLgTab + 1));                              // log(m!) | log(m), m = 0..kSecLgTab
+    for (int m = 0; m <= kSecLgTab; ++m) {
+        lg[(size_t)m] = std::lgamma((double)m + 1.0);
+        lg[(size_t)kSecLgTab + 1 + m] = m > 0 ? std::log((double)m) : 0.0;
+    }
     if (upload(ctx, ctx->sec_lgtab, lg.data(), lg.size() * 8)) return -1;
     UGVC_HIP(hipStreamSynchronize(ctx->stream));
     ctx->n_sec = n_db;
@@ -227,16 +364,31 @@ int ugvc_sec_apply(ugvc_ctx* ctx, double min_ratio, int scale_expected, int mark
     int rc = 0;
     do {
         if ((ratio && (rc = ensure(d_r, (size_t)n * 8))) || (is_sec && (rc = ensure(d_s, (size_t)n)))) break;
-        hipLaunchKernelGGL(sec_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->v_contig.as<uint16_t>(),
-                           ctx->v_pos.as<int32_t>(), ctx->v_dp.as<int32_t>(), ctx->v_adr.as<int32_t>(), ctx->v_ada.as<int32_t>(), n,
-                           ctx->sec_keys.as<uint64_t>(), ctx->sec_coarse.as<uint64_t>(), ctx->sec_exp.as<int32_t>(), ctx->sec_lgtab.as<double>(), ctx->n_sec,
-                           ctx->sec_k,
-                           min_ratio, scale_expected, ratio ? d_r.as<double>() : nullptr, is_sec ? d_s.as<uint8_t>() : nullptr,
-                           mark ? ctx->r_flags.as<uint8_t>() : nullptr);
+        static const bool simple = getenv("UGVC_SEC_SIMPLE") != nullptr;
+        if (simple) {
+            hipLaunchKernelGGL(sec_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->v_contig.as<uint16_t>(),
+                               ctx->v_pos.as<int32_t>(), ctx->v_dp.as<int32_t>(), ctx->v_adr.as<int32_t>(), ctx->v_ada.as<int32_t>(), n,
+                               ctx->sec_keys.as<uint64_t>(), ctx->sec_coarse.as<uint64_t>(), ctx->sec_exp.as<int32_t>(), ctx->sec_lgtab.as<double>(), ctx->n_sec,
+                               ctx->sec_k,
+                               min_ratio, scale_expected, ratio ? d_r.as<double>() : nullptr, is_sec ? d_s.as<uint8_t>() : nullptr,
+                               mark ? ctx->r_flags.as<uint8_t>() : nullptr);
+        } else {
+            // consecutive tiles per wave: enough waves for 8 per SIMD on every CU
+            const int64_t n_tiles = (n + 63) / 64;
+            const int64_t want_waves = (int64_t)ctx->n_cus * 32;
+            const int tpw = (int)std::max<int64_t>((n_tiles + want_waves - 1) / want_waves, 1);
+            const int64_t n_waves = (n_tiles + tpw - 1) / tpw;
+            hipLaunchKernelGGL(sec_apply_tiles_kernel, dim3((unsigned)((n_waves + 3) / 4)), dim3(256), 0, ctx->stream, ctx->v_contig.as<uint16_t>(),
+                               ctx->v_pos.as<int32_t>(), ctx->v_dp.as<int32_t>(), ctx->v_adr.as<int32_t>(), ctx->v_ada.as<int32_t>(), n,
+                               ctx->sec_keys.as<uint64_t>(), ctx->sec_exp.as<int32_t>(), ctx->sec_lgtab.as<double>(), ctx->n_sec, ctx->sec_k,
+                               min_ratio, scale_expected, ratio ? d_r.as<double>() : nullptr, is_sec ? d_s.as<uint8_t>() : nullptr,
+                               mark ? ctx->r_flags.as<uint8_t>() : nullptr, tpw);
+        }
         if (hipGetLastError() != hipSuccess) { rc = fail("sec_apply: launch failed"); break; }
+        // (mark-only calls stay stream-ordered: nothing to wait for on the host)
         if ((ratio && hipMemcpyAsync(ratio, d_r.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) ||
             (is_sec && hipMemcpyAsync(is_sec, d_s.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) ||
-            hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = fail("sec_apply: device error"); break; }
+            ((ratio || is_sec) && hipStreamSynchronize(ctx->stream) != hipSuccess)) { rc = fail("sec_apply: device error"); break; }
     } while (0);
     for (DeviceBuf* b : {&d_r, &d_s}) if (b->p) (void)hipFree(b->p);
     return rc;
