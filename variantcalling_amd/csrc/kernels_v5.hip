@@ -1142,16 +1142,7 @@ __device__ __forceinline__ Lds5 lds5_fill(unsigned char* smem, const V5Args& v, 
     L.thr_b = lds_addr(thr_l);
     off += ((size_t)(n_thr + (n_thr >> 5) + 1) * 4 + 15) & ~(size_t)15;
     uint16_t* gcr = reinterpret_cast<uint16_t*>(smem + off);
-    for (int q = tid; q < UGVC_N_GROUPS * kGcRank; q += nthreads) {
-        const int g = q / kGcRank, r = q % kGcRank, len = r / 11, cnt = r % 11;
-        const float f = (len > 0 && cnt <= len) ? (float)((double)cnt / (double)len) : 0.0f;
-        const uint2 d = v.desc3[g * kMaxFeatures + 13];
-        const float* t = v.thr + (d.x & 0xFFFFFu);
-        const int n = (int)(d.y & 0xFFFFu);
-        int rank = 0;
-        for (int e = 0; e < n; ++e) rank += t[e] < f ? 1 : 0;
-        gcr[q] = (uint16_t)rank;
-    }
+    for (int q = tid; q < kGcRankBytes / 4; q += nthreads) reinterpret_cast<uint32_t*>(gcr)[q] = reinterpret_cast<const uint32_t*>(v.gcr)[q];   // (built on the host: model_pack.hip)
     L.gcr_b = lds_addr(gcr);
     off += kGcRankBytes;
     uint8_t* css = smem + off;
@@ -1205,6 +1196,9 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
     const int wave = rfl(tid >> 6);
     const int n_waves = blockDim.x >> 6;
     const FilterArgs& a = v.f;
+#ifdef UGVC_PHASE_CLOCK
+    const uint64_t k_begin = __builtin_readcyclecounter();
+#endif
     const int64_t r0 = (int64_t)blockIdx.x * v.rows_wg;
     if (r0 >= a.n) return;                                       // (uniform: before the first barrier)
     const int64_t r1 = min(r0 + (int64_t)v.rows_wg, a.n);
@@ -1212,13 +1206,27 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
     const bool has0 = pg0.ok != 0;
     // the thresholds of every group: SNP tiles rank against group 0's slices (the head of the table), indel
     // tiles against their own group's
-    const Lds5 L = lds5_fill(smem, v, has0, tid, blockDim.x);
-    // ---- classes of this wave's rows (eight groups of 64 in flight)
+    // ---- classes of this wave's rows (eight groups of 64 in flight).  The first eight groups are requested BEFORE the
+    // LDS fill (their round trip runs under it) and are kept for the list pass below: a wave of a shard-sized callset has
+    // no more than that, so its rows are read once.
     const int64_t m = (r1 - r0 + n_waves - 1) / n_waves;
     const int64_t w0 = r0 + (int64_t)wave * m, w1 = min(w0 + m, r1);
     constexpr int U = 8;
+    int rl0[U], al0[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t r = w0 + 64 * u + lane;
+        rl0[u] = al0[u] = -1;
+        if (r < w1) { rl0[u] = a.ref_len[r]; al0[u] = a.alt_len[r]; }
+    }
+    const Lds5 L = lds5_fill(smem, v, has0, tid, blockDim.x);
     unsigned cs = 0, ci = 0;
-    for (int64_t g = w0; g < w1; g += 64 * U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        cs += (unsigned)__popcll(__ballot(rl0[u] >= 0 && rl0[u] == al0[u]));
+        ci += (unsigned)__popcll(__ballot(rl0[u] >= 0 && rl0[u] != al0[u]));
+    }
+    for (int64_t g = w0 + 64 * U; g < w1; g += 64 * U) {
         int rl[U], al[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1251,8 +1259,11 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t r = g + 64 * u + lane;
-                rl[u] = al[u] = -1;
-                if (r < w1) { rl[u] = a.ref_len[r]; al[u] = a.alt_len[r]; }
+                rl[u] = rl0[u]; al[u] = al0[u];
+                if (g != w0) {
+                    rl[u] = al[u] = -1;
+                    if (r < w1) { rl[u] = a.ref_len[r]; al[u] = a.alt_len[r]; }
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -1420,7 +1431,9 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
         printf("clk b%d w%d tiles %d total %llu | stage %llu window %llu joins %llu codes %llu cols_n %llu walk %llu\n", (int)blockIdx.x, wave, n_done,
                (unsigned long long)(pc.last - t_begin), (unsigned long long)pc.acc[0], (unsigned long long)pc.acc[1], (unsigned long long)pc.acc[2],
                (unsigned long long)pc.acc[3], (unsigned long long)pc.acc[4], (unsigned long long)pc.acc[5]);
-    if (lane == 0 && blockIdx.x == 0 && wave == 0) printf("  issue %llu eyt %llu\n", (unsigned long long)pc.acc[6], (unsigned long long)pc.acc[7]);
+    if (lane == 0 && blockIdx.x == 0 && wave == 0)
+        printf("  issue %llu eyt %llu | prologue (fill, class lists) %llu cycles before the first tile\n", (unsigned long long)pc.acc[6],
+               (unsigned long long)pc.acc[7], (unsigned long long)(t_begin - k_begin));
 #endif
 }
 

@@ -44,7 +44,7 @@ struct V2Group {
 struct V2State {
     V2Group g[UGVC_N_GROUPS];
     DeviceBuf desc, desc3, lut, thr, css, brackets, brackets3, counters, prof;
-    DeviceBuf snp_idx, indel_idx, counters5, rec5[UGVC_N_GROUPS], eyt;   // v5
+    DeviceBuf snp_idx, indel_idx, counters5, rec5[UGVC_N_GROUPS], eyt, gcr;   // v5
     int c5_set = 0;                          // v5 record counters: two sets, alternating passes
     bool c5_dirty[2] = {true, true};
     int eyt_off[3] = {0, 0, 0}, eyt_bits[3] = {0, 0, 0}, eyt_len = 0;
@@ -69,7 +69,7 @@ void v2_destroy(ugvc_ctx* ctx) {
     if (!ctx->v2) return;
     V2State* s = static_cast<V2State*>(ctx->v2);
     DeviceBuf* bufs[] = {&s->desc, &s->desc3, &s->lut, &s->thr, &s->css, &s->brackets, &s->brackets3, &s->counters, &s->prof,
-                         &s->snp_idx, &s->indel_idx, &s->counters5, &s->eyt};
+                         &s->snp_idx, &s->indel_idx, &s->counters5, &s->eyt, &s->gcr};
     for (auto* b : bufs) if (b->p) (void)hipFree(b->p);
     for (auto& r : s->rec) if (r.p) (void)hipFree(r.p);
     for (auto& r : s->rec5) if (r.p) (void)hipFree(r.p);
@@ -437,6 +437,22 @@ int finalize_pack(ugvc_ctx* ctx) {
             eyt.resize((eyt.size() + 3) & ~(size_t)3, std::numeric_limits<float>::infinity());
             s->eyt_len = (int)eyt.size();
             if (upload(ctx, s->eyt, eyt.data(), eyt.size() * 4)) return -1;
+            // v5: gc_content takes 121 values (count / len with len, count in 0..10): its rank among a group's thresholds
+            // is a table [group][len * 11 + count] (the fused kernel used to build it in its prologue: 363 threads looping
+            // over the thresholds, ~10 us per launch)
+            std::vector<uint16_t> gcr(384 * 1, 0);
+            for (int g = 0; g < UGVC_N_GROUPS; ++g) {
+                const std::vector<float> empty;
+                const auto& u = s->g[g].set ? s->g[g].uthr[13] : empty;
+                for (int r = 0; r < 121; ++r) {
+                    const int len = r / 11, cnt = r % 11;
+                    const float f = (len > 0 && cnt <= len) ? (float)((double)cnt / (double)len) : 0.0f;
+                    int rank = 0;
+                    for (float t : u) rank += t < f ? 1 : 0;
+                    gcr[(size_t)g * 121 + r] = (uint16_t)rank;
+                }
+            }
+            if (upload(ctx, s->gcr, gcr.data(), gcr.size() * 2)) return -1;
         }
         for (int k = 0; k < 4; ++k) {
             const int f = k == 0 ? 0 : (k == 1 ? 1 : (k == 2 ? 5 : 13));
@@ -660,6 +676,7 @@ int v5_fill_args(ugvc_ctx* ctx, V5Args& v, const FilterArgs& a) {
         }
     v.eyt = s->eyt.as<float>();
     v.eyt_len = s->eyt_len;
+    v.gcr = s->gcr.as<uint16_t>();
     for (int k = 0; k < 3; ++k) { v.eyt_off[k] = s->eyt_off[k]; v.eyt_bits[k] = s->eyt_bits[k]; }
     v.css_lut = s->css.as<uint8_t>();
     // rows per workgroup of the fused kernel: the callset split evenly over the CUs (at least kMinRowsWg5 rows each)

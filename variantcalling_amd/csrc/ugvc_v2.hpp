@@ -105,6 +105,7 @@ struct V5Args {
     int thr_bits;                        // descent depth of the float-feature searches of the indel groups (sorted slices)
     const float* eyt;                    // group 0: qual / sor / vaf thresholds as complete search trees (Eytzinger order, +inf padded)
     int eyt_off[3], eyt_bits[3], eyt_len;
+    const uint16_t* gcr;                 // [3][121] rank of gc_content = count / len among the group's thresholds (384 entries)
     int cap5[UGVC_N_GROUPS][kMaxFeatures];
     uint32_t used5[UGVC_N_GROUPS];       // features a group's forest tests
     const uint8_t* css_lut;
