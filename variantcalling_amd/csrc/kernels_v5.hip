@@ -1634,7 +1634,7 @@ int launch_filter_v5(ugvc_ctx* ctx, const FilterArgs& a) {
     const unsigned n_wg = (unsigned)((a.n + v.rows_wg - 1) / v.rows_wg);
     hipLaunchKernelGGL(fused5_for(a.n_tracks, (a.ablate & (1 << 28)) != 0), dim3(n_wg), dim3(v.n_waves * 64), lds_f, ctx->stream, v);
     if (step("fused5")) return -1;
-    if (!(a.ablate & 262144) && (v.pg[1].ok || v.pg[2].ok)) {
+    if (v.run_forest) {
         int n_waves = 0;
         size_t lds = 0;
         for (int w : {16, 12, 8, 4}) {

@@ -701,12 +701,19 @@ int v5_fill_args(ugvc_ctx* ctx, V5Args& v, const FilterArgs& a) {
         const int cur = s->c5_set;
         s->c5_set ^= 1;
         uint8_t* base = static_cast<uint8_t*>(s->counters5.p);
-        if (s->c5_dirty[cur]) UGVC_HIP(hipMemsetAsync(base + cur * c5_bytes, 0, c5_bytes, ctx->stream));
+        if (s->c5_dirty[cur]) {
+            UGVC_HIP(hipMemsetAsync(base + cur * c5_bytes, 0, c5_bytes, ctx->stream));
+            s->c5_dirty[cur] = false;
+        }
         v.counters = reinterpret_cast<uint32_t*>(base + cur * c5_bytes);
         v.counters_next = reinterpret_cast<uint32_t*>(base + (cur ^ 1) * c5_bytes);
-        const bool forest = !(a.ablate & 262144) && (v.pg[1].ok || v.pg[2].ok);
-        s->c5_dirty[cur] = true;
-        if (forest) s->c5_dirty[cur ^ 1] = false;
+        // (a callset without indels writes no records: no forest launch, nothing to zero)
+        const bool forest = ctx->n_indel > 0 && !(a.ablate & 262144) && (v.pg[1].ok || v.pg[2].ok);
+        v.run_forest = forest ? 1 : 0;
+        if (forest) {
+            s->c5_dirty[cur] = true;
+            s->c5_dirty[cur ^ 1] = false;
+        }
     }
     for (int gi = 1; gi < UGVC_N_GROUPS; ++gi) {
         v.rec5[gi] = nullptr;

@@ -113,6 +113,7 @@ struct V5Args {
     uint32_t* indel_idx;                 // ... of its indels
     int rows_wg;                         // consecutive rows a workgroup owns
     int list_stride;                     // entries per workgroup list (rows_wg rounded up to 64, + 64 of padding)
+    int run_forest;                      // the pass has indel records to walk (indels resident and a model for them)
     int indel_one_round;                 // indel tiles: every narrow slice and the blacklist keys staged together (scratch_indel holds them)
     uint32_t iwide;                      // bit t: interval table t is dense enough for the six-rows-per-lane slice under an indel tile
     uint4* rec5[UGVC_N_GROUPS];
