@@ -90,3 +90,16 @@ def test_three_ranks_from_plain_environment_variables(tmp_path, frozen_models):
         out, err = p.communicate(timeout=600)
         assert p.returncode == 0, err[-3000:]
     _check(tmp_path, frozen_models, 3)
+
+
+def test_eight_ranks_under_the_torchrun_launcher(tmp_path, frozen_models):
+    """The world size the node has GPUs for: eight workers behind `torch.distributed.run`, rank 0 serving the star, every
+    rank ending up with the whole callset in order."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, UGVC_ROOT=ROOT, UGVC_OUT=str(tmp_path / "out"), OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    _check(tmp_path, frozen_models, 8)
