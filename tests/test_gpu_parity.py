@@ -200,6 +200,27 @@ def test_v5_many_small_contigs_and_row_counts(engine, frozen_models):
         assert np.array_equal(got.tree_score, exp.tree_score[5000:5000 + n]), n
 
 
+@pytest.mark.parametrize("n_tracks", [0, 1, 2, 4, 5])
+@PATHS
+def test_track_counts_other_than_three(engine, small_callset, path, n_tracks):
+    """The v5 kernels are instantiated per number of annotation tracks (0..5): every count, a dense track among them,
+    with a random forest per variant type over the 17 + n_tracks features of that configuration."""
+    from test_gpu_fuzz import _random_forest
+    from variantcalling_amd import model_io, schema as S, synth
+    O = _oracle()
+    cs = small_callset
+    extra = [synth.make_interval_track(cs.ref, 4000, 500.0, 991, "extra.a"), synth.make_interval_track(cs.ref, 60_000, 150.0, 992, "extra.b")]
+    tracks = ([cs.tracks[2], extra[1]] + list(cs.tracks[:2]) + [extra[0]])[:n_tracks]
+    rng = np.random.default_rng(4200 + n_tracks)
+    forests = [_random_forest(rng, S.MODEL_RF, 17 + n_tracks, 24, 7, normalised=True) for _ in range(3)]
+    for f in forests:
+        f.max_depth = max(model_io._depth(f.left, f.right, f.feature, int(r)) for r in f.tree_root)
+    _configure(engine, cs.ref, cs.runs, tracks, cs.blacklist, forests)
+    engine.set_kernel_variant(path)
+    _assert_same(engine.filter_variants(cs.variants), O.filter_variants(cs.variants, cs.ref, cs.runs, tracks, cs.blacklist, forests),
+                 f"{n_tracks} tracks")
+
+
 @pytest.mark.parametrize("rounds", [False, True], ids=["one-round", "pair-rounds"])
 @pytest.mark.parametrize("iwide", ["0", "15"], ids=["narrow-slices", "wide-slices"])
 def test_v5_indel_slice_widths_agree(engine, small_callset, frozen_models, iwide, rounds, monkeypatch):
