@@ -25,6 +25,11 @@ __global__ __launch_bounds__(1024) void k(uint32_t* out, uint64_t* cyc, int iter
 #define ADDC(q) asm volatile("v_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(a[q]) : : "vcc");
 #define FMA(q) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a[q]) : "v"(s));
 #define SDWA(q) asm volatile("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "+v"(a[q]) : "v"(s));
+#define CMP16(q) asm volatile("v_cmp_lt_u16_e32 vcc, %0, %1" : : "v"(a[q]), "v"(s) : "vcc");
+#define CMPSDWA(q) asm volatile("v_cmp_lt_u32_sdwa vcc, %0, %1 src0_sel:WORD_0 src1_sel:DWORD" : : "v"(a[q]), "v"(s) : "vcc");
+#define CMP32(q) asm volatile("v_cmp_lt_u32_e32 vcc, %0, %1" : : "v"(a[q]), "v"(s) : "vcc");
+#define CMP16ADDC(q) asm volatile("v_cmp_lt_u16_e32 vcc, %0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(a[q]) : "v"(s) : "vcc");
+#define CMPSDWAADDC(q) asm volatile("v_cmp_lt_u32_sdwa vcc, %0, %1 src0_sel:WORD_0 src1_sel:DWORD\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(a[q]) : "v"(s) : "vcc");
 #define ADDF64(q) asm volatile("v_add_f64 %0, %0, %1" : "+v"(*(double*)&a[(q) & 14]) : "v"(*(double*)&a[(q) & 14]));
             if (OP == 0) { REP16(ADD) }
             if (OP == 1) { REP16(LSHLADD) }
@@ -33,6 +38,11 @@ __global__ __launch_bounds__(1024) void k(uint32_t* out, uint64_t* cyc, int iter
             if (OP == 4) { REP16(ADDC) }
             if (OP == 5) { REP16(FMA) }
             if (OP == 6) { REP16(SDWA) }
+            if (OP == 7) { REP16(CMP16) }
+            if (OP == 8) { REP16(CMPSDWA) }
+            if (OP == 9) { REP16(CMP32) }
+            if (OP == 10) { REP16(CMP16ADDC) }
+            if (OP == 11) { REP16(CMPSDWAADDC) }
         }
     }
     const uint64_t t1 = __builtin_readcyclecounter();
@@ -75,5 +85,10 @@ int main() {
     run<4>("v_addc_co_u32", 4, 1);
     run<5>("v_fma_f32", 1, 1); run<5>("v_fma_f32", 4, 1);
     run<6>("v_add_u32_sdwa", 4, 1);
+    run<7>("v_cmp_lt_u16_e32", 4, 1);
+    run<8>("v_cmp_lt_u32_sdwa", 4, 1);
+    run<9>("v_cmp_lt_u32_e32", 4, 1);
+    run<10>("v_cmp_u16 + v_addc", 4, 2);
+    run<11>("v_cmp_sdwa + v_addc", 4, 2);
     return 0;
 }
