@@ -153,7 +153,7 @@ def run_filter(args):
     eng = Engine(grp.local_rank)
     info = eng.device_info()
     # every rank keeps only the part of the genome and of the side tables its shard can touch
-    ctx_tables = shard.slice_context(cs.ref, cs.runs, cs.tracks, cs.blacklist, mine) if grp.world > 1 else \
+    ctx_tables = shard.slice_context(cs.ref, cs.runs, cs.tracks, cs.blacklist, mine, hpol_dist=10) if grp.world > 1 else \
         (cs.ref, cs.runs, cs.tracks, cs.blacklist, mine)
     ref_r, runs_r, tracks_r, bl_r, mine_r = ctx_tables
     configure(eng, ref_r, runs_r, tracks_r, bl_r, forests, "TGCA", 10, 10, True)
@@ -186,13 +186,21 @@ def run_filter(args):
         eng.filter_resident()
     res = eng.download_results()
     check = None
+    checked_rows = 0
     if grp.rank == 0:
+        # --check-rows K: the first K and the last K rows of this rank's shard (all of it if that covers it; K < 0: all),
+        # in chunks the vectorised oracle digests in seconds
         from oracle import oracle as O
-        k = min(5000, mine.n)
-        sub = mine.slice(0, k)
-        exp = O.filter_variants(sub, cs.ref, cs.runs, cs.tracks, cs.blacklist, forests)
-        check = bool(np.array_equal(res.filter[:k], exp.filter) and np.array_equal(res.flags[:k], exp.flags)
-                     and np.array_equal(res.tree_score[:k], exp.tree_score))
+        k = mine.n if args.check_rows < 0 else min(args.check_rows, mine.n)
+        spans = [(0, mine.n)] if 2 * k >= mine.n else [(0, k), (mine.n - k, mine.n)]
+        check = True
+        for lo, hi in spans:
+            for a in range(lo, hi, 250_000):
+                b_ = min(a + 250_000, hi)
+                exp = O.filter_variants(mine.slice(a, b_), cs.ref, cs.runs, cs.tracks, cs.blacklist, forests)
+                check = check and bool(np.array_equal(res.filter[a:b_], exp.filter) and np.array_equal(res.flags[a:b_], exp.flags)
+                                       and np.array_equal(res.tree_score[a:b_], exp.tree_score))
+                checked_rows += b_ - a
     if gather:
         b = shard.shard_bounds(n_total, grp.world)
         allr = eng.gathered_download(cap, grp.world, [int(b[r + 1] - b[r]) for r in range(grp.world)])
@@ -237,7 +245,7 @@ def run_filter(args):
                           kernel=PASS_KERNELS, kernel_ms=kern_ms, kernel_ms_p5=_pct(step_ms, 5), kernel_ms_p50=_pct(step_ms, 50),
                           kernel_ms_p95=_pct(step_ms, 95), alg_bytes_per_variant=alg, variants_per_launch=mine.n),
             e2e_incl_pcie=e2e,
-            parity=dict(oracle_slice_bit_exact=check, gather_consistent=ok_all),
+            parity=dict(oracle_slice_bit_exact=check, oracle_rows_checked=checked_rows, gather_consistent=ok_all),
             setup_s=round(t_setup, 1), cpu_baseline=cpu)
         print(json.dumps(out), flush=True)
     eng.close()
@@ -374,6 +382,8 @@ def main():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--cpu-sample", type=int, default=100_000, help="variants timed on the single-process CPU baseline (0 = skip)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive measurement")
+    ap.add_argument("--check-rows", type=int, default=5000,
+                    help="rows at either end of the shard compared with the CPU oracle after the timed region (-1: every row)")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (debug)")
     args = ap.parse_args()
     if args.snv_only:

@@ -16,7 +16,9 @@ from __future__ import annotations
 import numpy as np
 import pandas as pd
 
-from variantcalling_amd import schema as S
+from variantcalling_amd import schema as S      # containers only (named arrays); every number comes from spec.py
+
+from . import spec as P
 
 from . import oracle as O
 
@@ -57,8 +59,8 @@ def table_to_frame(vt: S.VariantTable) -> pd.DataFrame:
     rows = []
     pool = vt.alleles
     for i in range(vt.n):
-        ref = S.decode_bases(pool[vt.ref_off[i]: vt.ref_off[i] + vt.ref_len[i]])
-        alt = S.decode_bases(pool[vt.alt_off[i]: vt.alt_off[i] + vt.alt_len[i]])
+        ref = P.decode_bases(pool[vt.ref_off[i]: vt.ref_off[i] + vt.ref_len[i]])
+        alt = P.decode_bases(pool[vt.alt_off[i]: vt.alt_off[i] + vt.alt_len[i]])
         rows.append([int(vt.contig[i]), int(vt.pos[i]), ref, (ref, alt), float(vt.qual[i]),
                      float(vt.sor[i]), int(vt.dp[i]), (int(vt.ad_ref[i]), int(vt.ad_alt[i])),
                      int(vt.gq[i])])
@@ -192,7 +194,7 @@ def annotate_cycle_skip(df, flow_order):
 
 NUC = {None: 0, "N": 0, "A": 1, "C": 2, "G": 3, "T": 4}
 CLS = {None: 0, "ins": 1, "del": 2}
-CSS = {n: i for i, n in enumerate(S.CSS_NAMES)}
+CSS = {n: i for i, n in enumerate(P.CSS_NAMES)}
 
 
 def motif_code(m):
@@ -210,8 +212,8 @@ def filter_variants_idiom(vt, ref, runs, tracks, blacklist, sk_models, flow_orde
     df = table_to_frame(vt)
     df = classify_indel(df)
     df = is_hmer_indel(df, fa)
-    df = get_motif_around(df, S.MOTIF_SIZE, fa)
-    df = get_gc_content(df, S.GC_WINDOW, fa)
+    df = get_motif_around(df, P.MOTIF_SIZE, fa)
+    df = get_gc_content(df, P.GC_WINDOW, fa)
     df = annotate_cycle_skip(df, flow_order)
     contig = vt.contig
     if runs is not None:
@@ -225,7 +227,7 @@ def filter_variants_idiom(vt, ref, runs, tracks, blacklist, sk_models, flow_orde
     df["blacklst"] = [((int(c) << 32) | int(p)) in bl for c, p in zip(df["chrom"], df["pos"])]
 
     # feature_prepare: strings -> numbers, f32 matrix in schema.feature_names order
-    X = np.zeros((vt.n, S.N_BASE_FEATURES + len(tracks)), dtype=np.float32)
+    X = np.zeros((vt.n, P.N_BASE_FEATURES + len(tracks)), dtype=np.float32)
     X[:, 0] = df["qual"]; X[:, 1] = df["sor"]; X[:, 2] = df["dp"]
     X[:, 3] = df["ad"].apply(lambda a: a[0]); X[:, 4] = df["ad"].apply(lambda a: a[1])
     X[:, 5] = [np.float32(a[1]) / np.float32(d) if d > 0 else np.float32(0) for a, d in zip(df["ad"], df["dp"])]
@@ -249,7 +251,7 @@ def filter_variants_idiom(vt, ref, runs, tracks, blacklist, sk_models, flow_orde
             continue
         if isinstance(m, S.FlatForest):
             p0, p1 = O.forest_predict(m, X[sel])
-            if m.kind == S.MODEL_GBT:
+            if m.kind == P.MODEL_GBT:
                 score[sel] = p1
                 flt[sel] = np.where(p0 > np.float32(0), 0, 1)
                 continue
@@ -257,18 +259,18 @@ def filter_variants_idiom(vt, ref, runs, tracks, blacklist, sk_models, flow_orde
             pp = m.predict_proba(X[sel])
             p0, p1 = pp[:, 0], pp[:, 1]
         score[sel] = p1.astype(np.float32)
-        flt[sel] = np.where(p1 > p0, S.FILTER_PASS, S.FILTER_LOW_SCORE)
+        flt[sel] = np.where(p1 > p0, P.FILTER_PASS, P.FILTER_LOW_SCORE)
 
     # per-record write-back loop (pattern: calibrate_bridging_snvs.py:110-128)
     flags = np.zeros(vt.n, dtype=np.uint8)
     for i in range(vt.n):
         f = 0
         if mark_hpol and (df["inside_hmer_run"].iat[i] or df["close_to_hmer_run"].iat[i]):
-            f |= S.FLAG_HPOL_RUN
+            f |= P.FLAG_HPOL_RUN
         if df["blacklst"].iat[i]:
-            f |= S.FLAG_COHORT_FP
+            f |= P.FLAG_COHORT_FP
         for t in range(len(tracks)):
             if df[f"track{t}"].iat[i]:
-                f |= 1 << (S.FLAG_TRACK0_SHIFT + t)
+                f |= 1 << (P.FLAG_TRACK0_SHIFT + t)
         flags[i] = f
     return S.FilterResult(score, flt, flags), df, X

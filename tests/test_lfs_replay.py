@@ -202,6 +202,69 @@ def test_named_feature_columns_are_mapped_to_the_engine_order():
         model_io.flatten_sklearn(clf2, track_names=["LCR-hs38"])
 
 
+class _OldTreeState:
+    """Pickles as `sklearn.tree._tree.Tree(...)` with the state a scikit-learn <= 1.2 writes: the node array WITHOUT the
+    `missing_go_to_left` field (added in 1.3) and weighted sample COUNTS per leaf - the shape of the reference's own
+    model pickles (scikit-learn 1.2.2: setup/environment.yml:399)."""
+    def __init__(self, tree, n_features, n_classes):
+        st = tree.__getstate__()
+        old_fields = [f for f in st["nodes"].dtype.names if f != "missing_go_to_left"]
+        nodes = np.zeros(st["nodes"].shape, dtype=[(f, st["nodes"].dtype[f]) for f in old_fields])
+        for f in old_fields:
+            nodes[f] = st["nodes"][f]
+        counts = st["values"] * st["nodes"]["weighted_n_node_samples"][:, None, None]       # fractions -> counts
+        self.args = (n_features, np.asarray([n_classes], dtype=np.intp), 1)
+        self.state = dict(max_depth=st["max_depth"], node_count=st["node_count"], nodes=nodes, values=counts)
+
+    def __reduce__(self):
+        from sklearn.tree._tree import Tree
+        return (Tree, self.args, self.state)
+
+
+def test_old_scikit_learn_tree_state_is_read_as_data(tmp_path):
+    """`Tree.__setstate__` of this scikit-learn refuses a <= 1.2 node array (ValueError), which used to escape
+    from both loaders.  The shim holds the compiled tree as data and `model_io` reads nodes / values from the held state."""
+    from sklearn.ensemble import RandomForestClassifier
+    from oracle import oracle as O
+    rng = np.random.default_rng(3)
+    X = rng.normal(size=(1500, S.N_BASE_FEATURES)).astype(np.float32)
+    y = (X[:, 0] - X[:, 1] + 0.2 * X[:, 5] > 0).astype(int)
+    clf = RandomForestClassifier(n_estimators=5, max_depth=5, random_state=2).fit(X, y)
+    want = clf.predict_proba(X[:400])[:, 1]
+    for e in clf.estimators_:
+        e.tree_ = _OldTreeState(e.tree_, X.shape[1], 2)
+    raw = pickle.dumps({"rf_model_ignore_gt_incl_hpol_runs": [clf, clf, clf]})
+    with pytest.raises(ValueError):
+        pickle.loads(raw)                                            # the plain loader: incompatible dtype
+    path = str(tmp_path / "old_sklearn.model.pkl")
+    open(path, "wb").write(raw)
+    models = model_io.load_model_file(path)
+    f = models["rf_model_ignore_gt_incl_hpol_runs"][0]
+    assert f.n_trees == 5 and f.max_depth == 5
+    assert np.array_equal(O.forest_predict(f, X[:400])[1], want)     # count-valued leaves normalised as 1.2's predict_proba does
+
+
+def test_model_file_maps_annotation_columns_by_bed_stem(tmp_path):
+    """`load_model_file(..., track_names=...)` - what filter_variants_pipeline passes for --annotate_intervals -
+    resolves a model's named interval column; without the stems the same file is refused by name."""
+    import pandas as pd
+    from sklearn.tree import DecisionTreeClassifier
+    rng = np.random.default_rng(5)
+    cols = ["qual", "sor", "dp", "LCR-hs38", "exome.twist"]
+    Xd = pd.DataFrame(rng.normal(size=(600, len(cols))).astype(np.float32), columns=cols)
+    y = (Xd["qual"] + Xd["exome.twist"] > 0).astype(int)
+    clf = DecisionTreeClassifier(max_depth=4, random_state=0).fit(Xd, y)
+    path = str(tmp_path / "named.model.pkl")
+    open(path, "wb").write(pickle.dumps({"dt_model_ignore_gt_incl_hpol_runs": {g: clf for g in S.GROUP_NAMES}}))
+    forests = model_io.load_model_file(path, "dt_model_ignore_gt_incl_hpol_runs", track_names=["LCR-hs38", "exome.twist"])
+    used = set(int(x) for x in forests[0].feature[forests[0].feature >= 0])
+    assert used <= {S.BASE_FEATURES.index("qual"), S.BASE_FEATURES.index("sor"), S.BASE_FEATURES.index("dp"),
+                    S.N_BASE_FEATURES, S.N_BASE_FEATURES + 1}
+    assert S.N_BASE_FEATURES + 1 in used                                                   # exome.twist = the second BED
+    with pytest.raises(ValueError, match="LCR-hs38|exome.twist"):
+        model_io.load_model_file(path, "dt_model_ignore_gt_incl_hpol_runs")
+
+
 def test_reference_blacklist_pickle_is_read_without_the_reference_classes(tmp_path):
     import pandas as pd
     from variantcalling_amd.io import bed

@@ -310,3 +310,27 @@ def test_pileup_oracle_small_known_answer():
     # GATK StrandOddsRatio on the +1 table, locus 0: [[4,1],[1,2]]
     R = (4 * 2) / (1 * 1)
     assert np.isclose(r["sor64"][0], np.log(R + 1 / R) + np.log(1 / 4) - np.log(1 / 2))
+
+
+def test_oracle_spec_matches_the_product_schema():
+    """The oracle restates every encoding for itself (oracle/spec.py, with the reference lines it follows) instead of
+    importing the product's constants - a slip in `variantcalling_amd/schema.py` can no longer cancel out between the two
+    sides of a parity test.  This is the ONE place the two statements are compared, name by name."""
+    from oracle import spec as P
+    from variantcalling_amd import schema as S
+    names = [n for n in dir(P) if n.isupper() and not n.startswith("_")]
+    assert {"BASE_FEATURES", "FLAG_HPOL_RUN", "FLAG_COHORT_FP", "FLAG_SEC", "FLAG_TRACK0_SHIFT", "FILTER_LOW_SCORE", "GROUP_NAMES",
+            "MODEL_GBT", "CSS_NA", "INDEL_DEL", "GC_WINDOW", "MOTIF_SIZE", "N_BASE_FEATURES", "MAX_TRACKS"} <= set(names)
+    for n in names:
+        assert getattr(P, n) == getattr(S, n), n
+    assert P.N_BASE_FEATURES == len(P.BASE_FEATURES)
+    seq = "ACGTNacgtnRYK-"
+    assert np.array_equal(P.encode_bases(seq), S.encode_bases(seq))
+    # and the oracle modules take their numbers from the spec, not from the product
+    import ast
+    import inspect
+    from oracle import idiom, oracle
+    for mod in (oracle, idiom):
+        tree = ast.parse(inspect.getsource(mod))
+        used = {node.attr for node in ast.walk(tree) if isinstance(node, ast.Attribute) and isinstance(node.value, ast.Name) and node.value.id == "S"}
+        assert used <= {"Reference", "IntervalTrack", "VariantTable", "FlatForest", "FilterResult"}, (mod.__name__, used)

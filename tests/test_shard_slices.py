@@ -7,6 +7,7 @@ import pytest
 import edge_cases as E
 from conftest import real_chr1_reference
 from oracle import oracle as O
+from variantcalling_amd import schema as S
 from variantcalling_amd import shard, synth
 
 RF = "rf_model_ignore_gt_incl_hpol_runs"
@@ -59,3 +60,29 @@ def test_empty_shard_and_missing_tables():
     empty = cs.variants.slice(0, 0)
     ref_s, runs_s, tracks_s, bl_s, mine_s = shard.slice_context(cs.ref, None, [], None, empty)
     assert ref_s.codes.size == 0 and runs_s is None and tracks_s == [] and bl_s is None and mine_s.n == 0
+
+
+def test_cut_inside_a_long_run_is_vectorised_and_pad_follows_hpol_dist():
+    """the run a cut falls into is finished by block compares (a multi-megabase N run used to cost a Python
+    iteration per base), and the table pad follows --hpol_filter_length_dist's distance."""
+    import time
+    n = 6_000_000
+    codes = np.full(n, 0, np.uint8)                       # one long N run ...
+    codes[:1000] = np.tile(np.array([1, 2, 3, 4], np.uint8), 250)
+    codes[-1000:] = np.tile(np.array([4, 3, 2, 1], np.uint8), 250)
+    assert shard._run_end(codes, 2000, n) == n - 1000
+    ref = S.Reference(codes, np.array([0, n], np.int64), ["chrN"])
+    vt = S.VariantTable(contig=np.zeros(2, np.uint16), pos=np.array([500, 900], np.int32), ref_len=np.ones(2, np.uint16),
+                        alt_len=np.ones(2, np.uint16), ref_off=np.array([0, 2], np.uint32), alt_off=np.array([1, 3], np.uint32),
+                        alleles=np.array([1, 2, 3, 4], np.uint8), qual=np.ones(2, np.float32), sor=np.ones(2, np.float32),
+                        dp=np.ones(2, np.int32), ad_ref=np.ones(2, np.int32), ad_alt=np.ones(2, np.int32), gt=np.ones(2, np.uint8), gq=np.ones(2, np.uint8))
+    t0 = time.perf_counter()
+    ref_s, *_ = shard.slice_context(ref, None, [], None, vt, margin=200)          # the right cut (pos 901 + 200) lands in the N run
+    assert time.perf_counter() - t0 < 2.0
+    assert ref_s.codes.size == n - 1000 + 200 - (500 - 1 - 200)
+    # a run that begins 300 bases past the shard's last call still marks it when the distance is 400
+    runs = S.IntervalTrack(np.array([1200], np.int32), np.array([1230], np.int32), np.array([0, 1], np.int32), "runs")
+    _, runs_near, *_ = shard.slice_context(ref, runs, [], None, vt, margin=64, pad=128)
+    _, runs_far, *_ = shard.slice_context(ref, runs, [], None, vt, margin=64, pad=128, hpol_dist=400)
+    assert runs_far.starts.size == 1
+    assert runs_near.starts.size in (0, 1)                # (one row of halo may keep it; the pad is what guarantees it)

@@ -4,12 +4,11 @@
 //     group names test/resources/system/test_evaluate_concordance/expected.out.stats.csv:1-10, bins
 //     ugvc/reports/report_utils.py:508-538) - computed on the RESIDENT FILTER column, nothing is downloaded;
 //   * ugvc_pr_curve: the cumulative curve of ReportUtils.__calc_performance
-//     (ugvc/reports/report_utils.py:494-504): stable ascending sort by score (rocPRIM radix sort on an
-//     order-preserving 64-bit key), running tp / fp counts (device scans), recall / precision / f1 per
-//     position with the formulas of ugvc/utils/stats_utils.py:76-138 in f64 (bit-equal to the host numpy).
-#include <hipcub/hipcub.hpp>
-
-#include "ugvc_device.hpp"
+//     (ugvc/reports/report_utils.py:494-504): stable ascending sort by score (the library's own LSD radix sort,
+//     kernels_prims.hip, on an order-preserving 64-bit key), running tp / fp counts (one scan of the two counters
+//     packed in a 64-bit word), recall / precision / f1 per position with the formulas of
+//     ugvc/utils/stats_utils.py:76-138 in f64 (bit-equal to the host numpy).
+#include "ugvc_prims.hpp"
 
 namespace ugvc {
 
@@ -61,9 +60,10 @@ __global__ void pr_keys_kernel(const double* __restrict__ s, int64_t n, uint64_t
     if (i < n) { keys[i] = f64_key(s[i]); idx[i] = (uint32_t)i; }
 }
 
-__global__ void pr_flags_kernel(const uint32_t* __restrict__ idx, const uint8_t* __restrict__ cls, int64_t n, int* tpf, int* fpf) {
+// tp flag in the low word, fp flag in the high word: one scan carries both running counts (n < 2^31: no carry between them)
+__global__ void pr_flags_kernel(const uint32_t* __restrict__ idx, const uint8_t* __restrict__ cls, int64_t n, uint64_t* __restrict__ tpfp) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { const int c = cls[idx[i]]; tpf[i] = c == 1; fpf[i] = c == 2; }
+    if (i < n) { const int c = cls[idx[i]]; tpfp[i] = (uint64_t)(c == 1) | ((uint64_t)(c == 2) << 32); }
 }
 
 #pragma clang fp contract(off)
@@ -72,13 +72,14 @@ __device__ __forceinline__ double one_minus_ratio(double a, double b, double if_
     return den == 0.0 ? if_zero : 1.0 - a / den;
 }
 
-__global__ void pr_finish_kernel(const uint32_t* __restrict__ idx, const double* __restrict__ s, const int* __restrict__ ctp,
-                                 const int* __restrict__ cfp, int64_t n, int64_t i_tp, int64_t i_fp, int64_t i_fn,
+__global__ void pr_finish_kernel(const uint32_t* __restrict__ idx, const double* __restrict__ s, const uint64_t* __restrict__ ctpfp,
+                                 int64_t n, int64_t i_tp, int64_t i_fp, int64_t i_fn,
                                  double* s_sorted, double* recall, double* precision, double* f1, int32_t* order) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
-    const double c_fn = (double)(i_fn + ctp[i]), c_tp = (double)(i_tp - ctp[i]), c_fp = (double)(i_fp - cfp[i]);
+    const int64_t ctp = (int64_t)(ctpfp[i] & 0xFFFFFFFFull), cfp = (int64_t)(ctpfp[i] >> 32);
+    const double c_fn = (double)(i_fn + ctp), c_tp = (double)(i_tp - ctp), c_fp = (double)(i_fp - cfp);
     const double r = one_minus_ratio(c_fn, c_tp, nan), p = one_minus_ratio(c_fp, c_tp, nan);
     double f = (p + r == 0.0) ? 0.0 : 2.0 * p * r / (p + r);
     if (p != p || r != r) f = nan;
@@ -125,41 +126,27 @@ int ugvc_pr_curve(ugvc_ctx* ctx, const double* score, const uint8_t* cls, int64_
     if (ms_device) *ms_device = 0.f;
     if (n == 0) return 0;
     UGVC_HIP(hipSetDevice(ctx->device));
-    DeviceBuf d_s, d_cls, d_k0, d_k1, d_i0, d_i1, d_tp, d_fp, d_ctp, d_cfp, d_o, d_ord, d_tmp;
-    DeviceBuf* all[] = {&d_s, &d_cls, &d_k0, &d_k1, &d_i0, &d_i1, &d_tp, &d_fp, &d_ctp, &d_cfp, &d_o, &d_ord, &d_tmp};
+    DeviceBuf d_s, d_cls, d_k0, d_k1, d_i0, d_i1, d_tf, d_o, d_ord, d_tmp;
+    DeviceBuf* all[] = {&d_s, &d_cls, &d_k0, &d_k1, &d_i0, &d_i1, &d_tf, &d_o, &d_ord, &d_tmp};
     int rc = 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     do {
         const size_t N = (size_t)n;
         if ((rc = upload(ctx, d_s, score, N * 8)) || (rc = upload(ctx, d_cls, cls, N))) break;
         if ((rc = ensure(d_k0, N * 8)) || (rc = ensure(d_k1, N * 8)) || (rc = ensure(d_i0, N * 4)) || (rc = ensure(d_i1, N * 4)) ||
-            (rc = ensure(d_tp, N * 4)) || (rc = ensure(d_fp, N * 4)) || (rc = ensure(d_ctp, N * 4)) || (rc = ensure(d_cfp, N * 4)) ||
-            (rc = ensure(d_o, N * 8 * 4)) || (rc = ensure(d_ord, N * 4))) break;
-        size_t t_sort = 0, t_scan = 0;
-        if (hipcub::DeviceRadixSort::SortPairs(nullptr, t_sort, d_k0.as<uint64_t>(), d_k1.as<uint64_t>(), d_i0.as<uint32_t>(),
-                                               d_i1.as<uint32_t>(), (int)n, 0, 64, ctx->stream) != hipSuccess ||
-            hipcub::DeviceScan::InclusiveSum(nullptr, t_scan, d_tp.as<int>(), d_ctp.as<int>(), (int)n, ctx->stream) != hipSuccess) {
-            rc = fail("hipcub temp-storage query failed");
-            break;
-        }
-        size_t t_bytes = std::max(t_sort, t_scan);
-        if ((rc = ensure(d_tmp, t_bytes))) break;
+            (rc = ensure(d_tf, N * 8)) || (rc = ensure(d_o, N * 8 * 4)) || (rc = ensure(d_ord, N * 4))) break;
         if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { rc = fail("hipEventCreate failed"); break; }
         const unsigned grid = (unsigned)((n + 255) / 256);
         (void)hipEventRecord(e0, ctx->stream);
         hipLaunchKernelGGL(pr_keys_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_s.as<double>(), n, d_k0.as<uint64_t>(), d_i0.as<uint32_t>());
-        size_t tb = t_bytes;
-        if (hipcub::DeviceRadixSort::SortPairs(d_tmp.p, tb, d_k0.as<uint64_t>(), d_k1.as<uint64_t>(), d_i0.as<uint32_t>(),
-                                               d_i1.as<uint32_t>(), (int)n, 0, 64, ctx->stream) != hipSuccess) { rc = fail("radix sort failed"); break; }
-        hipLaunchKernelGGL(pr_flags_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_i1.as<uint32_t>(), d_cls.as<uint8_t>(), n,
-                           d_tp.as<int>(), d_fp.as<int>());
-        tb = t_bytes;
-        if (hipcub::DeviceScan::InclusiveSum(d_tmp.p, tb, d_tp.as<int>(), d_ctp.as<int>(), (int)n, ctx->stream) != hipSuccess) { rc = fail("scan failed"); break; }
-        tb = t_bytes;
-        if (hipcub::DeviceScan::InclusiveSum(d_tmp.p, tb, d_fp.as<int>(), d_cfp.as<int>(), (int)n, ctx->stream) != hipSuccess) { rc = fail("scan failed"); break; }
+        uint64_t* ks = nullptr;
+        uint32_t* is = nullptr;
+        if ((rc = radix_sort_pairs_u64(ctx, d_tmp, d_k0.as<uint64_t>(), d_k1.as<uint64_t>(), d_i0.as<uint32_t>(), d_i1.as<uint32_t>(), n, &ks, &is))) break;
+        hipLaunchKernelGGL(pr_flags_kernel, dim3(grid), dim3(256), 0, ctx->stream, is, d_cls.as<uint8_t>(), n, d_tf.as<uint64_t>());
+        if ((rc = scan_u64(ctx, d_tmp, d_tf.as<uint64_t>(), n, true))) break;
         double* o = d_o.as<double>();
-        hipLaunchKernelGGL(pr_finish_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_i1.as<uint32_t>(), d_s.as<double>(),
-                           d_ctp.as<int>(), d_cfp.as<int>(), n, initial_tp, initial_fp, initial_fn, o, o + N, o + 2 * N, o + 3 * N,
+        hipLaunchKernelGGL(pr_finish_kernel, dim3(grid), dim3(256), 0, ctx->stream, is, d_s.as<double>(),
+                           d_tf.as<uint64_t>(), n, initial_tp, initial_fp, initial_fn, o, o + N, o + 2 * N, o + 3 * N,
                            order ? d_ord.as<int32_t>() : nullptr);
         (void)hipEventRecord(e1, ctx->stream);
         bool ok = hipMemcpyAsync(sorted_score, o, N * 8, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&

@@ -15,14 +15,13 @@
 //     with scale_contingency_table (round half to even, as numpy); ratio = multinomial_likelihood_ratio(observed,
 //     expected)[1]; is_sec = ratio >= min_ratio; NaN / 0 off the database.  With `mark` the SEC bit is OR-ed into the
 //     resident flags column, so the gathered callset carries it.
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cmath>
 #include <stdlib.h>
 #include <vector>
 
-#include "ugvc_device.hpp"
+#include "ugvc_prims.hpp"
 
 namespace ugvc {
 
@@ -241,19 +240,32 @@ __global__ void sec_iota_kernel(uint32_t* idx, int64_t n) {
     if (i < n) idx[i] = (uint32_t)i;
 }
 
-__global__ void sec_gather_col_kernel(const int32_t* __restrict__ counts, const uint32_t* __restrict__ idx, int64_t n, int k, int c,
-                                      long long* __restrict__ col) {
+// sorted observations -> loci: head[i] = 1 where a new key begins (a 64-bit word: the segment index is its scan)
+__global__ void sec_heads_kernel(const uint64_t* __restrict__ keys, int64_t n, uint64_t* __restrict__ head) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) col[i] = counts[(int64_t)idx[i] * k + c];
+    if (i < n) head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1ull : 0ull;
 }
 
-__global__ void sec_scatter_col_kernel(const long long* __restrict__ sums, int64_t n, int k, int c, int32_t* __restrict__ out,
-                                       int* __restrict__ overflow) {
+// seg[i] = inclusive scan of the heads: observation i belongs to locus seg[i] - 1.  The locus' key is written by its head,
+// its k counts are summed with 64-bit integer atomics (integer sums commute: the result does not depend on the order).
+__global__ void sec_segment_sum_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idx, const uint64_t* __restrict__ seg,
+                                       const int32_t* __restrict__ counts, int64_t n, int k, uint64_t* __restrict__ out_keys,
+                                       unsigned long long* __restrict__ sums) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const long long v = sums[i];
-    if (v > 2147483647ll) { *overflow = 1; out[i * k + c] = 2147483647; }
-    else out[i * k + c] = (int32_t)v;
+    const uint64_t s = seg[i] - 1;
+    if (i == 0 || keys[i] != keys[i - 1]) out_keys[s] = keys[i];
+    const int32_t* row = counts + (int64_t)idx[i] * k;
+    for (int c = 0; c < k; ++c)
+        if (row[c]) atomicAdd(&sums[s * k + c], (unsigned long long)row[c]);
+}
+
+__global__ void sec_narrow_kernel(const unsigned long long* __restrict__ sums, int64_t n_words, int32_t* __restrict__ out, int* __restrict__ overflow) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_words) return;
+    const unsigned long long v = sums[i];
+    if (v > 2147483647ull) { *overflow = 1; out[i] = 2147483647; }
+    else out[i] = (int32_t)v;
 }
 
 }  // namespace ugvc
@@ -272,48 +284,34 @@ int ugvc_sec_db_build(ugvc_ctx* ctx, const uint64_t* keys, const int32_t* counts
     for (int64_t i = 0; i < n_obs * k; ++i)
         if (counts[i] < 0) return fail("counts must be non-negative");
     UGVC_HIP(hipSetDevice(ctx->device));
-    DeviceBuf d_k0, d_k1, d_i0, d_i1, d_cnt, d_col, d_uk, d_sum, d_num, d_out, d_ovf, d_tmp;
-    DeviceBuf* all[] = {&d_k0, &d_k1, &d_i0, &d_i1, &d_cnt, &d_col, &d_uk, &d_sum, &d_num, &d_out, &d_ovf, &d_tmp};
+    DeviceBuf d_k0, d_k1, d_i0, d_i1, d_cnt, d_seg, d_uk, d_sum, d_out, d_ovf, d_tmp;
+    DeviceBuf* all[] = {&d_k0, &d_k1, &d_i0, &d_i1, &d_cnt, &d_seg, &d_uk, &d_sum, &d_out, &d_ovf, &d_tmp};
     int rc = 0;
     const size_t N = (size_t)n_obs;
     const unsigned grid = (unsigned)((n_obs + 255) / 256);
+    int64_t n_unique = 0;
     do {
         if ((rc = upload(ctx, d_k0, keys, N * 8)) || (rc = upload(ctx, d_cnt, counts, N * k * 4))) break;
-        if ((rc = ensure(d_k1, N * 8)) || (rc = ensure(d_i0, N * 4)) || (rc = ensure(d_i1, N * 4)) || (rc = ensure(d_col, N * 8)) ||
-            (rc = ensure(d_uk, N * 8)) || (rc = ensure(d_sum, N * 8)) || (rc = ensure(d_num, 8)) || (rc = ensure(d_out, N * k * 4)) ||
-            (rc = ensure(d_ovf, 4))) break;
-        size_t t_sort = 0, t_red = 0;
-        if (hipcub::DeviceRadixSort::SortPairs(nullptr, t_sort, d_k0.as<uint64_t>(), d_k1.as<uint64_t>(), d_i0.as<uint32_t>(),
-                                               d_i1.as<uint32_t>(), (int)n_obs, 0, 64, ctx->stream) != hipSuccess ||
-            hipcub::DeviceReduce::ReduceByKey(nullptr, t_red, d_k1.as<uint64_t>(), d_uk.as<uint64_t>(), d_col.as<long long>(),
-                                              d_sum.as<long long>(), d_num.as<int>(), hipcub::Sum(), (int)n_obs, ctx->stream) != hipSuccess) {
-            rc = fail("hipcub temp-storage query failed");
+        if ((rc = ensure(d_k1, N * 8)) || (rc = ensure(d_i0, N * 4)) || (rc = ensure(d_i1, N * 4)) || (rc = ensure(d_seg, N * 8)) ||
+            (rc = ensure(d_uk, N * 8)) || (rc = ensure(d_sum, N * k * 8)) || (rc = ensure(d_out, N * k * 4)) || (rc = ensure(d_ovf, 4))) break;
+        if (hipMemsetAsync(d_ovf.p, 0, 4, ctx->stream) != hipSuccess || hipMemsetAsync(d_sum.p, 0, N * k * 8, ctx->stream) != hipSuccess) {
+            rc = fail("hipMemsetAsync failed");
             break;
         }
-        if ((rc = ensure(d_tmp, std::max(t_sort, t_red)))) break;
-        if (hipMemsetAsync(d_ovf.p, 0, 4, ctx->stream) != hipSuccess) { rc = fail("hipMemsetAsync failed"); break; }
         hipLaunchKernelGGL(sec_iota_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_i0.as<uint32_t>(), n_obs);
-        size_t t = d_tmp.cap;
-        if (hipcub::DeviceRadixSort::SortPairs(d_tmp.p, t, d_k0.as<uint64_t>(), d_k1.as<uint64_t>(), d_i0.as<uint32_t>(), d_i1.as<uint32_t>(),
-                                               (int)n_obs, 0, 64, ctx->stream) != hipSuccess) { rc = fail("radix sort failed"); break; }
-        int n_unique = 0;
-        for (int c = 0; c < k && !rc; ++c) {
-            hipLaunchKernelGGL(sec_gather_col_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_cnt.as<int32_t>(), d_i1.as<uint32_t>(), n_obs, k,
-                               c, d_col.as<long long>());
-            t = d_tmp.cap;
-            if (hipcub::DeviceReduce::ReduceByKey(d_tmp.p, t, d_k1.as<uint64_t>(), d_uk.as<uint64_t>(), d_col.as<long long>(),
-                                                  d_sum.as<long long>(), d_num.as<int>(), hipcub::Sum(), (int)n_obs, ctx->stream) != hipSuccess) {
-                rc = fail("reduce by key failed");
-                break;
-            }
-            if (c == 0) {
-                if (hipMemcpyAsync(&n_unique, d_num.p, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-                    hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = fail("sec_db_build: device error"); break; }
-            }
-            hipLaunchKernelGGL(sec_scatter_col_kernel, dim3((unsigned)((n_unique + 255) / 256)), dim3(256), 0, ctx->stream,
-                               d_sum.as<long long>(), (int64_t)n_unique, k, c, d_out.as<int32_t>(), d_ovf.as<int>());
-        }
-        if (rc) break;
+        uint64_t* ks = nullptr;
+        uint32_t* is = nullptr;
+        if ((rc = radix_sort_pairs_u64(ctx, d_tmp, d_k0.as<uint64_t>(), d_k1.as<uint64_t>(), d_i0.as<uint32_t>(), d_i1.as<uint32_t>(), n_obs, &ks, &is))) break;
+        hipLaunchKernelGGL(sec_heads_kernel, dim3(grid), dim3(256), 0, ctx->stream, ks, n_obs, d_seg.as<uint64_t>());
+        if ((rc = scan_u64(ctx, d_tmp, d_seg.as<uint64_t>(), n_obs, true))) break;
+        uint64_t last = 0;
+        if (hipMemcpyAsync(&last, d_seg.as<uint64_t>() + (N - 1), 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = fail("sec_db_build: device error"); break; }
+        n_unique = (int64_t)last;
+        hipLaunchKernelGGL(sec_segment_sum_kernel, dim3(grid), dim3(256), 0, ctx->stream, ks, is, d_seg.as<uint64_t>(), d_cnt.as<int32_t>(), n_obs, k,
+                           d_uk.as<uint64_t>(), d_sum.as<unsigned long long>());
+        hipLaunchKernelGGL(sec_narrow_kernel, dim3((unsigned)((n_unique * k + 255) / 256)), dim3(256), 0, ctx->stream, d_sum.as<unsigned long long>(),
+                           n_unique * k, d_out.as<int32_t>(), d_ovf.as<int>());
         int ovf = 0;
         if (hipMemcpyAsync(out_keys, d_uk.p, (size_t)n_unique * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
             hipMemcpyAsync(out_expected, d_out.p, (size_t)n_unique * k * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||

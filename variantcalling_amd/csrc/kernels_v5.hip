@@ -1612,11 +1612,11 @@ int launch_filter_v5(ugvc_ctx* ctx, const FilterArgs& a) {
     if (a.n == 0) return 0;
     V5Args v;
     if (v5_fill_args(ctx, v, a)) return -1;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};                               // (function attributes are per device)
+    if (!attr_set[ctx->device & 63]) {
         for (K5 f : {fused5_for(0), fused5_for(1), fused5_for(2), fused5_for(3), fused5_for(4), fused5_for(5), fused5_for(3, true), (K5)forest5_kernel})
             UGVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
-        attr_set = true;
+        attr_set[ctx->device & 63] = true;
     }
     // UGVC_DEBUG_SYNC=1: name every launch on stderr and wait for it (a GPU memory fault aborts the process; the
     // last name printed is the kernel that faulted)

@@ -802,6 +802,14 @@ bool v5_available(ugvc_ctx* ctx) {
     if (ctx->has_runs && ctx->runs_n >= ((int64_t)1 << 30)) return false;
     for (int t = 0; t < ctx->n_tracks; ++t)
         if (ctx->trk_n[t] >= ((int64_t)1 << 30)) return false;
+    // LDS of the forest kernel: an indel group's forest + four waves of code planes + its static words
+    // (kernels_v5.hip: k5_forest_lds + 1088) - a forest near the v3 budget goes to v3 instead of failing at launch
+    for (int gi = 1; gi < UGVC_N_GROUPS; ++gi) {
+        const V2Group& g = s->g[gi];
+        if (!g.set) continue;
+        const size_t n_hi = ((size_t)g.T << g.D) / 2;
+        if (n_hi * 12 + (size_t)g.n_pairs * 8 + 48 + 4 * (size_t)kMaxFeatures * 128 + 1088 > 158 * 1024) return false;
+    }
     // LDS: group 0's forest + the thresholds + at least 8 waves of scratch
     const V2Group& g0 = s->g[0];
     size_t forest = 0;

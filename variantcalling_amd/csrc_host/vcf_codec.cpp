@@ -830,6 +830,13 @@ int ugvc_vcf_write_filtered(const ugvc_vcf* h, const char* out_path, const float
             const std::string_view key = full.substr(0, full.find(','));
             if (!have(key)) { stream.append(full); stream.push_back('\n'); }
         }
+        // the SEC filter line only when a row carries the tag (correct_systematic_errors): other outputs keep their bytes
+        bool any_sec = false;
+        for (int64_t k = 0; k < n && !any_sec; ++k) any_sec = (flags[k] & 4u) != 0;
+        if (any_sec && !have("##FILTER=<ID=SEC")) {
+            stream.append("##FILTER=<ID=SEC,Description=\"Systematic error: the cohort's allele counts explain the call\">");
+            stream.push_back('\n');
+        }
         for (auto& l : chrom) { stream.append(l); stream.push_back('\n'); }
     }
     std::vector<int64_t> row_of((size_t)n);
@@ -917,6 +924,7 @@ int ugvc_vcf_write_filtered(const ugvc_vcf* h, const char* out_path, const float
                 bool any = false;
                 if (fl & 1u) { o.append("HPOL_RUN"); any = true; }
                 if ((fl & 2u) || (cohort_extra && cohort_extra[k])) { if (any) o.push_back(';'); o.append("COHORT_FP"); any = true; }
+                if (fl & 4u) { if (any) o.push_back(';'); o.append("SEC"); any = true; }
                 if (filter[k] == 1) { if (any) o.push_back(';'); o.append("LOW_SCORE"); any = true; }
                 if (!any) o.append("PASS");
                 o.push_back('\t');

@@ -114,9 +114,12 @@ class Group:
             except socket.timeout:
                 continue
             try:
-                conn.settimeout(10.0)
-                hello = _recv(conn)
-                if len(hello) != 36 or hello[:32] != token:
+                conn.settimeout(2.0)
+                # the hello is exactly 8 + 36 bytes: read that much and no more before the token has been checked (a
+                # stranger's length prefix is never trusted, and a silent one holds the accept loop for 2 s, not 10)
+                head = _recv_exact(conn, 8 + 36)
+                hello = head[8:]
+                if struct.unpack("<Q", head[:8])[0] != 36 or hello[:32] != token:
                     conn.close()                       # a stranger on our port
                     continue
                 (r,) = struct.unpack("<I", hello[32:])

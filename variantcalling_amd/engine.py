@@ -175,8 +175,14 @@ class Engine:
     def set_reference(self, ref: S.Reference):
         codes = _col(ref.codes, np.uint8)
         off = _col(ref.contig_off, np.int64)
-        self._check(self.lib.ugvc_ref_upload(self._h, _p(codes, _u8p), codes.size, _p(off, _i64p), off.size - 1))
+        buf = codes if codes.size else np.zeros(1, np.uint8)         # (an empty array has no address to hand over)
+        self._check(self.lib.ugvc_ref_upload(self._h, _p(buf, _u8p), codes.size, _p(off, _i64p), off.size - 1))
         self.n_contigs = off.size - 1
+
+    def set_contigs(self, names: list):
+        """Contig dictionary without bases - for the tools that join on (contig, pos) only (SEC apply): the variant upload
+        validates contig indices against it."""
+        self.set_reference(S.Reference(np.zeros(0, np.uint8), np.zeros(len(names) + 1, np.int64), list(names)))
 
     def set_runs(self, runs: S.IntervalTrack, min_len: int = 10, max_dist: int = 10, mark_hpol: bool = True):
         s, e, p = _col(runs.starts, np.int32), _col(runs.ends, np.int32), _col(runs.contig_ptr, np.int32)

@@ -171,6 +171,10 @@ def write_filtered_vcf(path: str, vcf: VcfFile, res: S.FilterResult, blacklist_c
         key = h.split(",")[0]
         if not any(x.startswith(key) for x in have):
             hdr.append(h)
+    # the SEC filter line only when a row carries the tag (correct_systematic_errors; ugvc/reports/report_utils.py:71-75
+    # turns it into filter = "SEC"): every other output keeps its bytes
+    if np.any(np.asarray(res.flags) & S.FLAG_SEC) and not any(x.startswith("##FILTER=<ID=SEC") for x in have):
+        hdr.append('##FILTER=<ID=SEC,Description="Systematic error: the cohort\'s allele counts explain the call">')
     hdr += [h for h in vcf.header if h.startswith("#CHROM")]
     out.write(("\n".join(hdr) + "\n").encode())
     n = len(vcf.records)
@@ -185,6 +189,8 @@ def write_filtered_vcf(path: str, vcf: VcfFile, res: S.FilterResult, blacklist_c
             tags.append("HPOL_RUN")
         if fl & S.FLAG_COHORT_FP or (blacklist_cg is not None and blacklist_cg[k]):
             tags.append("COHORT_FP")
+        if fl & S.FLAG_SEC:
+            tags.append("SEC")
         if res.filter[k] == S.FILTER_LOW_SCORE:
             tags.append("LOW_SCORE")
         f[6] = (";".join(tags) if tags else "PASS").encode()

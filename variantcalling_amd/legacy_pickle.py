@@ -61,9 +61,19 @@ def _holder_class(module: str, name: str):
     return _holders[key]
 
 
+# scikit-learn's compiled tree: `Tree.__setstate__` of scikit-learn >= 1.3 refuses the node array of a <= 1.2 pickle
+# ("node array from the pickle has an incompatible dtype": no `missing_go_to_left` field) - and the reference pins
+# 1.2.2 (setup/environment.yml:399).  Held instead, its state is plain numpy: `model_io.tree_arrays` reads either form.
+_HELD_ON_RETRY = {("sklearn.tree._tree", "Tree")}
+
+
 class _ShimUnpickler(pickle.Unpickler):
+    hold_trees = False
+
     def find_class(self, module, name):
         top = module.split(".", 1)[0]
+        if self.hold_trees and (module, name) in _HELD_ON_RETRY:
+            return _holder_class(module, name)
         if top in _REAL_TOPLEVEL:
             try:
                 return super().find_class(module, name)
@@ -75,7 +85,13 @@ class _ShimUnpickler(pickle.Unpickler):
 def load(path_or_bytes):
     """The object graph of a pickle, absent classes as Holders."""
     raw = path_or_bytes if isinstance(path_or_bytes, (bytes, bytearray)) else open(path_or_bytes, "rb").read()
-    return _ShimUnpickler(io.BytesIO(raw)).load()
+    try:
+        return _ShimUnpickler(io.BytesIO(raw)).load()
+    except ValueError:
+        # an estimator pickled by another scikit-learn generation: keep the compiled trees as data (see above)
+        up = _ShimUnpickler(io.BytesIO(raw))
+        up.hold_trees = True
+        return up.load()
 
 
 def _is_estimator(o) -> bool:

@@ -91,6 +91,33 @@ def flatten_sklearn(model, n_features: int | None = None, track_names: list | No
     return f
 
 
+class _TreeArrays:
+    """What `_flatten_sklearn` reads of a fitted tree, from the compiled `sklearn.tree._tree.Tree` or from its pickled
+    state held as data (legacy_pickle: a <= 1.2 node array that this scikit-learn refuses to load)."""
+    def __init__(self, t):
+        if hasattr(t, "children_left"):
+            self.node_count, self.max_depth = int(t.node_count), int(t.max_depth)
+            self.children_left, self.children_right = t.children_left, t.children_right
+            self.feature, self.threshold, self.value = t.feature, t.threshold, t.value
+            return
+        nodes = getattr(t, "nodes", None)
+        values = getattr(t, "values", None)
+        if nodes is None or values is None or getattr(nodes, "dtype", None) is None or nodes.dtype.names is None:
+            raise ValueError("unreadable scikit-learn tree state in the pickle (expected `nodes` / `values` arrays)")
+        self.node_count = int(getattr(t, "node_count", nodes.shape[0]))
+        nodes = nodes[: self.node_count]
+        self.children_left = np.asarray(nodes["left_child"], np.int64)
+        self.children_right = np.asarray(nodes["right_child"], np.int64)
+        self.feature = np.asarray(nodes["feature"], np.int64)
+        self.threshold = np.asarray(nodes["threshold"], np.float64)
+        self.value = np.asarray(values, np.float64)[: self.node_count]
+        self.max_depth = int(getattr(t, "max_depth", 0))
+
+
+def tree_arrays(t) -> _TreeArrays:
+    return _TreeArrays(t)
+
+
 def _flatten_sklearn(model, n_features: int | None = None) -> S.FlatForest:
     ests = list(model.estimators_) if hasattr(model, "estimators_") else [model]
     classes = list(getattr(model, "classes_", [0, 1]))
@@ -100,7 +127,7 @@ def _flatten_sklearn(model, n_features: int | None = None) -> S.FlatForest:
     node_base = leaf_base = 0
     depth = 0
     for e in ests:
-        t = e.tree_
+        t = tree_arrays(e.tree_)
         n = t.node_count
         is_leaf = t.children_left == -1
         leaf_id = np.cumsum(is_leaf) - 1 + leaf_base
@@ -274,19 +301,22 @@ def load_models(path: str) -> dict:
     return models
 
 
-def load_model_file(path: str, model_name: str | None = None):
+def load_model_file(path: str, model_name: str | None = None, track_names: list | None = None):
     """`--model_file` / `--model_name`: a .npz of flat models, or a pickle holding a dict of
     {name: model}; a model is either [estimator per group] / {group_name: estimator} or one
-    estimator used for every group."""
+    estimator used for every group.  `track_names`: the BED stems of --annotate_intervals in command-line order - an
+    estimator fitted on a named frame finds its interval-annotation columns (`LCR-hs38`, `exome.twist` ...:
+    ugvc/reports/report_data_loader.py:94) by these names."""
     if path.endswith(".npz"):
         models = load_models(path)
     else:
         try:
             with open(path, "rb") as fh:
                 raw = pickle.load(fh)
-        except (ImportError, AttributeError):
-            # a pickle of the reference's own model classes (ugbio_filtering.*, absent here): read the data without
-            # the classes and pull the estimators out of the object graph (legacy_pickle.py)
+        except (ImportError, AttributeError, ValueError):
+            # a pickle of the reference's own model classes (ugbio_filtering.*, absent here), or of estimators of another
+            # scikit-learn generation (ValueError from Tree.__setstate__): read the data without the classes and pull
+            # the estimators out of the object graph (legacy_pickle.py)
             from . import legacy_pickle
             raw = legacy_pickle.find_estimators(legacy_pickle.load(path), S.GROUP_NAMES)
             if not raw:
@@ -297,7 +327,7 @@ def load_model_file(path: str, model_name: str | None = None):
                 m = [m.get(g) for g in S.GROUP_NAMES]       # a group without a model scores 0 / PASS
             if not isinstance(m, (list, tuple)):
                 m = [m] * S.N_GROUPS
-            models[name] = [x if x is None or isinstance(x, S.FlatForest) else flatten_sklearn(x) for x in m]
+            models[name] = [x if x is None or isinstance(x, S.FlatForest) else flatten_sklearn(x, track_names=track_names) for x in m]
     if model_name is None:
         return models
     if model_name not in models:

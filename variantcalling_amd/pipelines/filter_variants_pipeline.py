@@ -57,7 +57,8 @@ def run(argv: list[str]):
     logger.info("reading side tables")
     ref, runs, tracks, bl = common.load_side_tables(args.reference_file, args.runs_file, args.annotate_intervals,
                                                     args.blacklist)
-    forests = model_io.load_model_file(args.model_file, args.model_name)
+    # an estimator fitted on a named frame finds its interval columns by BED stem (`LCR-hs38`, `exome.twist`, ...)
+    forests = model_io.load_model_file(args.model_file, args.model_name, track_names=[t.name for t in tracks])
     common.check_model_tracks(forests, len(tracks), "filter_variants_pipeline")
     lap("side tables + model")
     logger.info("reading %s", args.input_file)

@@ -73,14 +73,35 @@ def _slice_track(tr: S.IntervalTrack, lo: np.ndarray, hi: np.ndarray, shift: np.
     return S.IntervalTrack(st, en, np.asarray(ptr, np.int32), tr.name)
 
 
-def slice_context(ref: S.Reference, runs, tracks: list, blacklist, mine: S.VariantTable, margin: int = 64, pad: int = 128):
+def _run_end(seq: np.ndarray, b: int, clen: int, block: int = 1 << 16) -> int:
+    """First index >= b whose base differs from seq[b - 1] (the end of the run a cut at b falls into), vectorised: a cut
+    inside a multi-megabase N run or a centromere costs a few block compares, not a Python loop per base."""
+    if b <= 0 or b >= clen:
+        return min(max(b, 0), clen)
+    base = seq[b - 1]
+    while b < clen:
+        chunk = seq[b: b + block]
+        diff = np.flatnonzero(chunk != base)
+        if diff.size:
+            return b + int(diff[0])
+        b += chunk.size
+    return clen
+
+
+def slice_context(ref: S.Reference, runs, tracks: list, blacklist, mine: S.VariantTable, margin: int = 64, pad: int = 128,
+                  hpol_dist: int | None = None):
     """What ONE rank needs of the resident tables to score its shard `mine`: per touched contig the
     reference bases [min_pos - margin, max_pos + longest allele + margin) - extended to the end of the homopolymer run
-    the cut would fall into, so every run a variant of the shard can see is whole - the overlapping part of each interval
+    the cut would fall into, so every run a variant of the shard can see is whole (every feature looks FORWARD from a
+    call for its run; backwards only the 5-base motif and the GC window, which the margin covers) - the overlapping part of each interval
     table (+ one row of halo) and the blacklist keys inside, all shifted into the sliced contigs' coordinates; untouched
     contigs keep their index with length 0.  Returns (ref, runs, tracks, blacklist, variants) with results identical to
     scoring `mine` against the full tables (tests/test_host_logic.py on the oracle, tests/test_gpu_parity.py on the GPU).
     A 3.1 Gb genome becomes ~0.4 Gb per rank at 8 ranks."""
+    if hpol_dist is not None:
+        # `--hpol_filter_length_dist L D`: a run D bases beyond the shard's last call still marks it - the table pad
+        # follows the distance the engine is configured with instead of assuming it is small
+        pad = max(pad, int(hpol_dist) + 2)
     n_contigs = ref.n_contigs
     lo = np.zeros(n_contigs, np.int64)
     hi = np.zeros(n_contigs, np.int64)
@@ -96,8 +117,7 @@ def slice_context(ref: S.Reference, runs, tracks: list, blacklist, mine: S.Varia
             a = max(int(mine.pos[f]) - 1 - margin, 0)
             b = min(int(reach[f:l + 1].max()) + margin, clen)
             seq = ref.codes[int(ref.contig_off[cc]): int(ref.contig_off[cc + 1])]
-            while b < clen and b > 0 and seq[b] == seq[b - 1]:                     # finish the run the cut falls into
-                b += 1
+            b = _run_end(seq, b, clen)                                             # finish the run the cut falls into
             b = min(b + margin, clen)                                              # ... and keep the motif behind it
             lo[cc], hi[cc], touched[cc] = a, b, True
     parts = [ref.codes[int(ref.contig_off[cc]) + int(lo[cc]): int(ref.contig_off[cc]) + int(hi[cc])] for cc in range(n_contigs)]
