@@ -163,6 +163,11 @@ def run_filter(args):
     if gather:
         uid = grp.broadcast_bytes(eng.comm_unique_id() if grp.rank == 0 else None, 0)
         eng.comm_init(uid, grp.rank, grp.world)
+        rccl = eng.comm_info()                                   # what RCCL itself reports: a silent one-rank run cannot pass for N
+        if rccl["nranks"] != grp.world or rccl["rank"] != grp.rank:
+            raise SystemExit(f"RCCL communicator reports {rccl}, launcher says rank {grp.rank} of {grp.world}")
+    else:
+        rccl = None
     t_setup = time.perf_counter() - t_setup
 
     # ---- warm-up (untimed)
@@ -239,6 +244,7 @@ def run_filter(args):
                         variants_per_gpu=mine.n, model=MODEL, sharding=f"equal-count x{grp.world}"
                         + (", per-rank genome / side-table slices" if grp.world > 1 else ""),
                         collective="RCCL all-gather (score f32, filter u8, flags u8)" if gather else "none",
+                        rccl_nranks=rccl["nranks"] if rccl else 1,
                         device=info["name"], kernel_variant=args.variant, commit=_git_head()),
             roofline=dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBPS, unit="GB/s",
                           frac=achieved / HBM_PEAK_GBPS, traffic=traffic, traffic_measured_at_commit=traffic_commit,
@@ -348,6 +354,12 @@ def run_c5(args):
     eng.upload_variants(cs.variants)
     X, group = eng.feature_matrix()
     N = X.shape[0]
+    # BASELINE.md C5 "feature-build GB/s": the resident N x F matrix built `steps` times back to back (device events, no
+    # download); algorithmic bytes = the scoring pass's 121.6 B read per variant + 4 F written
+    eng.timed_feature_matrix(2)
+    fm_ms = eng.timed_feature_matrix(max(args.steps, 5))
+    fm_bytes = ALG_BYTES_C3 + 4.0 * X.shape[1]
+    fm_gbps = fm_bytes * N / (fm_ms * 1e-3) / 1e9
     tot_gemm = tot_trav = 0.0
     same = True
     t0 = time.perf_counter()
@@ -366,7 +378,10 @@ def run_c5(args):
           "next to the row traversal",
           dict(bound="mfma", achieved=tops, peak=MFMA_I8_PEAK_TOPS, unit="TOP/s (int8)", frac=tops / MFMA_I8_PEAK_TOPS, traffic=None,
                kernel="forest_gemm_kernel (csrc/kernels_gemm.hip), v_mfma_i32_16x16x64_i8", kernel_ms=tot_gemm,
-               alg_ops_per_variant=2.0 * I * L * T, traversal_ms=tot_trav, traversal_variants_per_s=N / (tot_trav * 1e-3)),
+               alg_ops_per_variant=2.0 * I * L * T, traversal_ms=tot_trav, traversal_variants_per_s=N / (tot_trav * 1e-3),
+               tops_vs_measured_i8_ceiling=tops / 3944.0,
+               feature_build=dict(bound="hbm", ms=fm_ms, achieved=fm_gbps, peak=HBM_PEAK_GBPS, unit="GB/s", frac=fm_gbps / HBM_PEAK_GBPS,
+                                  alg_bytes_per_variant=fm_bytes, kernel="ugvc_feature_matrix (resident N x F f32, no download)")),
           dict(parity=dict(gemm_equals_traversal=bool(same)), wall_s=round(wall, 2)), dtype="f32 compares, int8 MFMA path matrix, f32 margins")
     eng.close()
 

@@ -151,6 +151,9 @@ int ugvc_timed_steps(ugvc_ctx* ctx, int iters, int64_t shard_cap, int gather, fl
 int ugvc_last_step_ms(ugvc_ctx* ctx, float* out, int cap);
 int ugvc_device_sync(ugvc_ctx* ctx);   /* hipDeviceSynchronize on the context's device */
 int ugvc_feature_matrix(ugvc_ctx* ctx, float* x_host, uint8_t* group_host);
+/* `iters` back-to-back builds of the resident N x F matrix, nothing downloaded: total milliseconds on the context stream
+ * (bench.py --workload c5_gemm reports the build in GB/s of its algorithmic bytes: 121.6 read + 4 F written per variant) */
+int ugvc_timed_feature_matrix(ugvc_ctx* ctx, int iters, float* ms_total);
 int ugvc_n_features(ugvc_ctx* ctx);
 /* Config C5 (train_models_pipeline: on-GPU feature matrix + tree-ensemble inference as a leaf-matrix
  * GEMM on the matrix cores; docs/train_models_pipeline.md:46-54 `--evaluate_concordance`): evaluate the
@@ -250,6 +253,9 @@ int ugvc_bridging_snvs(ugvc_ctx* ctx, const ugvc_variants* v, const uint8_t* is_
 int ugvc_comm_unique_id(uint8_t id[128]);
 int ugvc_comm_init(ugvc_ctx* ctx, const uint8_t id[128], int rank, int world);
 int ugvc_comm_destroy(ugvc_ctx* ctx);
+/* what RCCL itself reports about the communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice): bench.py and the
+ * multi-rank tool print it, so a run that silently fell back to one rank cannot pass for N */
+int ugvc_comm_info(ugvc_ctx* ctx, int* nranks, int* rank, int* device);
 int ugvc_allgather_resident(ugvc_ctx* ctx, int64_t shard_cap);   /* async: collective on its own stream */
 int ugvc_gather_fence(ugvc_ctx* ctx);                             /* context stream waits for the outstanding gathers */
 /* zero-copy form used by ugvc_timed_steps: ugvc_gather_target picks the next of two gather buffers (waiting for

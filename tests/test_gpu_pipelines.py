@@ -184,3 +184,120 @@ def test_wgs_sized_contig_list_and_multiallelic_records_through_the_cli(tmp_path
     assert np.array_equal(score[v.order], exp.tree_score) or np.array_equal(score, exp.tree_score[inv])
     low = np.array(["LOW_SCORE" in t for t in tags])
     assert np.array_equal(low[v.order], exp.filter == S.FILTER_LOW_SCORE)
+
+
+def test_evaluate_concordance_device_flag_gives_identical_files(tmp_path):
+    """`evaluate_concordance --device N`: the cumulative performance curves come from ugvc_pr_curve (hand-written radix
+    sort + scan + f64 finish) - the files must equal the host run's byte for byte (ties, NaN scores, missing candidates)."""
+    import filecmp
+    from test_evaluate_concordance import _frame_with_expected_counts, _split_by_chrom
+    from variantcalling_amd.io import h5
+    from variantcalling_amd.pipelines import evaluate_concordance
+    rng = np.random.default_rng(8)
+    fr = _frame_with_expected_counts(rng)
+    sc = np.asarray(fr["tree_score"], np.float64)
+    sc[::7] = np.round(sc[::7], 1)                     # runs of equal scores: the tie rule (input order) matters
+    fr["tree_score"] = sc
+    src = str(tmp_path / "in.h5")
+    h5.write_hdf(src, _split_by_chrom(fr))
+    evaluate_concordance.run(["--input_file", src, "--output_prefix", str(tmp_path / "host")])
+    evaluate_concordance.run(["--input_file", src, "--output_prefix", str(tmp_path / "gpu"), "--device", "0"])
+    for ext in (".h5", ".stats.csv", ".thresholds.csv"):
+        assert filecmp.cmp(str(tmp_path / "host") + ext, str(tmp_path / "gpu") + ext, shallow=False), ext
+    perf = h5.read_hdf(str(tmp_path / "gpu") + ".h5", "performance_curve")
+    assert perf["score"][0].size > 1000 and np.isfinite(perf["f1"][0]).any()
+
+
+def test_sec_training_then_correct_systematic_errors(tmp_path):
+    """The two SEC tools end to end (/root/reference/ugvc/__main__.py:19,56; flags BUILDER-DEFINED): a database from four
+    cohort VCFs, applied to a fifth callset; database and verdicts equal oracle/stats.py on the same inputs."""
+    import gzip
+    from oracle import stats as st
+    from variantcalling_amd.pipelines import correct_systematic_errors, sec_training
+    cs = synth.make_callset(30_000, genome_len=20_000_000, n_contigs=3, seed=77)
+    fa = str(tmp_path / "ref.fa"); fasta.write_fasta(fa, cs.ref)
+    rng = np.random.default_rng(5)
+    cohort, obs_k, obs_c = [], [], []
+    for s in range(4):
+        keep = np.flatnonzero(rng.random(cs.variants.n) < 0.6)
+        parts = [cs.variants.slice(int(a), int(a) + 1) for a in keep[:0]]          # (slices are contiguous: build by mask below)
+        vt = cs.variants
+        sub = S.VariantTable(**{c: np.ascontiguousarray(getattr(vt, c)[keep]) for c in S.VariantTable.COLS if c not in ("ref_off", "alt_off")},
+                             ref_off=vt.ref_off[keep], alt_off=vt.alt_off[keep], alleles=vt.alleles)
+        sub.dp = rng.integers(10, 60, keep.size).astype(np.int32)
+        sub.ad_alt = (sub.dp * rng.random(keep.size) * 0.6).astype(np.int32)
+        sub.ad_ref = (sub.dp - sub.ad_alt - rng.integers(0, 3, keep.size)).clip(0).astype(np.int32)
+        p = str(tmp_path / f"sample{s}.vcf.gz")
+        vcfio.write_vcf_from_table(p, sub, cs.ref.names)
+        cohort += ["--inputs", p]
+        k, c = sec_training.observations(sub)
+        obs_k.append(k); obs_c.append(c)
+    db = str(tmp_path / "cohort.sec.npz")
+    assert sec_training.run(["sec_training", "--reference_file", fa, "--output_file", db] + cohort) == 0
+    z = np.load(db)
+    ok, oe = st.sec_db_build(np.concatenate(obs_k), np.concatenate(obs_c))
+    assert np.array_equal(z["keys"], ok) and np.array_equal(z["expected"], oe) and int(z["n_samples"]) == 4
+    # apply to the full callset
+    calls = str(tmp_path / "calls.vcf.gz")
+    vcfio.write_vcf_from_table(calls, cs.variants, cs.ref.names)
+    out = str(tmp_path / "calls.sec.vcf.gz")
+    assert correct_systematic_errors.run(["correct_systematic_errors", "--input_file", calls, "--sec_db", db, "--reference_file", fa,
+                                          "--output_file", out, "--min_ratio", "0.05"]) == 0
+    vt = cs.variants
+    keys = (vt.contig.astype(np.uint64) << np.uint64(32)) | vt.pos.astype(np.uint64)
+    ratio, hit = st.sec_apply(keys, vt.dp, vt.ad_ref, vt.ad_alt, ok, oe, 0.05, True)
+    lines = [x for x in gzip.open(out, "rt").read().splitlines()]
+    assert any(x.startswith("##FILTER=<ID=SEC") for x in lines) and any(x.startswith("##INFO=<ID=SEC_LR") for x in lines)
+    recs = [x.split("\t") for x in lines if not x.startswith("#")]
+    assert len(recs) == vt.n
+    got_hit = np.array(["SEC" in r[6].split(";") for r in recs])
+    got_lr = np.array([float(dict(kv.split("=") for kv in r[7].split(";") if "=" in kv).get("SEC_LR", "nan")) for r in recs])
+    on_db = ~np.isnan(ratio)
+    assert np.array_equal(~np.isnan(got_lr), on_db) and on_db.sum() > 10_000
+    sliver = np.abs(ratio - 0.05) < 1e-9                  # device lgamma / exp vs scipy: equal outside this sliver
+    assert np.array_equal(got_hit[~sliver], hit[~sliver]) and 0 < hit.sum() < on_db.sum()
+    assert np.allclose(got_lr[on_db], ratio[on_db].astype(np.float32), rtol=1e-6, atol=1e-30)
+    assert os.path.exists(out + ".tbi")
+
+
+def _hip_device_count() -> int:
+    import ctypes
+    n = ctypes.c_int(0)
+    try:
+        ctypes.CDLL("libamdhip64.so").hipGetDeviceCount(ctypes.byref(n))
+    except OSError:
+        return 0
+    return n.value
+
+
+def test_filter_variants_pipeline_two_ranks(tmp_path, frozen_models):
+    """Config C4 through the TOOL: `filter_variants_pipeline` under a two-process launch (RANK / WORLD_SIZE / MASTER_* as
+    `python -m torch.distributed.run` sets them; torch itself is never imported) - equal-count shards, per-rank genome and
+    table slices, ONE RCCL all-gather of (score, filter, flags), rank 0 writes - must produce the file the single-process
+    run writes, byte for byte.  Needs two GPUs: skipped on a one-GPU box."""
+    import filecmp
+    import socket
+    import subprocess
+    import sys
+    if _hip_device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL refuses two ranks on one device)")
+    cs = synth.make_callset(120_000, genome_len=80_000_000, n_contigs=4, seed=31)
+    d = _write_inputs(tmp_path, cs)
+    common = ["--input_file", d["vcf"], "--model_file", os.path.join(GOLDEN, "synth_rf_v1.npz"), "--model_name", RF, "--runs_file", d["runs"],
+              "--hpol_filter_length_dist", "10", "10", "--blacklist", d["bl"], "--reference_file", d["fa"], "--flow_order", "TGCA"] + d["ann"]
+    one = str(tmp_path / "one.vcf.gz")
+    subprocess.run([sys.executable, "-m", "variantcalling_amd", "filter_variants_pipeline"] + common + ["--output_file", one], check=True,
+                   cwd=os.path.dirname(GOLDEN) + "/..", timeout=600)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    two = str(tmp_path / "two.vcf.gz")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", LOCAL_WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-m", "variantcalling_amd", "filter_variants_pipeline"] + common + ["--output_file", two],
+                                      env=env, cwd=os.path.dirname(GOLDEN) + "/.."))
+    assert [p.wait(timeout=900) for p in procs] == [0, 0]
+    assert filecmp.cmp(one, two, shallow=False)
+    assert filecmp.cmp(one + ".tbi", two + ".tbi", shallow=False)

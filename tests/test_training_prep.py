@@ -52,6 +52,34 @@ def test_filter_status_and_interval_flags(tmp_path):
     tr = S.IntervalTrack(np.array([10, 100], np.int32), np.array([20, 150], np.int32), np.array([0, 1, 2], np.int32), "r")
     got = train_models_pipeline._inside_intervals(tr, np.array([0, 0, 0, 1, 1, 1], np.uint16), np.array([10, 11, 20, 100, 150, 151], np.int32))
     assert got.tolist() == [False, True, True, False, True, False]
-    with pytest.raises(NotImplementedError, match="joint"):
+    with pytest.raises(ValueError, match="single_sample"):
         train_models_pipeline.run(["train_models_pipeline", "--input_file", "x.vcf", "--reference", "r.fa", "--output_file_prefix",
-                                   str(tmp_path / "m"), "--vcf_type", "joint"])
+                                   str(tmp_path / "m"), "--vcf_type", "trio"])
+
+
+def test_joint_callset_is_folded_to_one_row_per_record(tmp_path):
+    """`--vcf_type joint` (docs/train_models_pipeline.md:72-73), BUILDER-DEFINED fold: AD / DP summed over the samples, the best
+    GQ, the most alternate GT; site-level columns untouched; one row per record in (contig, pos) order."""
+    import argparse
+    from variantcalling_amd.io import vcf_native
+    lines = ["##fileformat=VCFv4.2", "##contig=<ID=c1>", "##contig=<ID=c2>",
+             "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\ts1\ts2\ts3",
+             "c1\t100\t.\tA\tG\t50\t.\tSOR=1.5\tGT:AD:DP:GQ\t0/1:10,5:15:40\t0/0:20,0:20:60\t1/1:0,9:9:30",
+             "c2\t7\trs1\tAT\tA\t30\t.\tSOR=0.5\tGT:AD:DP:GQ\t0/0:8,0:8:20\t./.:.:.:.\t0/1:4,4:9:99",
+             "c1\t40\t.\tC\tT\t10\t.\tSOR=2\tGT:AD:DP:GQ\t0/1:3,3:6:10\t0/1:2,2:4:12\t0/1:1,1:2:5"]
+    path = str(tmp_path / "joint.vcf")
+    open(path, "w").write("\n".join(lines) + "\n")
+    assert train_models_pipeline._n_samples(path) == 3
+    ref = argparse.Namespace(names=["c1", "c2"])
+    args = argparse.Namespace(input_file=path, mutect=False, vcf_type="joint")
+    first = vcf_native.read_vcf(path, ref.names)
+    vt = train_models_pipeline._fold_joint_samples(args, ref, first)
+    assert vt.pos.tolist() == [40, 100, 7] and vt.contig.tolist() == [0, 0, 1]
+    assert vt.dp.tolist() == [12, 44, 17] and vt.ad_ref.tolist() == [6, 30, 12] and vt.ad_alt.tolist() == [6, 14, 4]
+    assert vt.gq.tolist() == [12, 60, 99] and vt.gt.tolist() == [1, 2, 1]
+    assert vt.qual.tolist() == [10.0, 50.0, 30.0] and np.allclose(vt.sor, [2.0, 1.5, 0.5])
+    one = str(tmp_path / "one.vcf")
+    open(one, "w").write("\n".join(l if not l.startswith(("c", "#CHROM")) else "\t".join(l.split("\t")[:10]) for l in lines) + "\n")
+    args.input_file = one
+    same = train_models_pipeline._fold_joint_samples(args, ref, vcf_native.read_vcf(one, ref.names))
+    assert same.dp.tolist() == [6, 15, 8]                                  # a single-sample file: nothing to pool

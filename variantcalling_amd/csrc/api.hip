@@ -124,6 +124,9 @@ int launch_score(ugvc_ctx* ctx, const FilterArgs& a) {
     return launch_filter(ctx, a, true, false);
 }
 
+void pipe_destroy(ugvc_ctx* ctx);                                                          // pipeline.hip
+int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_results* out, int n_chunks);
+
 }  // namespace ugvc
 
 using namespace ugvc;
@@ -159,6 +162,7 @@ int ugvc_ctx_destroy(ugvc_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     ugvc_comm_destroy(ctx);
+    pipe_destroy(ctx);
     v2_destroy(ctx);
     DeviceBuf* all[] = {&ctx->ref, &ctx->contig_off, &ctx->runs_s, &ctx->runs_e, &ctx->runs_p, &ctx->runs_c, &ctx->bl, &ctx->bl_c,
                         &ctx->v_contig, &ctx->v_pos, &ctx->v_rl, &ctx->v_al, &ctx->v_ro, &ctx->v_ao,
@@ -479,6 +483,15 @@ int ugvc_results_download(ugvc_ctx* ctx, const ugvc_results* out) {
 }
 
 int ugvc_filter_variants(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_results* out) {
+    // large callsets: a chunk pipeline - host validation + staging || H2D || pass || D2H (pipeline.hip); UGVC_PIPE_CHUNKS
+    // sets the number of chunks (1 = the plain upload / pass / download sequence below)
+    if (ctx && v && out && v->n >= 262144 && check_variants(v) == 0 && ctx->n_contigs > 0) {
+        static const int chunks = getenv("UGVC_PIPE_CHUNKS") ? atoi(getenv("UGVC_PIPE_CHUNKS")) : 8;
+        if (chunks > 1) {
+            UGVC_HIP(hipSetDevice(ctx->device));
+            return filter_variants_pipelined(ctx, v, out, chunks);
+        }
+    }
     if (ugvc_variants_upload(ctx, v)) return -1;
     if (ugvc_filter_resident(ctx)) return -1;
     return ugvc_results_download(ctx, out);
@@ -575,12 +588,32 @@ int ugvc_feature_matrix(ugvc_ctx* ctx, float* x_host, uint8_t* group_host) {
     if (ensure(ctx->x_mat, n * F * 4) || ensure(ctx->x_group, n)) return -1;
     FilterArgs a;
     if (build_args(ctx, a, true)) return -1;
-    if (launch_filter(ctx, a, false, true)) return -1;
+    // the fused kernel's featurize waves (kernels_v5.hip, WX) when the side tables allow, else the universal kernel
+    if (fm5_available(ctx) ? launch_feature_matrix_v5(ctx, a) : launch_filter(ctx, a, false, true)) return -1;
     if (n) {
         UGVC_HIP(hipMemcpyAsync(x_host, ctx->x_mat.p, n * F * 4, hipMemcpyDeviceToHost, ctx->stream));
         if (group_host) UGVC_HIP(hipMemcpyAsync(group_host, ctx->x_group.p, n, hipMemcpyDeviceToHost, ctx->stream));
     }
     UGVC_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+
+// `iters` back-to-back builds of the resident N x F feature matrix (no download): bench.py's C5 "feature-build GB/s"
+int ugvc_timed_feature_matrix(ugvc_ctx* ctx, int iters, float* ms_total) {
+    if (!ctx || !ms_total || iters < 1) return fail("bad arguments");
+    UGVC_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)ctx->n;
+    const size_t F = (size_t)(UGVC_N_BASE_FEATURES + ctx->n_tracks);
+    if (ensure(ctx->x_mat, n * F * 4) || ensure(ctx->x_group, n)) return -1;
+    FilterArgs a;
+    if (build_args(ctx, a, true)) return -1;
+    UGVC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    for (int it = 0; it < iters; ++it)
+        if (fm5_available(ctx) ? launch_feature_matrix_v5(ctx, a) : launch_filter(ctx, a, false, true)) return -1;
+    UGVC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    UGVC_HIP(hipEventSynchronize(ctx->ev1));
+    UGVC_HIP(hipEventElapsedTime(ms_total, ctx->ev0, ctx->ev1));
     return 0;
 }
 

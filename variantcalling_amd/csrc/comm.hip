@@ -18,6 +18,9 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
@@ -41,6 +44,9 @@ static int load_rccl() {
     UGVC_SYM(GetUniqueId, "ncclGetUniqueId");
     UGVC_SYM(CommInitRank, "ncclCommInitRank");
     UGVC_SYM(CommDestroy, "ncclCommDestroy");
+    UGVC_SYM(CommCount, "ncclCommCount");
+    UGVC_SYM(CommUserRank, "ncclCommUserRank");
+    UGVC_SYM(CommCuDevice, "ncclCommCuDevice");
     UGVC_SYM(AllGather, "ncclAllGather");
     UGVC_SYM(GroupStart, "ncclGroupStart");
     UGVC_SYM(GroupEnd, "ncclGroupEnd");
@@ -93,6 +99,20 @@ int ugvc_comm_init(ugvc_ctx* ctx, const uint8_t id[128], int rank, int world) {
         UGVC_HIP(hipEventCreateWithFlags(&ctx->ev_gather_done[k], hipEventDisableTiming));
         ctx->gather_pending[k] = 0;
     }
+    return 0;
+}
+
+int ugvc_comm_info(ugvc_ctx* ctx, int* nranks, int* rank, int* device) {
+    if (!ctx) return fail("ctx is NULL");
+    if (!ctx->comm) return fail("communicator not initialised (ugvc_comm_init)");
+    ncclComm_t comm = static_cast<ncclComm_t>(ctx->comm);
+    int a = 0, b = 0, c = 0;
+    UGVC_NCCL(g_rccl.CommCount(comm, &a));
+    UGVC_NCCL(g_rccl.CommUserRank(comm, &b));
+    UGVC_NCCL(g_rccl.CommCuDevice(comm, &c));
+    if (nranks) *nranks = a;
+    if (rank) *rank = b;
+    if (device) *device = c;
     return 0;
 }
 

@@ -9,7 +9,7 @@
 //   * database = sorted unique locus keys (contig << 32 | pos, the blacklist key) + k expected counts per locus, the
 //     cohort's summed allele tallies (k = 2: ref, alt; k = 3: ref, alt, other);
 //   * build   = concatenated per-sample (key, counts) observations -> stable radix sort by key -> segmented sums
-//     (rocPRIM via hipCUB: library primitives for a library-shaped step);
+//     (the library's own LSD radix sort + scan, kernels_prims.hip; sums by 64-bit integer atomics);
 //   * apply   = per resident variant: exact key lookup (two-level: every 64th key first, then one 64-key block);
 //     observed = (ad_ref, ad_alt[, max(dp - ad_ref - ad_alt, 0)]); expected optionally rescaled to the observed depth
 //     with scale_contingency_table (round half to even, as numpy); ratio = multinomial_likelihood_ratio(observed,
@@ -133,19 +133,41 @@ __device__ __forceinline__ void sec_log_pmf2_tab(const int* x, const int* e, int
 // step by the whole wave - happens once per wave; a tile whose calls run past the staged keys searches from the carried
 // rank in HBM.  (sec_apply_kernel stays as the checker of this one: UGVC_SEC_SIMPLE=1 selects it.)
 constexpr int kSecStage = 128;
+constexpr int kSecBlock = 1024;                                   // 16 waves; two workgroups per CU by LDS
+constexpr int kSecLdsTab = 2048;                                  // log(m!) and log(m) for m <= 2048 in LDS (2 x 16 KB)
 
-__global__ __launch_bounds__(256) void sec_apply_tiles_kernel(const uint16_t* __restrict__ contig, const int32_t* __restrict__ pos,
-                                                              const int32_t* __restrict__ dp, const int32_t* __restrict__ adr,
-                                                              const int32_t* __restrict__ ada, int64_t n,
-                                                              const uint64_t* __restrict__ keys, const int32_t* __restrict__ expected,
-                                                              const double* __restrict__ lg_tab, int64_t n_db, int k, double min_ratio, int scale,
-                                                              double* __restrict__ ratio, uint8_t* __restrict__ is_sec, uint8_t* __restrict__ flags,
-                                                              int tiles_per_wave) {
-    __shared__ uint64_t stage_all[4][kSecStage];
+// Round 3: what the round-2 kernel spent its time on was the log tables - twelve 8-byte gathers per hit from a 64 KB
+// table in L2 (a 64-lane gather of scattered 8-byte words keeps the texture path busy for ~64 cycles), then two f64 exp
+// and an f64 division per hit.  Here the first 2048 entries of both tables sit in LDS (depths beyond that read the
+// resident table, beyond 4096 libm), and the verdict is taken in the LOG domain - log ratio = lp_e - lp_x against
+// log(min_ratio) - so nothing is exponentiated unless the caller downloads the ratios (WANT_RATIO) or the log ratio lies
+// within 1e-9 of the threshold / a pmf underflows (then the round-2 expression decides: identical verdicts in every mode).
+__device__ __forceinline__ double sec_lf(const double* lt, const double* __restrict__ tab, int m) {
+    return m <= kSecLdsTab ? lt[m] : sec_log_fact(tab, m);
+}
+__device__ __forceinline__ double sec_li(const double* lt, const double* __restrict__ tab, long long m) {
+    return m <= kSecLdsTab ? lt[kSecLdsTab + 1 + m] : sec_log_int(tab, m);
+}
+
+template <bool WANT_RATIO>
+__global__ __launch_bounds__(kSecBlock) void sec_apply_tiles_kernel(const uint16_t* __restrict__ contig, const int32_t* __restrict__ pos,
+                                                                    const int32_t* __restrict__ dp, const int32_t* __restrict__ adr,
+                                                                    const int32_t* __restrict__ ada, int64_t n,
+                                                                    const uint64_t* __restrict__ keys, const int32_t* __restrict__ expected,
+                                                                    const double* __restrict__ lg_tab, int64_t n_db, int k, double min_ratio,
+                                                                    double log_min, int scale, double* __restrict__ ratio,
+                                                                    uint8_t* __restrict__ is_sec, uint8_t* __restrict__ flags, int tiles_per_wave) {
+    __shared__ double lt[2 * (kSecLdsTab + 1)];
+    __shared__ uint64_t stage_all[kSecBlock / 64][kSecStage];
+    for (int q = threadIdx.x; q <= kSecLdsTab; q += kSecBlock) {
+        lt[q] = lg_tab[q];
+        lt[kSecLdsTab + 1 + q] = lg_tab[kSecLgTab + 1 + q];
+    }
+    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint64_t* stage = stage_all[wave];
     const int64_t n_tiles = (n + 63) >> 6;
-    const int64_t t0 = ((int64_t)blockIdx.x * 4 + wave) * tiles_per_wave;
+    const int64_t t0 = ((int64_t)blockIdx.x * (kSecBlock / 64) + wave) * tiles_per_wave;
     const int64_t t1 = t0 + tiles_per_wave < n_tiles ? t0 + tiles_per_wave : n_tiles;
     if (t0 >= t1) return;
     auto key_of = [&](int64_t i) { return ((uint64_t)contig[i] << 32) | (uint32_t)pos[i]; };
@@ -209,7 +231,9 @@ __global__ __launch_bounds__(256) void sec_apply_tiles_kernel(const uint16_t* __
         if (t + 1 < t1) fetch(Lb, s0, s1);                          // in flight during this tile's arithmetic
         double r = __longlong_as_double(0x7ff8000000000000ll);
         uint8_t hit = 0;
-        if (found && valid) {
+        const bool go = found && valid;
+        double lp_e = 0.0, lp_x = 0.0;
+        if (go) {
             int a[kSecMaxK], e[kSecMaxK];
             const int r0 = adr[i] > 0 ? adr[i] : 0, a0 = ada[i] > 0 ? ada[i] : 0;
             a[0] = r0;
@@ -222,13 +246,34 @@ __global__ __launch_bounds__(256) void sec_apply_tiles_kernel(const uint16_t* __
                 const double f = (double)na / (double)s;              // stats_utils.py:24-27: np.round(table * (n / sum))
                 for (int c = 0; c < k; ++c) e[c] = (int)rint((double)e[c] * f);
             }
-            double lp_e, lp_x;
-            sec_log_pmf2_tab(a, e, k, lg_tab, lp_e, lp_x);
-            r = exp(lp_e) / exp(lp_x);
-            hit = r >= min_ratio ? 1 : 0;
+            // sec_log_pmf2_tab with the LDS tables
+            long long tot_e = 0, tot_x = 0;
+            int nn = 0;
+            for (int c = 0; c < k; ++c) { tot_e += (long long)e[c] + 1; tot_x += (long long)a[c] + 1; nn += a[c]; }
+            const double lte = sec_li(lt, lg_tab, tot_e), ltx = sec_li(lt, lg_tab, tot_x);
+            double g = sec_lf(lt, lg_tab, nn), se = 0.0, sx = 0.0;
+            for (int c = 0; c < k; ++c) {
+                if (a[c] > 0) {
+                    se += (double)a[c] * (sec_li(lt, lg_tab, (long long)e[c] + 1) - lte);
+                    sx += (double)a[c] * (sec_li(lt, lg_tab, (long long)a[c] + 1) - ltx);
+                }
+                g -= sec_lf(lt, lg_tab, a[c]);
+            }
+            lp_e = g + se;
+            lp_x = g + sx;
         }
+        const double d = lp_e - lp_x;
+        const bool exact = go && (WANT_RATIO || !(min_ratio > 0.0) || fabs(d - log_min) <= 1e-9 * fmax(1.0, fabs(log_min)) ||
+                                  lp_e < -700.0 || lp_x < -700.0);
+        if (__builtin_amdgcn_ballot_w64(exact) != 0) {
+            if (exact) {
+                r = exp(lp_e) / exp(lp_x);
+                hit = r >= min_ratio ? 1 : 0;
+            }
+        }
+        if (go && !exact) hit = d >= log_min ? 1 : 0;
         if (valid) {
-            if (ratio) ratio[i] = r;
+            if (WANT_RATIO && ratio) ratio[i] = r;
             if (is_sec) is_sec[i] = hit;
             if (flags && hit) flags[i] |= UGVC_FLAG_SEC;
         }
@@ -376,10 +421,13 @@ int ugvc_sec_apply(ugvc_ctx* ctx, double min_ratio, int scale_expected, int mark
             const int64_t want_waves = (int64_t)ctx->n_cus * 32;
             const int tpw = (int)std::max<int64_t>((n_tiles + want_waves - 1) / want_waves, 1);
             const int64_t n_waves = (n_tiles + tpw - 1) / tpw;
-            hipLaunchKernelGGL(sec_apply_tiles_kernel, dim3((unsigned)((n_waves + 3) / 4)), dim3(256), 0, ctx->stream, ctx->v_contig.as<uint16_t>(),
+            const unsigned grid = (unsigned)((n_waves + kSecBlock / 64 - 1) / (kSecBlock / 64));
+            const double log_min = min_ratio > 0.0 ? std::log(min_ratio) : -1e300;
+            auto kern = ratio ? sec_apply_tiles_kernel<true> : sec_apply_tiles_kernel<false>;
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(kSecBlock), 0, ctx->stream, ctx->v_contig.as<uint16_t>(),
                                ctx->v_pos.as<int32_t>(), ctx->v_dp.as<int32_t>(), ctx->v_adr.as<int32_t>(), ctx->v_ada.as<int32_t>(), n,
                                ctx->sec_keys.as<uint64_t>(), ctx->sec_exp.as<int32_t>(), ctx->sec_lgtab.as<double>(), ctx->n_sec, ctx->sec_k,
-                               min_ratio, scale_expected, ratio ? d_r.as<double>() : nullptr, is_sec ? d_s.as<uint8_t>() : nullptr,
+                               min_ratio, log_min, scale_expected, ratio ? d_r.as<double>() : nullptr, is_sec ? d_s.as<uint8_t>() : nullptr,
                                mark ? ctx->r_flags.as<uint8_t>() : nullptr, tpw);
         }
         if (hipGetLastError() != hipSuccess) { rc = fail("sec_apply: launch failed"); break; }

@@ -428,9 +428,31 @@ __device__ __forceinline__ void issue_slices(const V5Args& v, const Brk<NT>& bk,
     }
 }
 
+
+// ---- config C5: the N x F f32 feature matrix from the same featurize waves (round 3) -------------------
+// `train_models_pipeline` fits on this matrix (docs/train_models_pipeline.md:5-10).  Round 2 built it with the universal
+// one-thread-per-variant kernel (per-lane binary searches: 0.10 of the HBM roofline); with WX the fused kernel's
+// tiles write the lane's RAW feature values (schema.BASE_FEATURES order) instead of ranking them and walking - no model
+// is needed, nothing but X and `group` is written.  A row is 4 F bytes: 16-byte stores when F is a multiple of 4.
+__device__ __forceinline__ void store_feature_row(const FilterArgs& a, uint32_t i, bool live, const float (&x)[kMaxFeatures], int group) {
+    if (!live) return;
+    const int F = UGVC_N_BASE_FEATURES + a.n_tracks;
+    float* row = a.X + (size_t)i * (size_t)F;
+    if ((F & 3) == 0) {
+#pragma unroll
+        for (int q = 0; q < kMaxFeatures / 4 + 1; ++q)
+            if (4 * q < F) reinterpret_cast<float4*>(row)[q] = make_float4(x[4 * q], x[(4 * q + 1) % kMaxFeatures], x[(4 * q + 2) % kMaxFeatures], x[(4 * q + 3) % kMaxFeatures]);
+    } else {
+#pragma unroll
+        for (int f = 0; f < kMaxFeatures; ++f)
+            if (f < F) row[f] = x[f];
+    }
+    if (a.group) a.group[i] = (uint8_t)group;
+}
+
 // ---- SNP / MNP tile: features of 64 substitutions (ref_len == alt_len) ---------------------------------
 // Writes the flags column, leaves the 16-bit codes of the group-0 forest in the wave's code planes.
-template <int NTRK>
+template <int NTRK, bool WX>
 __device__ __forceinline__ void featurize_snp_tile(const V5Args& v, const Scratch& sc, int lane, uint32_t i, bool live, bool has_model,
                                                    const SnpCols& k, Brk<1 + NTRK>& bk, SlicePre<1 + NTRK>& pre, PhaseClk& pc) {
     constexpr int NT = 1 + NTRK;                               // interval tables: runs + tracks
@@ -589,9 +611,9 @@ __device__ __forceinline__ void featurize_snp_tile(const V5Args& v, const Scratc
     uint8_t flags = (uint8_t)(jo.trk << UGVC_FLAG_TRACK0_SHIFT);
     if (jo.cohort) flags |= UGVC_FLAG_COHORT_FP;
     if (a.mark_hpol && (jo.inside_run || jo.close_run)) flags |= UGVC_FLAG_HPOL_RUN;
-    if (live) stg32(a.flags, i, flags);
+    if (live && !WX) stg32(a.flags, i, flags);
     CLK(pc, 2);
-    if (!has_model) return;
+    if (!has_model && !WX) return;
     // (the window gather is consumed here, behind the joins: its round trip hides under the rank / join work)
     // ---- window: bases pos-5 .. pos+5 in bytes 0..10 of (w0, w1, w2)
     uint32_t w0 = __builtin_amdgcn_alignbyte(xw.y, xw.x, sh);
@@ -616,7 +638,7 @@ __device__ __forceinline__ void featurize_snp_tile(const V5Args& v, const Scratc
     const bool motif_n = any_zero_byte(w0) || any_zero_byte(w1 | 0x0000FF00u) || any_zero_byte(w2 | 0xFF000000u);
     // gc_content (10): bases pos-4 .. pos+5; everything that is not A / T counts (N included, as the reference's string test)
     const uint32_t n_at = (uint32_t)__popc(at_bytes(w0) & 0x01010100u) + (uint32_t)__popc(at_bytes(w1)) + (uint32_t)__popc(at_bytes(w2) & 0x00010101u);
-    const uint32_t gc_code = lds_u16(sc.gcr_b + 2u * (gc_len * 11u + (gc_len - n_at)));       // group 0
+    const uint32_t gc_code = WX ? 0u : lds_u16(sc.gcr_b + 2u * (gc_len * 11u + (gc_len - n_at)));       // group 0
     // cycle skip
     int css = 0;
     if (!(motif_n || rbase == 0 || abase == 0)) css = (int)lds_u8(sc.css_b + (((b4 - 1) << 6) | ((rbase - 1) << 4) | ((abase - 1) << 2) | (b6 - 1)));
@@ -645,6 +667,21 @@ __device__ __forceinline__ void featurize_snp_tile(const V5Args& v, const Scratc
 
     CLK(pc, 1);
 
+    if (WX) {
+        float x[kMaxFeatures];
+#pragma unroll
+        for (int f = 0; f < kMaxFeatures; ++f) x[f] = 0.f;
+        x[0] = qual; x[1] = sor; x[2] = (float)dp; x[3] = (float)adr; x[4] = (float)ada; x[5] = vaf; x[6] = (float)gq;
+        x[11] = (float)lm; x[12] = (float)rm;
+        x[13] = gc_len > 0 ? (float)((double)(gc_len - n_at) / (double)gc_len) : 0.0f;
+        x[14] = (float)css;
+        x[15] = jo.inside_run ? 1.f : 0.f;
+        x[16] = jo.close_run ? 1.f : 0.f;
+#pragma unroll
+        for (int t = 0; t < UGVC_MAX_TRACKS; ++t) x[UGVC_N_BASE_FEATURES + t] = (jo.trk >> t) & 1u ? 1.f : 0.f;
+        store_feature_row(a, i, live, x, 0);
+        return;
+    }
     // ---- codes -> the wave's code planes (the staged slices are dead: LDS executes a wave's accesses in order)
     __builtin_amdgcn_wave_barrier();
     const int hslot = ((lane & 31) << 1) | (lane >> 5);
@@ -713,7 +750,7 @@ __device__ __forceinline__ IndelCols load_indel_cols(const FilterArgs& a, uint32
     return k;
 }
 
-template <int NTRK>
+template <int NTRK, bool WX>
 __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scratch& sc, uint32_t rshard, int lane, uint32_t i, bool live,
                                                      const IndelCols& k, Brk<1 + NTRK>& bk, IndelPre<1 + NTRK>& pre, PhaseClk& pc) {
     constexpr int NT = 1 + NTRK;
@@ -817,8 +854,8 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
     }
     const bool is_h = hmer_len > 0;
     const int group = is_h ? 1 : 2;
-    const bool pg_ok = group == 1 ? v.pg[1].ok != 0 : v.pg[2].ok != 0;
-    if (live && !pg_ok) {                                      // no model for this variant type: score 0, PASS
+    const bool pg_ok = !WX && (group == 1 ? v.pg[1].ok != 0 : v.pg[2].ok != 0);
+    if (live && !pg_ok && !WX) {                               // no model for this variant type: score 0, PASS
         a.score[i] = 0.f;
         a.filter[i] = UGVC_FILTER_PASS;
     }
@@ -1005,8 +1042,25 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
     uint8_t flags = (uint8_t)(jo.trk << UGVC_FLAG_TRACK0_SHIFT);
     if (jo.cohort) flags |= UGVC_FLAG_COHORT_FP;
     if (a.mark_hpol && (jo.inside_run || jo.close_run)) flags |= UGVC_FLAG_HPOL_RUN;
-    if (live) stg32(a.flags, i, flags);
+    if (live && !WX) stg32(a.flags, i, flags);
     CLK(pc, 2);
+    if (WX) {
+        float x[kMaxFeatures];
+#pragma unroll
+        for (int f = 0; f < kMaxFeatures; ++f) x[f] = 0.f;
+        x[0] = qual; x[1] = sor; x[2] = (float)dp; x[3] = (float)adr; x[4] = (float)ada;
+        x[5] = dp > 0 ? __fdiv_rn((float)ada, (float)dp) : 0.0f;
+        x[6] = (float)gq; x[7] = (float)classify; x[8] = (float)indel_length; x[9] = (float)hmer_len; x[10] = (float)hmer_nuc;
+        x[11] = (float)lm; x[12] = (float)rm;
+        x[13] = gc_len > 0 ? (float)((double)gc_cnt / (double)gc_len) : 0.0f;
+        x[14] = 3.f;                                               // cycle skip: NA for indels
+        x[15] = jo.inside_run ? 1.f : 0.f;
+        x[16] = jo.close_run ? 1.f : 0.f;
+#pragma unroll
+        for (int t = 0; t < UGVC_MAX_TRACKS; ++t) x[UGVC_N_BASE_FEATURES + t] = (jo.trk >> t) & 1u ? 1.f : 0.f;
+        store_feature_row(a, i, live, x, group);
+        return;
+    }
     // ---- codes of the lane's own group
     const float vaf = dp > 0 ? __fdiv_rn((float)ada, (float)dp) : 0.0f;
     uint32_t cd[4] = {0, 0, 0, 0};
@@ -1107,7 +1161,7 @@ struct Lds5 {
     uint32_t hi_b, last_b, p1_b, eyt_b, thr_b, gcr_b, css_b, gtab_b, scratch_b;
 };
 
-__device__ __forceinline__ Lds5 lds5_fill(unsigned char* smem, const V5Args& v, bool with_forest, int tid, int nthreads) {
+__device__ __forceinline__ Lds5 lds5_fill(unsigned char* smem, const V5Args& v, bool with_forest, int tid, int nthreads, bool model_tables = true) {
     const PackedGroupView& pg = v.pg[0];
     Lds5 L;
     size_t off = 0;
@@ -1142,7 +1196,8 @@ __device__ __forceinline__ Lds5 lds5_fill(unsigned char* smem, const V5Args& v, 
     L.thr_b = lds_addr(thr_l);
     off += ((size_t)(n_thr + (n_thr >> 5) + 1) * 4 + 15) & ~(size_t)15;
     uint16_t* gcr = reinterpret_cast<uint16_t*>(smem + off);
-    for (int q = tid; q < kGcRankBytes / 4; q += nthreads) reinterpret_cast<uint32_t*>(gcr)[q] = reinterpret_cast<const uint32_t*>(v.gcr)[q];   // (built on the host: model_pack.hip)
+    if (model_tables)
+        for (int q = tid; q < kGcRankBytes / 4; q += nthreads) reinterpret_cast<uint32_t*>(gcr)[q] = reinterpret_cast<const uint32_t*>(v.gcr)[q];   // (built on the host: model_pack.hip)
     L.gcr_b = lds_addr(gcr);
     off += kGcRankBytes;
     uint8_t* css = smem + off;
@@ -1153,7 +1208,7 @@ __device__ __forceinline__ Lds5 lds5_fill(unsigned char* smem, const V5Args& v, 
     // features' threshold slices in the staged table - read per lane by its group instead of scalar loads + selects
     unsigned char* gtab = smem + off;
     if (tid < 32) reinterpret_cast<uint16_t*>(gtab)[tid] = (uint16_t)v.cap5[1 + (tid >> 4)][tid & 15];
-    if (tid >= 64 && tid < 70) {
+    if (model_tables && tid >= 64 && tid < 70) {
         const int q = tid - 64, g = 1 + q / 3, sfeat = q % 3;
         const int fj = sfeat == 0 ? 0 : (sfeat == 1 ? 1 : 5);
         const uint2 d = v.desc3[g * kMaxFeatures + fj];
@@ -1187,7 +1242,7 @@ static size_t lds5_bytes(const V5Args& v, int n_waves) {
 // alt_len: the SNP forest) and indels - in callset order.  A tile is 64 consecutive entries of a list: pure in
 // class (every lane of a wave walks the SAME forest), ascending in position.  Waves then take CONSECUTIVE tiles:
 // the first `n_sw` waves share the SNP tiles, the others the indel tiles, in proportion to the tile counts.
-template <int NTRK, int NTW>
+template <int NTRK, int NTW, bool WX = false>
 __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned wcnt[2][kK2Threads / 64];
@@ -1203,7 +1258,7 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
     if (r0 >= a.n) return;                                       // (uniform: before the first barrier)
     const int64_t r1 = min(r0 + (int64_t)v.rows_wg, a.n);
     const PackedGroupView& pg0 = v.pg[0];
-    const bool has0 = pg0.ok != 0;
+    const bool has0 = !WX && pg0.ok != 0;
     // the thresholds of every group: SNP tiles rank against group 0's slices (the head of the table), indel
     // tiles against their own group's
     // ---- classes of this wave's rows (eight groups of 64 in flight).  The first eight groups are requested BEFORE the
@@ -1219,7 +1274,7 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
         rl0[u] = al0[u] = -1;
         if (r < w1) { rl0[u] = a.ref_len[r]; al0[u] = a.alt_len[r]; }
     }
-    const Lds5 L = lds5_fill(smem, v, has0, tid, blockDim.x);
+    const Lds5 L = lds5_fill(smem, v, has0, tid, blockDim.x, !WX);
     unsigned cs = 0, ci = 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -1336,7 +1391,7 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
             if (t + 1 < t1) cols_n = load_indel_cols(vt.f, i_n);
             uint32_t id_n2 = ~0u;
             if (t + 2 < t1) id_n2 = li[(t + 2) * 64 + lane];
-            featurize_indel_tile<NTRK>(vt, sc, (uint32_t)(blockIdx.x * 7 + t), lane, i, live, cols, bk, pre, pc);
+            featurize_indel_tile<NTRK, WX>(vt, sc, (uint32_t)(blockIdx.x * 7 + t), lane, i, live, cols, bk, pre, pc);
             if (t + 1 < t1 && joins_on && bk.c >= 0) issue_indel_slices<NTRK>(vt, bk, lane, pre);
             if (t + 2 < t1) {
                 live_n2 = id_n2 != ~0u;
@@ -1396,7 +1451,7 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
         bool live_n = false;
         if (prio) __builtin_amdgcn_s_setprio(2);
         if (more) id_n = ls[(t + 1) * 64 + lane];                // consumed after the joins
-        featurize_snp_tile<NTRK>(vt, sc, lane, i, live, has0, cols, bk, pre, pc);
+        featurize_snp_tile<NTRK, WX>(vt, sc, lane, i, live, has0, cols, bk, pre, pc);
         SnpCols cols_n = cols;
         if (more) {
             live_n = id_n != ~0u;
@@ -1415,7 +1470,7 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
                 stg32(at.score, i, score);
                 stg32(at.filter, i, filt);
             }
-        } else if (live) {                                     // no model for substitutions: score 0, PASS
+        } else if (live && !WX) {                              // no model for substitutions: score 0, PASS
             stg32(at.score, i, 0.f);
             stg32(at.filter, i, (uint8_t)UGVC_FILTER_PASS);
         }
@@ -1606,6 +1661,39 @@ static K5 fused5_for(int n_tracks, bool narrow = false) {
         case 4: return fused5_kernel<4, 16>;
         default: return fused5_kernel<5, 16>;
     }
+}
+
+static K5 fused5_wx_for(int n_tracks) {
+    switch (n_tracks) {
+        case 0: return fused5_kernel<0, 16, true>;
+        case 1: return fused5_kernel<1, 16, true>;
+        case 2: return fused5_kernel<2, 16, true>;
+        case 3: return fused5_kernel<3, 16, true>;
+        case 4: return fused5_kernel<4, 16, true>;
+        default: return fused5_kernel<5, 16, true>;
+    }
+}
+
+// The N x F feature matrix (a.X, a.group) from the fused kernel's featurize waves; no model needed.
+int launch_feature_matrix_v5(ugvc_ctx* ctx, const FilterArgs& a) {
+    if (a.n == 0) return 0;
+    V5Args v;
+    if (v5_fill_args(ctx, v, a)) return -1;
+    static bool attr_set[64] = {};
+    if (!attr_set[ctx->device & 63]) {
+        for (int t = 0; t <= UGVC_MAX_TRACKS; ++t)
+            UGVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused5_wx_for(t)), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+        attr_set[ctx->device & 63] = true;
+    }
+    for (int g = 0; g < UGVC_N_GROUPS; ++g) v.pg[g].ok = 0;      // (nothing is ranked or walked: the LDS holds scratch only)
+    v.run_forest = 0;
+    v.n_waves = 16;
+    v.n_indel_waves = 4;
+    if (lds5_bytes(v, v.n_waves) > 158 * 1024) return fail("internal: feature-matrix scratch does not fit LDS");
+    const unsigned n_wg = (unsigned)((a.n + v.rows_wg - 1) / v.rows_wg);
+    hipLaunchKernelGGL(fused5_wx_for(a.n_tracks), dim3(n_wg), dim3(v.n_waves * 64), lds5_bytes(v, v.n_waves), ctx->stream, v);
+    UGVC_HIP(hipGetLastError());
+    return 0;
 }
 
 int launch_filter_v5(ugvc_ctx* ctx, const FilterArgs& a) {

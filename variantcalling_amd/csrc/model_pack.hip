@@ -736,7 +736,7 @@ int v5_fill_args(ugvc_ctx* ctx, V5Args& v, const FilterArgs& a) {
         for (int t = 0; t < n_int; ++t) order.push_back(t);
         std::sort(order.begin(), order.end(), [&](int x, int y) { return v.na[x] > v.na[y]; });
         for (int t : order) {
-            const double per_tile = (double)v.na[t] / (double)std::max<int64_t>(n, 1) * 96.0;
+            const double per_tile = (double)v.na[t] / (double)std::max<int64_t>(ctx->density_n ? ctx->density_n : n, 1) * 96.0;
             if (per_tile > 40.0 && budget >= 128) { v.jcap[t] = 128; budget -= 128; }
         }
         int used = 0;
@@ -815,6 +815,22 @@ bool v5_available(ugvc_ctx* ctx) {
     size_t forest = 0;
     if (g0.set) forest = ((size_t)g0.T << g0.D) / 2 * 12 + (size_t)g0.n_pairs * 8 + 64;
     if (forest + (size_t)(s->thr_lds_len - s->thr0_len) * 33 / 8 + (size_t)s->eyt_len * 4 + 2048 + 6 * 3072 + 2 * 3328 > 158 * 1024) return false;
+    return true;
+}
+
+// the feature matrix on the fused kernel's featurize waves (kernels_v5.hip, WX): needs what those tiles assume of the
+// side tables (sorted, disjoint runs; 32-bit offsets) - no model at all
+bool fm5_available(ugvc_ctx* ctx) {
+    if (ctx->kernel_variant & 256) return false;              // (bit 8 forces the universal kernel everywhere)
+    if (ctx->has_runs && !ctx->runs_fast) return false;
+    for (int t = 0; t < ctx->n_tracks; ++t)
+        if (!ctx->trk_fast[t]) return false;
+    if (ctx->n >= ((int64_t)1 << 30) || ctx->n_bl >= ((int64_t)1 << 29)) return false;
+    if (ctx->has_runs && ctx->runs_n >= ((int64_t)1 << 30)) return false;
+    for (int t = 0; t < ctx->n_tracks; ++t)
+        if (ctx->trk_n[t] >= ((int64_t)1 << 30)) return false;
+    const size_t F = (size_t)(UGVC_N_BASE_FEATURES + ctx->n_tracks);
+    if ((size_t)ctx->n * F * 4 >= ((size_t)1 << 32)) return false;      // (row offsets are formed in 64 bits, but keep X below the 32-bit list indices' reach)
     return true;
 }
 

@@ -143,6 +143,8 @@ struct ugvc_ctx {
     int kernel_variant = 0;
     std::vector<float> step_ms;     // per-step kernel times of the last ugvc_timed_steps
     void* v2 = nullptr;             // ugvc::V2State (model_pack.hip)
+    void* pipe = nullptr;           // ugvc::PipeState (pipeline.hip): host pool, pinned staging, copy streams
+    int64_t density_n = 0;          // when a pass covers a row range of a larger callset: that callset's size (table-density estimates)
 };
 
 namespace ugvc {

@@ -141,6 +141,8 @@ int build_css_lut(ugvc_ctx* ctx);
 bool v2_available(ugvc_ctx* ctx);
 int launch_filter_v3(ugvc_ctx* ctx, const FilterArgs& a);
 int launch_filter_v5(ugvc_ctx* ctx, const FilterArgs& a);
+int launch_feature_matrix_v5(ugvc_ctx* ctx, const FilterArgs& a);
+bool fm5_available(ugvc_ctx* ctx);
 bool v5_available(ugvc_ctx* ctx);
 int launch_forest3(ugvc_ctx* ctx, const V2Args& v, const FilterArgs& a);
 int v2_fill_args(ugvc_ctx* ctx, V2Args& v, int64_t n, int n_tiles = 0);

@@ -71,6 +71,7 @@ class Group:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(self.world)))     # ranks on this host (host threads are shared out by it)
         self._peers: list = []          # rank 0: sockets of ranks 1..world-1 (index r - 1)
         self._up: socket.socket | None = None
         self._listener: socket.socket | None = None

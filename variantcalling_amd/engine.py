@@ -87,8 +87,10 @@ ABI = {
     "ugvc_sec_apply": (C.c_int, [_ctx, C.c_double, C.c_int, C.c_int, _f64p, _u8p]),
     "ugvc_bridging_snvs": (C.c_int, [_ctx, C.POINTER(CVariants), _u8p, _i32p, _i32p, _i32p,
                                      C.POINTER(CBridgingParams), _u8p, _u8p]),
+    "ugvc_timed_feature_matrix": (C.c_int, [_ctx, C.c_int, _f32p]),
     "ugvc_comm_unique_id": (C.c_int, [_u8p]),
     "ugvc_comm_init": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int]),
+    "ugvc_comm_info": (C.c_int, [_ctx, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ugvc_comm_destroy": (C.c_int, [_ctx]),
     "ugvc_allgather_resident": (C.c_int, [_ctx, C.c_int64]),
     "ugvc_gather_fence": (C.c_int, [_ctx]),
@@ -342,6 +344,12 @@ class Engine:
         self._check(self.lib.ugvc_feature_matrix(self._h, _p(X, _f32p), _p(g, _u8p)))
         return X, g
 
+    def timed_feature_matrix(self, iters: int) -> float:
+        """ms per build of the resident N x F feature matrix (no download)."""
+        ms = C.c_float()
+        self._check(self.lib.ugvc_timed_feature_matrix(self._h, int(iters), C.byref(ms)))
+        return ms.value / iters
+
     def forest_gemm(self, group: int, rows: np.ndarray | None = None, use_mfma: bool = True, iters: int = 1):
         """(f32 margins, ms per launch) of group `group`'s additive ensemble on rows of the resident feature
         matrix: leaf-matrix GEMM on MFMA (use_mfma) or row traversal."""
@@ -455,6 +463,12 @@ class Engine:
         buf = np.frombuffer(uid, dtype=np.uint8).copy()
         self._check(self.lib.ugvc_comm_init(self._h, _p(buf, _u8p), rank, world))
         self.rank, self.world = rank, world
+
+    def comm_info(self) -> dict:
+        """What RCCL reports about this context's communicator: {"nranks", "rank", "device"}."""
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        self._check(self.lib.ugvc_comm_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(nranks=a.value, rank=b.value, device=c.value)
 
     def allgather_resident(self, shard_cap: int):
         self._check(self.lib.ugvc_allgather_resident(self._h, shard_cap))

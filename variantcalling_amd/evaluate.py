@@ -82,9 +82,10 @@ def precision_recall_curve(gtr, predictions, fn_mask, pos_label=1, min_class_cou
     return precisions[keep], recalls[keep], f1[keep], thr[keep]
 
 
-def calc_performance(score, passed, tp, fp, fn, missing_candidate=None, curve: bool = True):
+def calc_performance(score, passed, tp, fp, fn, missing_candidate=None, curve: bool = True, pr_curve=None):
     """report_utils.py:415-505 on arrays.  score: tree_score (NaN allowed); passed: FILTER == PASS;
     tp/fp/fn: boolean classification of every row; missing_candidate: FN rows that had no call at all.
+    `pr_curve`: `Engine.pr_curve` - the cumulative curve (:494-504) then runs on the GPU, else on the host.
     Returns (metrics dict, (sorted score, recall, precision, f1) or None)."""
     score = np.asarray(score, dtype=np.float64)
     passed = np.asarray(passed, dtype=bool)
@@ -111,6 +112,12 @@ def calc_performance(score, passed, tp, fp, fn, missing_candidate=None, curve: b
            "miss_candidate": n_miss}
     if not curve or score.size < 10:
         return res, None
+    if pr_curve is not None:
+        # the sort + running counts + per-position formulas on the GPU (Engine.pr_curve -> ugvc_pr_curve: stable radix sort
+        # of an order-preserving key, one scan, f64 finish): bit-equal to the host statement below (tests/test_gpu_eval.py)
+        cls = np.where(tp, 1, np.where(fp, 2, 0)).astype(np.uint8)
+        ss, rec, prec, f1 = pr_curve(s, cls, i_tp, i_fp, i_fn)[:4]
+        return res, (ss, rec, prec, f1)
     # pandas sort_values' default quicksort leaves the order inside a run of equal scores unspecified; BUILDER-DEFINED:
     # stable (input order), which is also what the GPU curve (Engine.pr_curve: stable radix sort) produces
     order = np.argsort(s, kind="stable")

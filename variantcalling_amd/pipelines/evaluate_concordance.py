@@ -8,7 +8,10 @@ PREFIX.thresholds.csv (:103,110).  The two table builders (`calc_accuracy_metric
 live in the absent submodule; here they are `evaluate.accuracy_rows` - pinned on the reference's own expected table,
 test/resources/system/test_evaluate_concordance/expected.out.stats.csv - and the FN-aware
 `evaluate.precision_recall_curve` (the in-tree ugvc/utils/stats_utils.py:141-210) per variant category.
-Host-side consumer of the hot path's two output columns: no GPU needed."""
+Key `performance_curve` (BUILDER-DEFINED) holds, per category, the cumulative curve of the in-tree
+`ReportUtils.__calc_performance` (ugvc/reports/report_utils.py:494-504); with `--device N` its sort + scan + finish run on
+the GPU (`ugvc_pr_curve`), without it on the host - same bytes either way.  Host-side consumer of the hot path's two
+output columns: no GPU needed."""
 from __future__ import annotations
 
 import argparse
@@ -35,6 +38,8 @@ def parse_args(argv: list[str]):
     ap.add_argument("--output_bed", help="output bed files of fp/fn/tp per variant-type", action="store_true", default=False)
     ap.add_argument("--use_for_group_testing", help="Column in the h5 to use for grouping (or generate default groupings)", type=str)
     ap.add_argument("--verbosity", help="Verbosity: ERROR, WARNING, INFO, DEBUG", required=False, default="INFO")
+    # BUILDER-DEFINED (not a reference flag): the cumulative performance curves on an MI355X; same files either way
+    ap.add_argument("--device", help="GPU index (MI355X) for the cumulative performance curves (default: host numpy)", type=int)
     return ap.parse_args(argv)
 
 
@@ -96,6 +101,27 @@ def calc_recall_precision_curve(df: h5.Frame, classify_column: str, ignored_filt
     return rows
 
 
+def calc_performance_curves(df: h5.Frame, classify_column: str, ignored_filters, group_column=None, pr_curve=None) -> list:
+    """One row per group: the cumulative curve of `ReportUtils.__calc_performance` (/root/reference/ugvc/reports/
+    report_utils.py:415-505: calls sorted by normalised score, running tp / fp removed from the callset, recall /
+    precision / f1 per position :494-504) - what the reports draw from this tool's input.  Truth variants without a call
+    (classify == "fn") are the missing candidates (:443-446).  `pr_curve` = `Engine.pr_curve`: sort, scan and the f64
+    finish run on the GPU (ugvc_pr_curve), bit-equal to the host statement.  Key `performance_curve`: BUILDER-DEFINED."""
+    cls = np.asarray(df[classify_column], dtype=object)
+    score = np.asarray(df["tree_score"], dtype=np.float64)
+    ok = passing(df["filter"], ignored_filters) if "filter" in df else np.ones(df.n_rows, bool)
+    rows = []
+    for name, m in group_masks(df, group_column).items():
+        tp, fp, fn = (cls == "tp") & m, (cls == "fp") & m, (cls == "fn") & m
+        sel = tp | fp | fn
+        res, curve = evaluate.calc_performance(score[sel], ok[sel], tp[sel], fp[sel], fn[sel], missing_candidate=fn[sel],
+                                               pr_curve=pr_curve)
+        empty = np.zeros(0)
+        s, r, p, f = curve if curve is not None else (empty, empty, empty, empty)
+        rows.append(dict(group=name, n_pos=res["# pos"], max_recall=res["max_recall"], score=s, recall=r, precision=p, f1=f))
+    return rows
+
+
 def _frame(rows) -> h5.Frame:
     fr = h5.Frame()
     for k in rows[0]:
@@ -126,7 +152,14 @@ def run(argv: list[str]):
 
     acc = calc_accuracy_metrics(df, classify_column, ignored, args.use_for_group_testing)
     curve = calc_recall_precision_curve(df, classify_column, ignored, args.use_for_group_testing)
-    h5.write_hdf(f"{args.output_prefix}.h5", {"optimal_recall_precision": _frame(acc), "recall_precision_curve": _frame(curve)})
+    if args.device is not None:
+        from ..engine import Engine            # fails loudly if the library or the GPU is missing
+        with Engine(args.device) as eng:
+            perf = calc_performance_curves(df, classify_column, ignored, args.use_for_group_testing, pr_curve=eng.pr_curve)
+    else:
+        perf = calc_performance_curves(df, classify_column, ignored, args.use_for_group_testing)
+    h5.write_hdf(f"{args.output_prefix}.h5", {"optimal_recall_precision": _frame(acc), "recall_precision_curve": _frame(curve),
+                                              "performance_curve": _frame(perf)})
     with open(f"{args.output_prefix}.stats.csv", "w", newline="") as fh:
         w = csv.DictWriter(fh, fieldnames=list(acc[0]), delimiter=";", lineterminator="\n")
         w.writeheader()

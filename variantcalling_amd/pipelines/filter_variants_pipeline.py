@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import argparse
 import logging
+import os
 import sys
 
 from .. import model_io
@@ -35,7 +36,7 @@ def get_parser() -> argparse.ArgumentParser:
     ap.add_argument("--flow_order", help="Sequencing flow order (4 cycle)", type=str, default="TGCA")
     ap.add_argument("--annotate_intervals", help="interval files for annotation (multiple possible)", type=str,
                     action="append", default=[])
-    ap.add_argument("--device", help="GPU index (MI355X)", type=int, default=0)
+    ap.add_argument("--device", help="GPU index (MI355X); under a multi-process launcher every rank takes its LOCAL_RANK", type=int, default=0)
     return ap
 
 
@@ -54,6 +55,16 @@ def run(argv: list[str]):
         stages[name] = t1 - t0
         t0 = t1
 
+    # One process per GPU when launched under `python -m torch.distributed.run` / with RANK, WORLD_SIZE, MASTER_* in the
+    # environment (the reference parallelises the neighbouring tools per contig, docs/run_comparison_pipeline.md:81;
+    # here: equal-count slices of the sorted callset).  Every rank parses the inputs with its share of
+    # the host threads (rank 0 needs every record's text anyway to write the output), scores its slice against the part
+    # of the genome and of the side tables that slice can touch, and one RCCL all-gather of (score, filter, flags) puts
+    # the whole verdict on every rank; rank 0 writes.  No torch anywhere: the rendezvous is dist.Group (plain TCP).
+    from .. import dist, shard
+    grp = dist.Group()
+    device = args.device if grp.world == 1 else grp.local_rank
+    n_threads = 0 if grp.world == 1 else max(1, (os.cpu_count() or 1) // max(grp.local_world, 1))
     logger.info("reading side tables")
     ref, runs, tracks, bl = common.load_side_tables(args.reference_file, args.runs_file, args.annotate_intervals,
                                                     args.blacklist)
@@ -62,16 +73,39 @@ def run(argv: list[str]):
     common.check_model_tracks(forests, len(tracks), "filter_variants_pipeline")
     lap("side tables + model")
     logger.info("reading %s", args.input_file)
-    vcf = vcfio.read_vcf(args.input_file, ref.names, is_mutect=args.is_mutect)
+    vcf = vcfio.read_vcf(args.input_file, ref.names, is_mutect=args.is_mutect, n_threads=n_threads)
     lap("VCF -> columns (native codec)")
     hp_len, hp_dist = args.hpol_filter_length_dist
-    with Engine(args.device) as eng:
-        configure(eng, ref, runs, tracks, bl, forests, args.flow_order, hp_len, hp_dist, True)
-        lap("context + uploads (reference, tables, model)")
-        # one row per ALT allele (multi-allelic records, spanning deletions: io/multiallelic.py), one verdict per record
-        table, base_row = multiallelic.expand(vcf)
-        res = multiallelic.collapse(eng.filter_variants(table), base_row, vcf.table.n)
-        lap("upload variants + scoring pass + download")
+    # one row per ALT allele (multi-allelic records, spanning deletions: io/multiallelic.py), one verdict per record
+    table, base_row = multiallelic.expand(vcf)
+    with Engine(device) as eng:
+        if grp.world == 1:
+            configure(eng, ref, runs, tracks, bl, forests, args.flow_order, hp_len, hp_dist, True)
+            lap("context + uploads (reference, tables, model)")
+            res_rows = eng.filter_variants(table)
+            lap("upload variants + scoring pass + download")
+        else:
+            b = shard.shard_bounds(table.n, grp.world)
+            mine = table.slice(int(b[grp.rank]), int(b[grp.rank + 1]))
+            ref_r, runs_r, tracks_r, bl_r, mine_r = shard.slice_context(ref, runs, tracks, bl, mine, hpol_dist=hp_dist)
+            configure(eng, ref_r, runs_r, tracks_r, bl_r, forests, args.flow_order, hp_len, hp_dist, True)
+            uid = grp.broadcast_bytes(eng.comm_unique_id() if grp.rank == 0 else None, 0)
+            eng.comm_init(uid, grp.rank, grp.world)
+            info = eng.comm_info()
+            if info["nranks"] != grp.world or info["rank"] != grp.rank:
+                raise RuntimeError(f"RCCL communicator reports {info}, launcher says rank {grp.rank} of {grp.world}")
+            lap("context + uploads (reference slice, table slices, model) + RCCL communicator")
+            cap = shard.shard_cap(table.n, grp.world)
+            eng.upload_variants(mine_r)
+            eng.filter_resident()
+            eng.allgather_resident(cap)
+            res_rows = eng.gathered_download(cap, grp.world, [int(b[r + 1] - b[r]) for r in range(grp.world)])
+            lap(f"upload shard + scoring pass + RCCL all-gather x{info['nranks']} + download")
+        res = multiallelic.collapse(res_rows, base_row, vcf.table.n)
+    grp.barrier()
+    if grp.rank != 0:
+        grp.close()
+        return 0
     cg = common.cg_insertion_mask(vcf.table) if args.blacklist_cg_insertions else None
     logger.info("writing %s", args.output_file)
     vcfio.write_filtered_vcf(args.output_file, vcf, res, cg)
@@ -80,6 +114,7 @@ def run(argv: list[str]):
     logger.info("stage seconds: %s", ", ".join(f"{k} {v:.3f}" for k, v in stages.items()))
     n_pass = int(((res.filter == 0) & (res.flags & 3 == 0)).sum())
     logger.info("%d variants, %d PASS", vcf.table.n, n_pass)
+    grp.close()
     return 0
 
 
