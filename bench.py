@@ -55,6 +55,16 @@ def _cpu_chunk(bounds):
     return hi - lo
 
 
+def _cpu_chunk_vec(bounds):
+    """One worker of the strongest CPU formulation: the vectorised numpy oracle on rows [lo, hi)."""
+    from oracle import oracle as O
+    lo, hi = bounds
+    job = _CPU_JOB
+    cs = job["cs"]
+    O.filter_variants(job["vt"].slice(lo, hi), cs.ref, cs.runs, cs.tracks, cs.blacklist, job["forests"])
+    return hi - lo
+
+
 def cpu_baseline(cs, forests, sample_n):
     """Oracle restatement in the reference idiom (pandas per-row apply + tree scoring): one process on the first
     `sample_n` variants (the reference tool is single-process), then one process per host core over contig-ordered
@@ -79,7 +89,7 @@ def cpu_baseline(cs, forests, sample_n):
                vectorised_numpy_value=sub.n / t_vec, vectorised_numpy_seconds=round(t_vec, 2))
     cores = os.cpu_count() or 1
     workers = max(1, min(cores, 256))
-    n_multi = int(min(cs.variants.n, max(sample_n, sub.n / t_idiom * 12.0 * workers)))    # ~12 s of work per worker
+    n_multi = int(min(cs.variants.n, max(sample_n, sub.n / t_idiom * 6.0 * workers)))     # ~6 s of work per worker
     chunks = workers                   # one chunk per process: each pays the tool's per-run table preparation once
     edges = np.linspace(0, n_multi, chunks + 1).astype(np.int64)
     for c in np.unique(cs.variants.contig[:n_multi]):   # "open the FASTA" once, before the fork and outside the timed region
@@ -94,8 +104,18 @@ def cpu_baseline(cs, forests, sample_n):
         out["multi"] = dict(value=done / t_multi, unit="variants/s", cores=workers,
                             sample=f"first {done} variants in {chunks} position-ordered chunks, one forked process per host core "
                                    f"({workers}), same idiom code, {t_multi:.1f} s wall incl. process start")
+        # the strongest CPU formulation: the VECTORISED oracle over all host cores on the whole callset (the
+        # forked idiom run is slower than one core of this) - what "the same box's host cores" can do at best
+        edges = np.linspace(0, cs.variants.n, 4 * workers + 1).astype(np.int64)
+        t0 = time.perf_counter()
+        with ctx.Pool(workers) as pool:
+            done = sum(pool.map(_cpu_chunk_vec, [(int(edges[k]), int(edges[k + 1])) for k in range(4 * workers)], chunksize=1))
+        t_vm = time.perf_counter() - t0
+        out["vectorised_multi"] = dict(value=done / t_vm, unit="variants/s", cores=workers,
+                                       sample=f"all {done} variants in {4 * workers} chunks over {workers} forked processes, oracle/oracle.py "
+                                              f"(vectorised numpy), {t_vm:.1f} s wall incl. process start")
     except Exception as e:                # a box that cannot fork this much: report, do not fail the bench
-        out["multi"] = dict(value=None, error=repr(e)[:200])
+        out.setdefault("multi", dict(value=None, error=repr(e)[:200]))
     finally:
         _CPU_JOB.clear()
     return out
@@ -170,6 +190,16 @@ def run_filter(args):
         rccl = None
     t_setup = time.perf_counter() - t_setup
 
+    # ---- spin-up (untimed, part of the setup): the chip's clock and power state take ~40 dispatches to settle - the
+    # per-dispatch trace of a 200-step run (profiles/r03_jitter_hist.txt) shows the first fifth 3 % slower than the rest,
+    # lag-1 autocorrelation 0.74: a ramp, not noise.  A production stream scores callset after callset; the timed region
+    # below measures that state.  The ramp itself is reported (first / last 20 passes of the spin-up) in `spinup`.
+    ramp = None
+    if args.spinup > 0:
+        eng.timed_steps(args.spinup, cap, gather)
+        sp = np.asarray(eng.last_step_ms(args.spinup), np.float64)
+        k = min(20, sp.size)
+        ramp = dict(passes=int(args.spinup), first_ms=float(sp[:k].mean()), last_ms=float(sp[-k:].mean()))
     # ---- warm-up (untimed)
     if args.warmup > 0:
         eng.timed_steps(args.warmup, cap, gather)
@@ -238,8 +268,9 @@ def run_filter(args):
             ms_per_step=wall / args.steps * 1e3, higher_is_better=True, scaling=args.scaling,
             vs_baseline=None, dtype="u8/i32 featurize + f32 compare + f64 accumulate", data="synthetic",
             config=dict(workload=("C2 " if snv_only else "C3 ") + f"{n_total} variants "
-                        f"({'SNV-only' if snv_only else '82% SNV / 18% indel'}), 3.1 Gb 24-contig genome tiled from "
-                        "real hg38 chr1 blocks, runs + 3 annotation tracks (5.0M intervals), 1M-locus blacklist, "
+                        f"({'SNV-only' if snv_only else '82% SNV / 18% indel'}), {cs.ref.codes.size / 1e9:.1f} Gb 24-contig genome tiled from "
+                        f"real hg38 chr1 blocks, runs + 3 annotation tracks ({(cs.runs.starts.size + sum(t.starts.size for t in cs.tracks)) / 1e6:.1f}M "
+                        f"intervals), {cs.blacklist.size / 1e6:.1f}M-locus blacklist, "
                         "RF 40 trees depth 8 x 3 groups, F=20; fused featurize+lookup+score+FILTER, inputs resident in HBM",
                         variants_per_gpu=mine.n, model=MODEL, sharding=f"equal-count x{grp.world}"
                         + (", per-rank genome / side-table slices" if grp.world > 1 else ""),
@@ -250,7 +281,7 @@ def run_filter(args):
                           frac=achieved / HBM_PEAK_GBPS, traffic=traffic, traffic_measured_at_commit=traffic_commit,
                           kernel=PASS_KERNELS, kernel_ms=kern_ms, kernel_ms_p5=_pct(step_ms, 5), kernel_ms_p50=_pct(step_ms, 50),
                           kernel_ms_p95=_pct(step_ms, 95), alg_bytes_per_variant=alg, variants_per_launch=mine.n),
-            e2e_incl_pcie=e2e,
+            e2e_incl_pcie=e2e, spinup=ramp,
             parity=dict(oracle_slice_bit_exact=check, oracle_rows_checked=checked_rows, gather_consistent=ok_all),
             setup_s=round(t_setup, 1), cpu_baseline=cpu)
         print(json.dumps(out), flush=True)
@@ -397,6 +428,8 @@ def main():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--cpu-sample", type=int, default=100_000, help="variants timed on the single-process CPU baseline (0 = skip)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive measurement")
+    ap.add_argument("--spinup", type=int, default=150,
+                    help="untimed passes before the warm-up steps: brings the GPU to its sustained clock (reported in `spinup`; 0 = none)")
     ap.add_argument("--check-rows", type=int, default=5000,
                     help="rows at either end of the shard compared with the CPU oracle after the timed region (-1: every row)")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (debug)")

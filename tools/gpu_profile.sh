@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 TAG=${1:-r01}
 shift || true
-CMD="python bench.py --steps 20 --warmup 3 --cpu-sample 0 $*"
+CMD="python bench.py --steps 20 --warmup 5 --cpu-sample 0 --no-e2e $*"
 rm -rf gpurun_out/prof_$TAG
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG/trace -o trace -- $CMD > gpurun_out/prof_$TAG.bench.log 2>&1
 tail -2 gpurun_out/prof_$TAG.bench.log

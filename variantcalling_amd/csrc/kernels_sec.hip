@@ -159,6 +159,7 @@ __global__ __launch_bounds__(kSecBlock) void sec_apply_tiles_kernel(const uint16
                                                                     uint8_t* __restrict__ is_sec, uint8_t* __restrict__ flags, int tiles_per_wave) {
     __shared__ double lt[2 * (kSecLdsTab + 1)];
     __shared__ uint64_t stage_all[kSecBlock / 64][kSecStage];
+    __shared__ uint2 queue_all[kSecBlock / 64][128];
     for (int q = threadIdx.x; q <= kSecLdsTab; q += kSecBlock) {
         lt[q] = lg_tab[q];
         lt[kSecLdsTab + 1 + q] = lg_tab[kSecLgTab + 1 + q];
@@ -193,6 +194,48 @@ __global__ __launch_bounds__(kSecBlock) void sec_apply_tiles_kernel(const uint16
     auto fetch = [&](int64_t from, uint64_t& a0, uint64_t& a1) {
         a0 = from + lane < n_db ? keys[from + lane] : ~0ull;
         a1 = from + 64 + lane < n_db ? keys[from + 64 + lane] : ~0ull;
+    };
+    uint2* queue = queue_all[wave];
+    int qn = 0;                                                      // hits waiting in the wave's queue (< 64 between tiles)
+    // one hit: observed counts of call q.x against the expected counts of database row q.y
+    auto work = [&](uint2 q) {
+        const int64_t ci = (int64_t)q.x, l2 = (int64_t)q.y;
+        int a[kSecMaxK], e[kSecMaxK];
+        const int r0 = adr[ci] > 0 ? adr[ci] : 0, a0 = ada[ci] > 0 ? ada[ci] : 0;
+        a[0] = r0;
+        a[1] = a0;
+        if (k > 2) { const int o = dp[ci] - r0 - a0; a[2] = o > 0 ? o : 0; }
+        for (int c = 3; c < k; ++c) a[c] = 0;
+        long long s = 0, na = 0;
+        for (int c = 0; c < k; ++c) { e[c] = expected[l2 * k + c]; s += e[c]; na += a[c]; }
+        if (scale && s > 0) {
+            const double f = (double)na / (double)s;              // stats_utils.py:24-27: np.round(table * (n / sum))
+            for (int c = 0; c < k; ++c) e[c] = (int)rint((double)e[c] * f);
+        }
+        // sec_log_pmf2_tab with the LDS tables
+        long long tot_e = 0, tot_x = 0;
+        int nn = 0;
+        for (int c = 0; c < k; ++c) { tot_e += (long long)e[c] + 1; tot_x += (long long)a[c] + 1; nn += a[c]; }
+        const double lte = sec_li(lt, lg_tab, tot_e), ltx = sec_li(lt, lg_tab, tot_x);
+        double g = sec_lf(lt, lg_tab, nn), se = 0.0, sx = 0.0;
+        for (int c = 0; c < k; ++c) {
+            if (a[c] > 0) {
+                se += (double)a[c] * (sec_li(lt, lg_tab, (long long)e[c] + 1) - lte);
+                sx += (double)a[c] * (sec_li(lt, lg_tab, (long long)a[c] + 1) - ltx);
+            }
+            g -= sec_lf(lt, lg_tab, a[c]);
+        }
+        const double lp_e = g + se, lp_x = g + sx, d = lp_e - lp_x;
+        const bool exact = WANT_RATIO || !(min_ratio > 0.0) || fabs(d - log_min) <= 1e-9 * fmax(1.0, fabs(log_min)) || lp_e < -700.0 || lp_x < -700.0;
+        double r = 0.0;
+        uint8_t hit;
+        if (exact) {
+            r = exp(lp_e) / exp(lp_x);
+            hit = r >= min_ratio ? 1 : 0;
+        } else hit = d >= log_min ? 1 : 0;
+        if (WANT_RATIO && ratio) ratio[ci] = r;
+        if (is_sec) is_sec[ci] = hit;
+        if (flags && hit) flags[ci] |= UGVC_FLAG_SEC;
     };
     uint64_t s0, s1;
     fetch(Lb, s0, s1);
@@ -229,55 +272,29 @@ __global__ __launch_bounds__(kSecBlock) void sec_apply_tiles_kernel(const uint16
         __builtin_amdgcn_wave_barrier();
         Lb = __shfl(l2, last);
         if (t + 1 < t1) fetch(Lb, s0, s1);                          // in flight during this tile's arithmetic
-        double r = __longlong_as_double(0x7ff8000000000000ll);
-        uint8_t hit = 0;
+        // calls off the database: their outputs now; hits go to the wave's queue and are worked on 64 at a time - ~40 % of
+        // the lanes hit in every tile, so the f64 arithmetic below used to run for every wave with 60 % of its lanes idle
         const bool go = found && valid;
-        double lp_e = 0.0, lp_x = 0.0;
-        if (go) {
-            int a[kSecMaxK], e[kSecMaxK];
-            const int r0 = adr[i] > 0 ? adr[i] : 0, a0 = ada[i] > 0 ? ada[i] : 0;
-            a[0] = r0;
-            a[1] = a0;
-            if (k > 2) { const int o = dp[i] - r0 - a0; a[2] = o > 0 ? o : 0; }
-            for (int c = 3; c < k; ++c) a[c] = 0;
-            long long s = 0, na = 0;
-            for (int c = 0; c < k; ++c) { e[c] = expected[l2 * k + c]; s += e[c]; na += a[c]; }
-            if (scale && s > 0) {
-                const double f = (double)na / (double)s;              // stats_utils.py:24-27: np.round(table * (n / sum))
-                for (int c = 0; c < k; ++c) e[c] = (int)rint((double)e[c] * f);
-            }
-            // sec_log_pmf2_tab with the LDS tables
-            long long tot_e = 0, tot_x = 0;
-            int nn = 0;
-            for (int c = 0; c < k; ++c) { tot_e += (long long)e[c] + 1; tot_x += (long long)a[c] + 1; nn += a[c]; }
-            const double lte = sec_li(lt, lg_tab, tot_e), ltx = sec_li(lt, lg_tab, tot_x);
-            double g = sec_lf(lt, lg_tab, nn), se = 0.0, sx = 0.0;
-            for (int c = 0; c < k; ++c) {
-                if (a[c] > 0) {
-                    se += (double)a[c] * (sec_li(lt, lg_tab, (long long)e[c] + 1) - lte);
-                    sx += (double)a[c] * (sec_li(lt, lg_tab, (long long)a[c] + 1) - ltx);
-                }
-                g -= sec_lf(lt, lg_tab, a[c]);
-            }
-            lp_e = g + se;
-            lp_x = g + sx;
+        if (valid && !go) {
+            if (WANT_RATIO && ratio) ratio[i] = __longlong_as_double(0x7ff8000000000000ll);
+            if (is_sec) is_sec[i] = 0;
         }
-        const double d = lp_e - lp_x;
-        const bool exact = go && (WANT_RATIO || !(min_ratio > 0.0) || fabs(d - log_min) <= 1e-9 * fmax(1.0, fabs(log_min)) ||
-                                  lp_e < -700.0 || lp_x < -700.0);
-        if (__builtin_amdgcn_ballot_w64(exact) != 0) {
-            if (exact) {
-                r = exp(lp_e) / exp(lp_x);
-                hit = r >= min_ratio ? 1 : 0;
-            }
-        }
-        if (go && !exact) hit = d >= log_min ? 1 : 0;
-        if (valid) {
-            if (WANT_RATIO && ratio) ratio[i] = r;
-            if (is_sec) is_sec[i] = hit;
-            if (flags && hit) flags[i] |= UGVC_FLAG_SEC;
+        const unsigned long long gm = __builtin_amdgcn_ballot_w64(go);
+        if (go) queue[qn + (int)__popcll(gm & ((1ull << lane) - 1))] = make_uint2((uint32_t)i, (uint32_t)l2);
+        qn += (int)__popcll(gm);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (qn >= 64) {
+            work(queue[lane]);
+            const uint2 rest = queue[64 + lane];
+            __builtin_amdgcn_wave_barrier();
+            queue[lane] = rest;
+            qn -= 64;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     }
+    if (qn > 0 && lane < qn) work(queue[lane]);
 }
 
 __global__ void sec_iota_kernel(uint32_t* idx, int64_t n) {
@@ -407,7 +424,8 @@ int ugvc_sec_apply(ugvc_ctx* ctx, double min_ratio, int scale_expected, int mark
     int rc = 0;
     do {
         if ((ratio && (rc = ensure(d_r, (size_t)n * 8))) || (is_sec && (rc = ensure(d_s, (size_t)n)))) break;
-        static const bool simple = getenv("UGVC_SEC_SIMPLE") != nullptr;
+        static const bool simple_env = getenv("UGVC_SEC_SIMPLE") != nullptr;
+        const bool simple = simple_env || n >= ((int64_t)1 << 32) || ctx->n_sec >= ((int64_t)1 << 32);   // (the hit queue holds 32-bit row numbers)
         if (simple) {
             hipLaunchKernelGGL(sec_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->v_contig.as<uint16_t>(),
                                ctx->v_pos.as<int32_t>(), ctx->v_dp.as<int32_t>(), ctx->v_adr.as<int32_t>(), ctx->v_ada.as<int32_t>(), n,

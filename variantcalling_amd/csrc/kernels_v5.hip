@@ -1349,7 +1349,9 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
     // it works on the current one.
     const int n_big = v.n_indel_waves, n_small = n_waves - n_big;
     sc.base = L.scratch_b + (uint32_t)(wave < n_small ? wave * v.scratch_bytes : n_small * v.scratch_bytes + (wave - n_small) * v.scratch_indel);
-    int n_iw = nit > 0 ? (int)((n_waves * nit + (nst + nit) - 1) / (nst + nit)) : 0;
+    // (an indel tile's cost relative to an SNP tile's, in 1/256: V5Args::indel_w - 1 for the scoring pass, ~3 when nothing is walked)
+    const int64_t wi = nit * v.indel_w, ws = nst * 256;
+    int n_iw = nit > 0 ? (int)((n_waves * wi + (ws + wi) - 1) / (ws + wi)) : 0;
     n_iw = n_iw < n_big ? n_iw : n_big;
     if (nst == 0) n_iw = n_big;
     const int n_sw = n_waves - n_iw;
@@ -1688,7 +1690,9 @@ int launch_feature_matrix_v5(ugvc_ctx* ctx, const FilterArgs& a) {
     for (int g = 0; g < UGVC_N_GROUPS; ++g) v.pg[g].ok = 0;      // (nothing is ranked or walked: the LDS holds scratch only)
     v.run_forest = 0;
     v.n_waves = 16;
-    v.n_indel_waves = 4;
+    v.n_indel_waves = 8;
+    v.indel_w = 768;                                              // without the walk an indel tile costs about three SNP tiles
+    if (const char* e = getenv("UGVC_FM_INDEL_W")) v.indel_w = std::max(1, (int)(atof(e) * 256.0));      // (profiling)
     if (lds5_bytes(v, v.n_waves) > 158 * 1024) return fail("internal: feature-matrix scratch does not fit LDS");
     const unsigned n_wg = (unsigned)((a.n + v.rows_wg - 1) / v.rows_wg);
     hipLaunchKernelGGL(fused5_wx_for(a.n_tracks), dim3(n_wg), dim3(v.n_waves * 64), lds5_bytes(v, v.n_waves), ctx->stream, v);

@@ -755,6 +755,7 @@ int v5_fill_args(ugvc_ctx* ctx, V5Args& v, const FilterArgs& a) {
             if ((double)v.na[t] / tiles > 100.0) v.iwide |= 1u << t;
         if (const char* e = getenv("UGVC_IWIDE")) v.iwide = (uint32_t)atoi(e);        // (profiling)
     }
+    v.indel_w = 256;
     v.n_indel_waves = 0;
     v.n_waves = v5_fused_waves(v);
     if (v.n_waves == 0) return fail("internal: the SNP forest does not fit the fused kernel's LDS");

@@ -5,8 +5,10 @@
 // download-everything from PAGEABLE caller memory with a serial 5 M-iteration validation loop in front: 10.2 ms for a
 // callset the resident pass scores in 0.5 ms.  Here the callset is cut into K row chunks and three things overlap:
 //   host     a small pool of threads validates a chunk's rows (sortedness, contig range, allele bounds - what the
-//            kernels rely on) WHILE copying its columns into a pinned staging slot (two slots, ping-pong);
-//   H2D      the slot's columns go to their place in the resident columns by DMA on a copy stream;
+//            kernels rely on) WHILE packing its twelve columns back to back into a pinned slot (two slots, ping-pong);
+//   H2D      ONE DMA per chunk moves the slot to a device staging block (the host link moves one 200 MB copy at 57.5 GB/s
+//            but 96 pieces of 2 MB at 45: tools/calib/pcie_probe.hip, profiles/r03_pcie_probe.txt); twelve device copies
+//            at HBM rate put the columns in their place in the resident columns;
 //   compute  the scoring pass over that row range runs on the context stream behind an event, and its three result
 //            columns come back by DMA on a third stream into pinned memory, from where the pool copies them into the
 //            caller's arrays while later chunks are still in flight.
@@ -57,7 +59,26 @@ class HostPool {
         done_.wait(g, [this] { return pending_ == 0; });
         job_ = nullptr;
     }
+    // the same without the caller: start() returns at once, wait() blocks until the tasks are done
+    void start(int n_tasks, const std::function<void(int)>& f) {
+        if (n_tasks <= 0) return;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            job_ = &f;
+            n_tasks_ = n_tasks;
+            next_.store(0);
+            pending_ = n_tasks;
+            ++gen_;
+        }
+        cv_.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [this] { return pending_ == 0; });
+        job_ = nullptr;
+    }
     int size() const { return (int)th_.size() + 1; }
+    int workers() const { return (int)th_.size(); }
 
   private:
     void drain() {
@@ -93,14 +114,16 @@ class HostPool {
 
 struct PipeState {
     HostPool* pool = nullptr;
-    hipStream_t h2d = nullptr, h2d_b = nullptr, d2h = nullptr;   // two copy-in streams: two DMA engines share a chunk's columns
-    void* stage[2] = {nullptr, nullptr};        // pinned: one chunk's columns
-    size_t stage_cap = 0;
-    void* res = nullptr;                        // pinned: the whole callset's result columns (score | filter | flags)
+    hipStream_t h2d = nullptr, d2h = nullptr;
+    void* stage[2] = {nullptr, nullptr};        // pinned: one chunk's columns, back to back
+    size_t stage_cap[2] = {0, 0};
+    DeviceBuf d_stage[2];                       // where a slot lands on the device before it is scattered into the columns
+    void* res = nullptr;                        // pinned: every chunk's packed result columns
     size_t res_cap = 0;
+    DeviceBuf d_res;
     void* alle = nullptr;                       // pinned: the allele pool
     size_t alle_cap = 0;
-    std::vector<hipEvent_t> ev;                 // per chunk: columns landed, pass done, results landed; per slot: slot free
+    std::vector<hipEvent_t> ev;                 // four per chunk
 };
 
 static PipeState* pipe_state(ugvc_ctx* ctx) {
@@ -114,9 +137,10 @@ void pipe_destroy(ugvc_ctx* ctx) {
     delete p->pool;
     for (void* q : {p->stage[0], p->stage[1], p->res, p->alle})
         if (q) (void)hipHostFree(q);
+    for (DeviceBuf* b : {&p->d_stage[0], &p->d_stage[1], &p->d_res})
+        if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     if (p->h2d) (void)hipStreamDestroy(p->h2d);
-    if (p->h2d_b) (void)hipStreamDestroy(p->h2d_b);
     if (p->d2h) (void)hipStreamDestroy(p->d2h);
     delete p;
     ctx->pipe = nullptr;
@@ -148,7 +172,6 @@ int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_
         ps->pool = new HostPool(want - 1);
     }
     if (!ps->h2d) UGVC_HIP(hipStreamCreateWithFlags(&ps->h2d, hipStreamNonBlocking));
-    if (!ps->h2d_b) UGVC_HIP(hipStreamCreateWithFlags(&ps->h2d_b, hipStreamNonBlocking));
     if (!ps->d2h) UGVC_HIP(hipStreamCreateWithFlags(&ps->d2h, hipStreamNonBlocking));
     const Col cols[] = {{v->contig, &ctx->v_contig, 2}, {v->pos, &ctx->v_pos, 4},   {v->ref_len, &ctx->v_rl, 2}, {v->alt_len, &ctx->v_al, 2},
                         {v->ref_off, &ctx->v_ro, 4},    {v->alt_off, &ctx->v_ao, 4}, {v->qual, &ctx->v_qual, 4},  {v->sor, &ctx->v_sor, 4},
@@ -160,40 +183,58 @@ int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_
         if (ensure(*c.dst, (size_t)n * c.w)) return -1;
     if (ensure(ctx->v_alleles, (size_t)v->alleles_len + 16)) return -1;
     if (ensure(ctx->r_score, (size_t)n * 4) || ensure(ctx->r_filter, (size_t)n) || ensure(ctx->r_flags, (size_t)n)) return -1;
-    const int64_t rows_chunk = ((n + n_chunks - 1) / n_chunks + 63) & ~(int64_t)63;
-    const int K = (int)((n + rows_chunk - 1) / rows_chunk);
-    if (pinned(ps->stage[0], ps->stage_cap, (size_t)rows_chunk * row_bytes + 64 * NC)) return -1;
+    // chunk bounds: the first and the last chunk are half-size - nothing overlaps the staging of the first (the link idles) nor
+    // the pass + download + hand-over of the last
+    std::vector<int64_t> cb;
     {
-        size_t cap1 = ps->stage[1] ? ps->stage_cap : 0;
-        if (pinned(ps->stage[1], cap1, ps->stage_cap)) return -1;
+        const int64_t unit = ((2 * n + 2 * n_chunks - 3) / (2 * n_chunks - 2) + 63) & ~(int64_t)63;     // n = (K - 1) units
+        int64_t at = 0;
+        cb.push_back(0);
+        at = std::min<int64_t>(((unit / 2) + 63) & ~(int64_t)63, n);
+        if (at > 0 && at < n) cb.push_back(at);
+        while (at < n) {
+            int64_t next = std::min(at + unit, n);
+            if (n - next < unit / 4) next = n;                    // (no sliver at the end)
+            at = next;
+            cb.push_back(at);
+        }
     }
-    if (pinned(ps->res, ps->res_cap, (size_t)n * 6 + 64)) return -1;
+    const int K = (int)cb.size() - 1;
+    int64_t rows_chunk = 0;
+    for (int c = 0; c < K; ++c) rows_chunk = std::max(rows_chunk, cb[(size_t)c + 1] - cb[(size_t)c]);
+    // a slot = one chunk's twelve columns back to back (64-byte aligned) | its three result columns: ONE copy each way per
+    // chunk.  (Twelve copies per chunk - ~2 MB pieces - cost ~1 ms per hundred in fixed overheads: tools/calib/pcie_probe.hip,
+    // 3.65 ms for one 200 MB copy against 4.64 ms for 96 pieces; measured on this call: 6.2 ms with per-column copies.)
+    const size_t slot_bytes = (size_t)rows_chunk * row_bytes + 64 * NC, res_bytes = (size_t)rows_chunk * 6 + 64 * 3;
+    for (int k = 0; k < 2; ++k) {
+        if (pinned(ps->stage[k], ps->stage_cap[k], slot_bytes)) return -1;
+        if (ensure(ps->d_stage[k], slot_bytes)) return -1;
+    }
+    if (pinned(ps->res, ps->res_cap, (size_t)K * res_bytes)) return -1;
+    if (ensure(ps->d_res, (size_t)K * res_bytes)) return -1;
     if (pinned(ps->alle, ps->alle_cap, (size_t)v->alleles_len + 16)) return -1;
-    while (ps->ev.size() < (size_t)(4 * K + 4)) {
+    while (ps->ev.size() < (size_t)(4 * K)) {
         hipEvent_t e;
         UGVC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ps->ev.push_back(e);
     }
-    auto ev_in = [&](int c) { return ps->ev[(size_t)(3 * c)]; };
-    auto ev_pass = [&](int c) { return ps->ev[(size_t)(3 * c + 1)]; };
-    auto ev_out = [&](int c) { return ps->ev[(size_t)(3 * c + 2)]; };
-    hipEvent_t slot_free[2] = {ps->ev[(size_t)(3 * K)], ps->ev[(size_t)(3 * K + 1)]};
-    hipEvent_t slot_free_b[2] = {ps->ev[(size_t)(3 * K + 2)], ps->ev[(size_t)(3 * K + 3)]};
-    auto ev_in_b = [&](int c) { return ps->ev[(size_t)(3 * K + 4 + c)]; };
-    static const bool two_dma = getenv("UGVC_ONE_DMA") == nullptr;
+    auto ev_in = [&](int c) { return ps->ev[(size_t)(4 * c)]; };          // the chunk's slot has landed in device staging
+    auto ev_scat = [&](int c) { return ps->ev[(size_t)(4 * c + 1)]; };    // ... and has been scattered into the resident columns
+    auto ev_pass = [&](int c) { return ps->ev[(size_t)(4 * c + 2)]; };    // the pass over the chunk is done, results packed
+    auto ev_out = [&](int c) { return ps->ev[(size_t)(4 * c + 3)]; };     // the chunk's results are in pinned memory
 
     HostPool& pool = *ps->pool;
     const int T = pool.size();
     // ---- the allele pool first (codes 0..4, 16 zero bytes behind it: allele tails are fetched with fixed-width loads)
     {
-        uint8_t* a = static_cast<uint8_t*>(ps->alle);
+        uint8_t* al = static_cast<uint8_t*>(ps->alle);
         const size_t len = (size_t)v->alleles_len;
         pool.parallel_for(T, [&](int t) {
             const size_t lo = len * (size_t)t / (size_t)T, hi = len * (size_t)(t + 1) / (size_t)T;
-            memcpy(a + lo, v->alleles + lo, hi - lo);
+            memcpy(al + lo, v->alleles + lo, hi - lo);
         });
-        ::memset(a + len, 0, 16);
-        UGVC_HIP(hipMemcpyAsync(ctx->v_alleles.p, a, len + 16, hipMemcpyHostToDevice, ps->h2d));
+        ::memset(al + len, 0, 16);
+        UGVC_HIP(hipMemcpyAsync(ctx->v_alleles.p, al, len + 16, hipMemcpyHostToDevice, ps->h2d));
     }
     // everything queued on the context stream so far (model uploads ...) precedes the first pass; the copy stream must
     // not overwrite columns an earlier pass may still be reading
@@ -203,38 +244,36 @@ int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_
     if (build_args(ctx, base, false)) return -1;
     std::atomic<int64_t> bad_row{INT64_MAX};
     std::atomic<int> bad_what{0};
-    std::atomic<int64_t> n_indel_total{0};
-    uint8_t* rs = static_cast<uint8_t*>(ps->res);
-    float* r_score = reinterpret_cast<float*>(rs);
-    uint8_t* r_filter = rs + (size_t)n * 4;
-    uint8_t* r_flags = r_filter + (size_t)n;
+    int64_t n_indel_total = 0;
     const int n_contigs = ctx->n_contigs;
     int rc = 0;
     int copied_out = 0;                                    // chunks whose results have reached the caller's arrays
+    auto res_off = [&](int c, int64_t m, size_t (&o)[3]) {
+        o[0] = (size_t)c * res_bytes;
+        o[1] = o[0] + (((size_t)m * 4 + 63) & ~(size_t)63);
+        o[2] = o[1] + (((size_t)m + 63) & ~(size_t)63);
+    };
     auto copy_out = [&](int c) -> int {
         UGVC_HIP(hipEventSynchronize(ev_out(c)));
-        const int64_t a = (int64_t)c * rows_chunk, b = std::min(a + rows_chunk, n);
+        const int64_t a = cb[(size_t)c], m = cb[(size_t)c + 1] - a;
+        size_t o[3];
+        res_off(c, m, o);
+        const uint8_t* r = static_cast<const uint8_t*>(ps->res);
         pool.parallel_for(T, [&](int t) {
-            const int64_t lo = a + (b - a) * t / T, hi = a + (b - a) * (t + 1) / T;
-            if (out->tree_score) memcpy(out->tree_score + lo, r_score + lo, (size_t)(hi - lo) * 4);
-            if (out->filter) memcpy(out->filter + lo, r_filter + lo, (size_t)(hi - lo));
-            if (out->flags) memcpy(out->flags + lo, r_flags + lo, (size_t)(hi - lo));
+            const int64_t lo = m * t / T, hi = m * (t + 1) / T;
+            if (out->tree_score) memcpy(out->tree_score + a + lo, r + o[0] + (size_t)lo * 4, (size_t)(hi - lo) * 4);
+            if (out->filter) memcpy(out->filter + a + lo, r + o[1] + (size_t)lo, (size_t)(hi - lo));
+            if (out->flags) memcpy(out->flags + a + lo, r + o[2] + (size_t)lo, (size_t)(hi - lo));
         });
         return 0;
     };
     for (int c = 0; c < K && !rc; ++c) {
-        const int64_t a = (int64_t)c * rows_chunk, b = std::min(a + rows_chunk, n), m = b - a;
+        const int64_t a = cb[(size_t)c], b = cb[(size_t)c + 1], m = b - a;
         const int slot = c & 1;
-        if (c >= 2) {                                                   // the DMA out of this slot (chunk c - 2) has finished
-            UGVC_HIP(hipEventSynchronize(slot_free[slot]));
-            UGVC_HIP(hipEventSynchronize(slot_free_b[slot]));
-        }
+        if (c >= 2) UGVC_HIP(hipEventSynchronize(ev_in(c - 2)));        // the DMA out of this pinned slot (chunk c - 2) has finished
         uint8_t* st = static_cast<uint8_t*>(ps->stage[slot]);
-        size_t off[NC];
-        {
-            size_t o = 0;
-            for (int q = 0; q < NC; ++q) { off[q] = o; o += ((size_t)m * cols[q].w + 63) & ~(size_t)63; }
-        }
+        size_t off[NC], used = 0;
+        for (int q = 0; q < NC; ++q) { off[q] = used; used += ((size_t)m * cols[q].w + 63) & ~(size_t)63; }
         std::atomic<int64_t> n_indel{0};
         pool.parallel_for(T, [&](int t) {
             const int64_t lo = a + m * t / T, hi = a + m * (t + 1) / T;
@@ -262,17 +301,18 @@ int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_
                        (size_t)(hi - lo) * cols[q].w);
         });
         if (bad_row.load() != INT64_MAX) break;
-        n_indel_total.fetch_add(n_indel.load());
-        for (int q = 0; q < NC; ++q)
-            UGVC_HIP(hipMemcpyAsync(static_cast<uint8_t*>(cols[q].dst->p) + (size_t)a * cols[q].w, st + off[q], (size_t)m * cols[q].w,
-                                    hipMemcpyHostToDevice, (two_dma && (q & 1)) ? ps->h2d_b : ps->h2d));
+        n_indel_total += n_indel.load();
+        // ---- one DMA for the whole slot; the device copy of slot (c & 1) is free once chunk c - 2 has been scattered
+        uint8_t* dst = static_cast<uint8_t*>(ps->d_stage[slot].p);
+        if (c >= 2) UGVC_HIP(hipStreamWaitEvent(ps->h2d, ev_scat(c - 2), 0));
+        UGVC_HIP(hipMemcpyAsync(dst, st, used, hipMemcpyHostToDevice, ps->h2d));
         UGVC_HIP(hipEventRecord(ev_in(c), ps->h2d));
-        UGVC_HIP(hipEventRecord(slot_free[slot], ps->h2d));
-        UGVC_HIP(hipEventRecord(ev_in_b(c), ps->h2d_b));
-        UGVC_HIP(hipEventRecord(slot_free_b[slot], ps->h2d_b));
-        // ---- the pass over rows [a, b)
+        // ---- on the context stream: scatter into the resident columns (device copies at HBM rate), then the pass over rows [a, b)
         UGVC_HIP(hipStreamWaitEvent(ctx->stream, ev_in(c), 0));
-        UGVC_HIP(hipStreamWaitEvent(ctx->stream, ev_in_b(c), 0));
+        for (int q = 0; q < NC; ++q)
+            UGVC_HIP(hipMemcpyAsync(static_cast<uint8_t*>(cols[q].dst->p) + (size_t)a * cols[q].w, dst + off[q], (size_t)m * cols[q].w,
+                                    hipMemcpyDeviceToDevice, ctx->stream));
+        UGVC_HIP(hipEventRecord(ev_scat(c), ctx->stream));
         FilterArgs fa = base;
         fa.n = m;
         fa.contig += a; fa.pos += a; fa.ref_len += a; fa.alt_len += a; fa.ref_off += a; fa.alt_off += a;
@@ -283,20 +323,25 @@ int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_
         rc = launch_score(ctx, fa);
         ctx->density_n = 0;
         if (rc) break;
+        // ---- the chunk's three result columns, packed, in one copy
+        size_t o[3];
+        res_off(c, m, o);
+        uint8_t* dr = static_cast<uint8_t*>(ps->d_res.p);
+        UGVC_HIP(hipMemcpyAsync(dr + o[0], ctx->r_score.as<float>() + a, (size_t)m * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        UGVC_HIP(hipMemcpyAsync(dr + o[1], ctx->r_filter.as<uint8_t>() + a, (size_t)m, hipMemcpyDeviceToDevice, ctx->stream));
+        UGVC_HIP(hipMemcpyAsync(dr + o[2], ctx->r_flags.as<uint8_t>() + a, (size_t)m, hipMemcpyDeviceToDevice, ctx->stream));
         UGVC_HIP(hipEventRecord(ev_pass(c), ctx->stream));
         UGVC_HIP(hipStreamWaitEvent(ps->d2h, ev_pass(c), 0));
-        UGVC_HIP(hipMemcpyAsync(r_score + a, ctx->r_score.as<float>() + a, (size_t)m * 4, hipMemcpyDeviceToHost, ps->d2h));
-        UGVC_HIP(hipMemcpyAsync(r_filter + a, ctx->r_filter.as<uint8_t>() + a, (size_t)m, hipMemcpyDeviceToHost, ps->d2h));
-        UGVC_HIP(hipMemcpyAsync(r_flags + a, ctx->r_flags.as<uint8_t>() + a, (size_t)m, hipMemcpyDeviceToHost, ps->d2h));
+        UGVC_HIP(hipMemcpyAsync(static_cast<uint8_t*>(ps->res) + o[0], dr + o[0], o[2] + (size_t)m - o[0], hipMemcpyDeviceToHost, ps->d2h));
         UGVC_HIP(hipEventRecord(ev_out(c), ps->d2h));
         // results of a chunk two behind are long back: hand them to the caller while this one is in flight
         if (c >= 2 && copy_out(copied_out++)) return -1;
     }
-    if (bad_row.load() != INT64_MAX) {
+    if (bad_row.load() != INT64_MAX || rc) {
         (void)hipStreamSynchronize(ps->h2d);
-        (void)hipStreamSynchronize(ps->h2d_b);
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipStreamSynchronize(ps->d2h);
+        if (rc) return -1;
         ctx->n = 0;
         ctx->scored = 0;
         const int64_t i = bad_row.load();
@@ -308,20 +353,12 @@ int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_
             default: return fail("variants must be sorted by (contig, pos); row " + std::to_string(i));
         }
     }
-    if (rc) {
-        (void)hipStreamSynchronize(ps->h2d_b);
-        (void)hipStreamSynchronize(ps->h2d);
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipStreamSynchronize(ps->d2h);
-        return -1;
-    }
     while (copied_out < K)
         if (copy_out(copied_out++)) return -1;
     UGVC_HIP(hipStreamSynchronize(ps->h2d));
-    UGVC_HIP(hipStreamSynchronize(ps->h2d_b));
     UGVC_HIP(hipStreamSynchronize(ctx->stream));
     ctx->n = n;
-    ctx->n_indel = n_indel_total.load();
+    ctx->n_indel = n_indel_total;
     ctx->scored = 1;
     return 0;
 }

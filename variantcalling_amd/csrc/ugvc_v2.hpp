@@ -127,6 +127,7 @@ struct V5Args {
     int scratch_indel;                   // ... of its indel waves (48-byte window rows)
     int n_waves;
     int n_indel_waves;                   // waves of a fused workgroup that work on indel tiles
+    int indel_w;                         // cost of an indel tile relative to an SNP tile, in 1/256 (the wave role split follows it)
 };
 
 int v5_fill_args(ugvc_ctx* ctx, V5Args& v, const FilterArgs& a);

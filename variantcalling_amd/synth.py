@@ -80,7 +80,11 @@ def make_variants(ref: Reference, n: int, seed: int = 20260116, snv_only: bool =
     total = int(ref.contig_off[-1])
     codes = ref.codes
     margin = 80
-    g = np.unique(rng.integers(margin, total - margin, size=int(n * 1.05) + 64, dtype=np.int64))
+    # draws needed for n DISTINCT positions: total * -ln(1 - n / total) (+2 %); the 5 % surplus of the sparse callsets
+    # (5 M, 50 M of 3.1 G positions: unchanged, the goldens depend on it) stops sufficing at 500 M
+    span = total - 2 * margin
+    need = int(-span * np.log1p(-min(n / span, 0.999)) * 1.02) if n < span else n
+    g = np.unique(rng.integers(margin, total - margin, size=max(int(n * 1.05) + 64, need), dtype=np.int64))
     if g.size < n:
         raise ValueError("genome too small for the requested number of variants")
     g = np.sort(rng.choice(g, size=n, replace=False))
