@@ -385,6 +385,28 @@ def test_full_size_properties(engine, frozen_models):
     assert 0.05 < (full.filter == 0).mean() < 0.95
 
 
+def test_feature_matrix_between_scoring_passes(engine, small_callset, frozen_models):
+    """Regression (round 3): the feature matrix now comes from the fused kernel's featurize waves; such a launch writes no
+    indel records and runs no forest kernel, so it must not touch the two record-counter sets - it used to mark the set the
+    previous scoring pass had counted into as zeroed, and the next pass on ANOTHER callset then walked the stale records
+    (caught by the determinism test: wrong TREE_SCORE in the first rows)."""
+    from variantcalling_amd import synth
+    O = _oracle()
+    a = small_callset
+    b = synth.make_callset(45_000, genome_len=25_000_000, n_contigs=3, seed=4321)
+    forests = frozen_models[RF]
+    for first, second in ((a, b), (b, a)):
+        _configure(engine, first.ref, first.runs, first.tracks, first.blacklist, forests)
+        engine.filter_variants(first.variants)
+        engine.feature_matrix(first.variants)
+        engine.feature_matrix(first.variants)
+        _configure(engine, second.ref, second.runs, second.tracks, second.blacklist, forests)
+        got = engine.filter_variants(second.variants)
+        _assert_same(got, O.filter_variants(second.variants, second.ref, second.runs, second.tracks, second.blacklist, forests), "after feature matrices")
+        again = engine.filter_variants(second.variants)
+        _assert_same(again, got, "determinism")
+
+
 @pytest.mark.parametrize("config", ["C3", "C2"])
 def test_full_size_every_row_equals_the_oracle(engine, frozen_models, config):
     """BASELINE.json configs at FULL size, every row: C3 (5 M SNV + indel calls, the configuration the metric is quoted on)

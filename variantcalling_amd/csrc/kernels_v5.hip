@@ -1680,7 +1680,7 @@ static K5 fused5_wx_for(int n_tracks) {
 int launch_feature_matrix_v5(ugvc_ctx* ctx, const FilterArgs& a) {
     if (a.n == 0) return 0;
     V5Args v;
-    if (v5_fill_args(ctx, v, a)) return -1;
+    if (v5_fill_args(ctx, v, a, false)) return -1;
     static bool attr_set[64] = {};
     if (!attr_set[ctx->device & 63]) {
         for (int t = 0; t <= UGVC_MAX_TRACKS; ++t)

@@ -640,7 +640,7 @@ int v5_fused_waves(const V5Args& v);
 
 // Everything the v5 launches need for the resident variants: node tables, index lists, brackets, record lists,
 // and the LDS layout of a wave's staged side-table slices (capacities follow the tables' densities).
-int v5_fill_args(ugvc_ctx* ctx, V5Args& v, const FilterArgs& a) {
+int v5_fill_args(ugvc_ctx* ctx, V5Args& v, const FilterArgs& a, bool scoring) {
     V2State* s = state(ctx);
     if (!s->css.p && build_css_lut(ctx)) return -1;
     v = V5Args{};
@@ -698,17 +698,21 @@ int v5_fill_args(ugvc_ctx* ctx, V5Args& v, const FilterArgs& a) {
     {
         // the forest kernel of a pass zeroes the set the NEXT pass counts into; a set that missed that (the first two
         // passes, a pass without indel models in between) is cleared here
+        // (a feature-matrix launch - scoring == false - writes no records and runs no forest kernel: it must leave the
+        // two counter sets and what is known about them alone.  Found by the determinism test: a feature-matrix launch
+        // between two scoring passes used to mark the set the first pass had counted into as "zeroed by the forest
+        // kernel", and the second pass appended its records behind the first one's.)
         const int cur = s->c5_set;
-        s->c5_set ^= 1;
+        if (scoring) s->c5_set ^= 1;
         uint8_t* base = static_cast<uint8_t*>(s->counters5.p);
-        if (s->c5_dirty[cur]) {
+        if (scoring && s->c5_dirty[cur]) {
             UGVC_HIP(hipMemsetAsync(base + cur * c5_bytes, 0, c5_bytes, ctx->stream));
             s->c5_dirty[cur] = false;
         }
         v.counters = reinterpret_cast<uint32_t*>(base + cur * c5_bytes);
         v.counters_next = reinterpret_cast<uint32_t*>(base + (cur ^ 1) * c5_bytes);
         // (a callset without indels writes no records: no forest launch, nothing to zero)
-        const bool forest = ctx->n_indel > 0 && !(a.ablate & 262144) && (v.pg[1].ok || v.pg[2].ok);
+        const bool forest = scoring && ctx->n_indel > 0 && !(a.ablate & 262144) && (v.pg[1].ok || v.pg[2].ok);
         v.run_forest = forest ? 1 : 0;
         if (forest) {
             s->c5_dirty[cur] = true;

@@ -183,21 +183,13 @@ int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_
         if (ensure(*c.dst, (size_t)n * c.w)) return -1;
     if (ensure(ctx->v_alleles, (size_t)v->alleles_len + 16)) return -1;
     if (ensure(ctx->r_score, (size_t)n * 4) || ensure(ctx->r_filter, (size_t)n) || ensure(ctx->r_flags, (size_t)n)) return -1;
-    // chunk bounds: the first and the last chunk are half-size - nothing overlaps the staging of the first (the link idles) nor
-    // the pass + download + hand-over of the last
+    // chunk bounds: equal chunks (half-size first and last chunks - nothing overlaps the staging of the first nor the tail of
+    // the last - measured no better: 5.6 against 5.3 ms)
     std::vector<int64_t> cb;
     {
-        const int64_t unit = ((2 * n + 2 * n_chunks - 3) / (2 * n_chunks - 2) + 63) & ~(int64_t)63;     // n = (K - 1) units
-        int64_t at = 0;
-        cb.push_back(0);
-        at = std::min<int64_t>(((unit / 2) + 63) & ~(int64_t)63, n);
-        if (at > 0 && at < n) cb.push_back(at);
-        while (at < n) {
-            int64_t next = std::min(at + unit, n);
-            if (n - next < unit / 4) next = n;                    // (no sliver at the end)
-            at = next;
-            cb.push_back(at);
-        }
+        const int64_t unit = ((n + n_chunks - 1) / n_chunks + 63) & ~(int64_t)63;
+        for (int64_t at = 0; at < n; at += unit) cb.push_back(at);
+        cb.push_back(n);
     }
     const int K = (int)cb.size() - 1;
     int64_t rows_chunk = 0;

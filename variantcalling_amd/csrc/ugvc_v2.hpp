@@ -130,7 +130,7 @@ struct V5Args {
     int indel_w;                         // cost of an indel tile relative to an SNP tile, in 1/256 (the wave role split follows it)
 };
 
-int v5_fill_args(ugvc_ctx* ctx, V5Args& v, const FilterArgs& a);
+int v5_fill_args(ugvc_ctx* ctx, V5Args& v, const FilterArgs& a, bool scoring = true);
 
 int pack_model_group(ugvc_ctx* ctx, int g, const int32_t* feature, const float* threshold,
                      const int32_t* left, const int32_t* right, int n_nodes, const int32_t* tree_root,
