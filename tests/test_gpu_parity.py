@@ -548,6 +548,7 @@ def test_rccl_gather_path_single_rank(small_callset, frozen_models):
         configure(e2, cs.ref, cs.runs, cs.tracks, cs.blacklist, frozen_models[RF])
         e2.upload_variants(cs.variants)
         e2.comm_init(e2.comm_unique_id(), 0, 1)
+        assert e2.comm_info() == dict(nranks=1, rank=0, device=0)        # what RCCL itself reports (ncclCommCount / UserRank / CuDevice)
         cap = cs.variants.n + 37                      # padded shard, as ceil(N / world) is in general
         tot, ker = e2.timed_steps(4, cap, True)       # 4 x {scoring pass, overlapped gather}
         assert tot > 0 and ker > 0
