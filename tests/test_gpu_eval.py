@@ -79,3 +79,29 @@ def test_pr_curve_edges(engine):
     ctp, cfp = np.cumsum(cls[order] == 1), np.cumsum(cls[order] == 2)
     assert np.array_equal(rec, evaluate.get_recall(1 + ctp, 4 - ctp, np.nan), equal_nan=True)
     assert np.array_equal(prec, evaluate.get_precision(3 - cfp, 4 - ctp, np.nan), equal_nan=True)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 256, 257, 4095, 4096, 4097, 8191, 8193, 12289, 70_001])
+def test_radix_sort_and_scan_at_tile_edges(engine, n):
+    """The library's own sort / scan (csrc/kernels_prims.hip) around their tile sizes (256-key rounds, 4096-key blocks, scan
+    tiles of 4096 words): full-range f64 keys - every digit position differs, no pass is skipped - with duplicates, both
+    zeros, infinities and NaNs; the order must be numpy's stable order and the running counts exact."""
+    rng = np.random.default_rng(n)
+    s = rng.standard_normal(n) * 10.0 ** rng.integers(-300, 300, n)
+    dup = rng.random(n) < 0.2
+    if dup.any():
+        s[dup] = rng.choice(s, int(dup.sum()))                  # runs of equal keys: the order inside them is the input order
+    if n > 8:
+        s[:8] = [0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, 1.0, -1.0]
+    cls = rng.choice(np.array([0, 1, 2], np.uint8), n)
+    i_tp, i_fp = int((cls == 1).sum()), int((cls == 2).sum())
+    gs, grec, gprec, gf1, order, _ = engine.pr_curve(s, cls, i_tp, i_fp, 7, want_order=True)
+    # numpy sorts -0.0 and 0.0 as equal and NaN last; stable
+    want = np.argsort(s, kind="stable")
+    assert np.array_equal(order, want.astype(np.int32))
+    assert np.array_equal(gs, s[want], equal_nan=True)
+    ctp, cfp = np.cumsum(cls[want] == 1), np.cumsum(cls[want] == 2)
+    rec = evaluate.get_recall(7 + ctp, i_tp - ctp, np.nan)
+    prec = evaluate.get_precision(i_fp - cfp, i_tp - ctp, np.nan)
+    assert np.array_equal(grec, rec, equal_nan=True) and np.array_equal(gprec, prec, equal_nan=True)
+    assert np.array_equal(gf1, evaluate.get_f1(prec, rec), equal_nan=True)
