@@ -1655,6 +1655,10 @@ using K5 = void (*)(const V5Args);
 // 16 trees in flight per lane (8 measured 4 % slower: 506 vs 485 us; kernel variant bit 28 selects 8 for the 3-track kernel)
 static K5 fused5_for(int n_tracks, bool narrow = false) {
     if (narrow && n_tracks == 3) return fused5_kernel<3, 8>;
+    static const int ntw = getenv("UGVC_NTW") ? atoi(getenv("UGVC_NTW")) : 0;          // (profiling: trees in flight, 3-track kernel)
+    if (n_tracks == 3 && ntw == 10) return fused5_kernel<3, 10>;
+    if (n_tracks == 3 && ntw == 20) return fused5_kernel<3, 20>;
+    if (n_tracks == 3 && ntw == 12) return fused5_kernel<3, 12>;
     switch (n_tracks) {
         case 0: return fused5_kernel<0, 16>;
         case 1: return fused5_kernel<1, 16>;
@@ -1706,7 +1710,8 @@ int launch_filter_v5(ugvc_ctx* ctx, const FilterArgs& a) {
     if (v5_fill_args(ctx, v, a)) return -1;
     static bool attr_set[64] = {};                               // (function attributes are per device)
     if (!attr_set[ctx->device & 63]) {
-        for (K5 f : {fused5_for(0), fused5_for(1), fused5_for(2), fused5_for(3), fused5_for(4), fused5_for(5), fused5_for(3, true), (K5)forest5_kernel})
+        for (K5 f : {fused5_for(0), fused5_for(1), fused5_for(2), fused5_for(3), fused5_for(4), fused5_for(5), fused5_for(3, true), (K5)forest5_kernel,
+                     (K5)fused5_kernel<3, 16>})
             UGVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
         attr_set[ctx->device & 63] = true;
     }
