@@ -259,9 +259,10 @@ def test_empty_no_tables_and_ragged(engine, small_callset, frozen_models):
         assert np.array_equal(X, O.featurize(sub, cs.ref, None, [])["X"])
 
 
-def test_error_paths(engine, small_callset):
+def test_error_paths(engine, small_callset, frozen_models):
     import copy
     cs = small_callset
+    _configure(engine, cs.ref, cs.runs, cs.tracks, cs.blacklist, frozen_models[RF])     # (contigs known: also when run alone)
     vt = copy.copy(cs.variants.slice(0, 100))
     vt.pos = vt.pos[::-1].copy()
     with pytest.raises(RuntimeError, match="sorted"):
@@ -272,6 +273,40 @@ def test_error_paths(engine, small_callset):
         engine.filter_variants(vt)
     with pytest.raises(RuntimeError, match="permutation"):
         engine.set_flow_order("AAGT")
+
+
+def test_chunk_pipeline_boundary(engine, frozen_models):
+    """ugvc_filter_variants on a callset large enough for the chunk pipeline (csrc/pipeline.hip: >= 262144 rows; passes read
+    the staging blocks, results are written packed and placed into the resident columns behind the pass): (i) equals the
+    oracle on every row of a 300 k callset whose last chunk is ragged; (ii) leaves the context as upload + resident pass
+    would - a resident pass and a download give the same columns, and the feature matrix of the resident callset equals the
+    oracle's; (iii) a row that breaks the sort order in a LATER chunk is reported by its row number; (iv) the next valid call is unaffected."""
+    import copy
+    from variantcalling_amd import synth
+    O = _oracle()
+    cs = synth.make_callset(300_011, genome_len=150_000_000, n_contigs=5, seed=99)
+    forests = frozen_models[RF]
+    _configure(engine, cs.ref, cs.runs, cs.tracks, cs.blacklist, forests)
+    vt = cs.variants
+    assert vt.n >= 262144
+    got = engine.filter_variants(vt)
+    exp = O.filter_variants(vt, cs.ref, cs.runs, cs.tracks, cs.blacklist, forests)
+    _assert_same(got, exp, "pipelined")
+    _assert_same(engine.download_results(), exp, "resident result columns after the pipelined call")
+    engine.filter_resident()
+    _assert_same(engine.download_results(), exp, "resident pass over the placed columns")
+    X, g = engine.feature_matrix()
+    f = O.featurize(vt, cs.ref, cs.runs, cs.tracks)
+    assert np.array_equal(X, f["X"]) and np.array_equal(g, f["group"])
+    bad = copy.copy(vt)
+    bad.pos = vt.pos.copy()
+    row = 200_003
+    same = np.flatnonzero(vt.contig == vt.contig[row])
+    assert same[0] < row - 2
+    bad.pos[row] = bad.pos[row - 2] - 1 if bad.pos[row - 2] > 1 else 0
+    with pytest.raises(RuntimeError, match=f"row {row}$"):
+        engine.filter_variants(bad)
+    _assert_same(engine.filter_variants(vt), exp, "after the failed call")
 
 
 def test_golden_fixture_outputs(engine, frozen_models):

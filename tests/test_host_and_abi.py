@@ -257,3 +257,78 @@ def test_frame_to_table_rejects_alleles_longer_than_u16():
                    ("alleles", np.array([("A", "C"), ("A" * 70000, "A")], object))])
     with pytest.raises(ValueError, match="longer than 65535"):
         concordance.frame_to_table(fr, ["chr1"])
+
+
+def test_host_row_checks_name_the_first_offending_row(lib):
+    """csrc/host_rows.cpp: the vectorised block check + scalar re-read behind ugvc_variants_upload and the chunk pipeline
+    (internal C++ symbols, no GPU needed) against a row-by-row numpy restatement: clean tables, one planted fault of each
+    kind at block edges (block = 8192 rows), several faults (the FIRST is reported), and piece starts in the middle of a
+    table (row lo is compared with row lo - 1); the streaming copy equals memcpy at odd sizes and alignments."""
+    import ctypes as C
+    from variantcalling_amd import engine as EN
+    vr = getattr(lib, "_ZN4ugvc13validate_rowsEPK13ugvc_variantslliPlS3_")
+    vr.restype = C.c_int
+    vr.argtypes = [C.POINTER(EN.CVariants), C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    rng = np.random.default_rng(5)
+    n, n_contigs = 40_000, 7
+    contig = np.sort(rng.integers(0, n_contigs, n)).astype(np.uint16)
+    pos = np.zeros(n, np.int32)
+    for c in range(n_contigs):
+        m = contig == c
+        pos[m] = np.sort(rng.integers(1, 5_000_000, int(m.sum())))
+    rl = rng.integers(1, 4, n).astype(np.uint16)
+    al = rng.integers(1, 4, n).astype(np.uint16)
+    ro = np.cumsum(np.r_[0, (rl + al)[:-1]]).astype(np.uint32)
+    ao = (ro + rl).astype(np.uint32)
+    alleles_len = int(ro[-1]) + int(rl[-1]) + int(al[-1])
+
+    def run(cols, lo, hi):
+        ct, ps, r, a, rof, aof = (np.ascontiguousarray(x) for x in cols)
+        z8, zf, zi = np.zeros(1, np.uint8), np.zeros(1, np.float32), np.zeros(1, np.int32)
+        cv = EN.CVariants(n, EN._p(ct, EN._u16p), EN._p(ps, EN._i32p), EN._p(r, EN._u16p), EN._p(a, EN._u16p), EN._p(rof, EN._u32p),
+                          EN._p(aof, EN._u32p), EN._p(z8, EN._u8p), alleles_len, EN._p(zf, EN._f32p), EN._p(zf, EN._f32p),
+                          EN._p(zi, EN._i32p), EN._p(zi, EN._i32p), EN._p(zi, EN._i32p), EN._p(z8, EN._u8p))
+        k, row = C.c_int64(0), C.c_int64(-1)
+        what = vr(C.byref(cv), lo, hi, n_contigs, C.byref(k), C.byref(row))
+        return what, row.value, k.value
+
+    def expect(cols, lo, hi):
+        ct, ps, r, a, rof, aof = cols
+        for i in range(lo, hi):
+            if ct[i] >= n_contigs: return 1, i
+            if r[i] == 0 or a[i] == 0: return 2, i
+            if int(rof[i]) + int(r[i]) > alleles_len or int(aof[i]) + int(a[i]) > alleles_len: return 3, i
+            if ps[i] < 1: return 4, i
+            if i and (ct[i] < ct[i - 1] or (ct[i] == ct[i - 1] and ps[i] < ps[i - 1])): return 5, i
+        return 0, -1
+
+    base = (contig, pos, rl, al, ro, ao)
+    for lo, hi in ((0, n), (1, n), (8191, 8193), (12_345, 33_333), (n - 1, n), (5, 5)):
+        what, row, k = run(base, lo, hi)
+        assert (what, row) == (0, -1) and k == int((rl[lo:hi] != al[lo:hi]).sum()), (lo, hi)
+    plant = {1: lambda c, i: c[0].__setitem__(i, 200), 2: lambda c, i: c[2].__setitem__(i, 0), 3: lambda c, i: c[5].__setitem__(i, 2**32 - 1),
+             4: lambda c, i: c[1].__setitem__(i, 0), 5: lambda c, i: c[1].__setitem__(i, max(int(c[1][i - 1]) - 1, 1))}
+    for what_planted, f in plant.items():
+        for i in (0, 1, 8191, 8192, 8193, 16_384, 29_999, n - 1):
+            if what_planted == 5 and (i == 0 or contig[i] != contig[i - 1] or pos[i - 1] <= 1):
+                continue
+            cols = tuple(x.copy() for x in base)
+            f(cols, i)
+            for lo, hi in ((0, n), (max(i - 3, 0), min(i + 3, n)), (i, i + 1), (min(i + 1, n), n)):
+                got = run(cols, lo, hi)[:2]
+                assert got == expect(cols, lo, hi), (what_planted, i, lo, hi, got)
+    cols = tuple(x.copy() for x in base)
+    for i in (30_000, 9_000, 25_000):
+        cols[2][i] = 0
+    cols[1][9_500] = -4
+    assert run(cols, 0, n)[:2] == (2, 9_000) and run(cols, 9_001, n)[:2] == (4, 9_500)
+    cs = getattr(lib, "_ZN4ugvc11copy_streamEPvPKvm")
+    cs.restype = None
+    cs.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    src = rng.integers(0, 256, 300_000).astype(np.uint8)
+    for ln in (0, 1, 4095, 4096, 4097, 70_001, 262_144):
+        for da in (0, 1, 33, 63, 64):
+            for sa in (0, 5):
+                dst = np.full(ln + 200, 0xEE, np.uint8)
+                cs(dst.ctypes.data + 100 + da, src.ctypes.data + sa, ln)
+                assert np.array_equal(dst[100 + da:100 + da + ln], src[sa:sa + ln]) and dst[99 + da] == 0xEE and dst[100 + da + ln] == 0xEE

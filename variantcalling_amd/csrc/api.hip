@@ -124,6 +124,8 @@ int launch_score(ugvc_ctx* ctx, const FilterArgs& a) {
     return launch_filter(ctx, a, true, false);
 }
 
+int validate_rows(const ugvc_variants* v, int64_t lo, int64_t hi, int n_contigs, int64_t* n_indel, int64_t* row);   // host_rows.cpp
+const char* row_error_text(int what);
 void pipe_destroy(ugvc_ctx* ctx);                                                          // pipeline.hip
 int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_results* out, int n_chunks);
 
@@ -423,20 +425,10 @@ int ugvc_variants_upload(ugvc_ctx* ctx, const ugvc_variants* v) {
     if (ctx->n_contigs == 0) return fail("upload the reference before variants");
     UGVC_HIP(hipSetDevice(ctx->device));
     const size_t n = (size_t)v->n;
-    // host-side validation the kernel relies on (sortedness, contig range, allele bounds)
-    int64_t n_indel = 0;                                       // (sizes the indel tiles' table slices: model_pack.hip)
-    for (size_t i = 0; i < n; ++i) {
-        n_indel += v->ref_len[i] != v->alt_len[i] ? 1 : 0;
-        if (v->contig[i] >= ctx->n_contigs) return fail("contig index out of range at row " + std::to_string(i));
-        if (v->ref_len[i] == 0 || v->alt_len[i] == 0) return fail("empty allele at row " + std::to_string(i));
-        if ((int64_t)v->ref_off[i] + v->ref_len[i] > v->alleles_len ||
-            (int64_t)v->alt_off[i] + v->alt_len[i] > v->alleles_len)
-            return fail("allele offset outside the pool at row " + std::to_string(i));
-        if (v->pos[i] < 1) return fail("POS must be >= 1 at row " + std::to_string(i));
-        if (i && (v->contig[i] < v->contig[i - 1] ||
-                  (v->contig[i] == v->contig[i - 1] && v->pos[i] < v->pos[i - 1])))
-            return fail("variants must be sorted by (contig, pos); row " + std::to_string(i));
-    }
+    // host-side validation the kernels rely on (sortedness, contig range, allele bounds): host_rows.cpp, vectorised
+    int64_t n_indel = 0, bad = -1;                             // (n_indel sizes the indel tiles' table slices: model_pack.hip)
+    if (const int what = validate_rows(v, 0, (int64_t)n, ctx->n_contigs, &n_indel, &bad))
+        return fail(std::string(row_error_text(what)) + std::to_string(bad));
     if (upload(ctx, ctx->v_contig, v->contig, n * 2)) return -1;
     if (upload(ctx, ctx->v_pos, v->pos, n * 4)) return -1;
     if (upload(ctx, ctx->v_rl, v->ref_len, n * 2)) return -1;
@@ -486,7 +478,8 @@ int ugvc_filter_variants(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_resul
     // large callsets: a chunk pipeline - host validation + staging || H2D || pass || D2H (pipeline.hip); UGVC_PIPE_CHUNKS
     // sets the number of chunks (1 = the plain upload / pass / download sequence below)
     if (ctx && v && out && v->n >= 262144 && check_variants(v) == 0 && ctx->n_contigs > 0) {
-        static const int chunks = getenv("UGVC_PIPE_CHUNKS") ? atoi(getenv("UGVC_PIPE_CHUNKS")) : 8;
+        const char* e = getenv("UGVC_PIPE_CHUNKS");          // (read per call: tools/e2e_ab.py sweeps it in one process)
+        const int chunks = std::min(e ? atoi(e) : 8, 64);
         if (chunks > 1) {
             UGVC_HIP(hipSetDevice(ctx->device));
             return filter_variants_pipelined(ctx, v, out, chunks);

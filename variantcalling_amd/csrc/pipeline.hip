@@ -19,108 +19,24 @@
 #include <string.h>
 
 #include <atomic>
+#include <chrono>
 #include <fstream>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
 #include <thread>
 
+#include "host_pool.hpp"
 #include "ugvc_v2.hpp"
 
 namespace ugvc {
 
 int launch_score(ugvc_ctx* ctx, const FilterArgs& a);
-
-// ---- a persistent pool: parallel_for(n_tasks, f) runs f(task) on the workers and on the caller
-class HostPool {
-  public:
-    // `cpus`: the workers stay on these CPUs (the GPU's NUMA node: staging buffers and copy engines are local to it)
-    explicit HostPool(int n_threads, const cpu_set_t* cpus = nullptr) {
-        if (cpus) { cpus_ = *cpus; pinned_ = true; }
-        for (int t = 0; t < n_threads; ++t)
-            th_.emplace_back([this] {
-                if (pinned_) (void)sched_setaffinity(0, sizeof(cpus_), &cpus_);
-                work();
-            });
-    }
-    ~HostPool() {
-        {
-            std::lock_guard<std::mutex> g(m_);
-            stop_ = true;
-        }
-        cv_.notify_all();
-        for (auto& t : th_) t.join();
-    }
-    void parallel_for(int n_tasks, const std::function<void(int)>& f) {
-        if (n_tasks <= 0) return;
-        {
-            std::lock_guard<std::mutex> g(m_);
-            job_ = &f;
-            n_tasks_ = n_tasks;
-            next_.store(0);
-            pending_ = n_tasks;
-            ++gen_;
-        }
-        cv_.notify_all();
-        drain();                                             // the caller works too
-        std::unique_lock<std::mutex> g(m_);
-        done_.wait(g, [this] { return pending_ == 0; });
-        job_ = nullptr;
-    }
-    // the same without the caller: start() returns at once, wait() blocks until the tasks are done
-    void start(int n_tasks, const std::function<void(int)>& f) {
-        if (n_tasks <= 0) return;
-        {
-            std::lock_guard<std::mutex> g(m_);
-            job_ = &f;
-            n_tasks_ = n_tasks;
-            next_.store(0);
-            pending_ = n_tasks;
-            ++gen_;
-        }
-        cv_.notify_all();
-    }
-    void wait() {
-        std::unique_lock<std::mutex> g(m_);
-        done_.wait(g, [this] { return pending_ == 0; });
-        job_ = nullptr;
-    }
-    int size() const { return (int)th_.size() + 1; }
-    int workers() const { return (int)th_.size(); }
-
-  private:
-    void drain() {
-        for (;;) {
-            const int t = next_.fetch_add(1);
-            if (t >= n_tasks_) return;
-            (*job_)(t);
-            std::lock_guard<std::mutex> g(m_);
-            if (--pending_ == 0) done_.notify_all();
-        }
-    }
-    void work() {
-        uint64_t seen = 0;
-        for (;;) {
-            {
-                std::unique_lock<std::mutex> g(m_);
-                cv_.wait(g, [&] { return stop_ || (gen_ != seen && job_ != nullptr); });
-                if (stop_) return;
-                seen = gen_;
-            }
-            drain();
-        }
-    }
-    cpu_set_t cpus_;
-    bool pinned_ = false;
-    std::vector<std::thread> th_;
-    std::mutex m_;
-    std::condition_variable cv_, done_;
-    const std::function<void(int)>* job_ = nullptr;
-    std::atomic<int> next_{0};
-    int n_tasks_ = 0, pending_ = 0;
-    uint64_t gen_ = 0;
-    bool stop_ = false;
-};
+// host_rows.cpp (g++, vectorised)
+int validate_rows(const ugvc_variants* v, int64_t lo, int64_t hi, int n_contigs, int64_t* n_indel, int64_t* row);
+const char* row_error_text(int what);
+void copy_stream(void* dst, const void* src, size_t n);
+void copy_stream_fence();
 
 // CPUs of the NUMA node the GPU hangs on (sysfs: the PCI device's numa_node, the node's cpulist); false when the host has one
 // node, hides the topology, or UGVC_NO_NUMA is set.  On the two-socket hosts of this pool the boundary call takes 5.3-5.6 ms
@@ -154,17 +70,22 @@ static bool gpu_node_cpus(int device, cpu_set_t& out) {
 }
 
 struct PipeState {
+    static constexpr int kSlots = 3;            // staging slots in flight: being packed | in the DMA | being read by a pass
     HostPool* pool = nullptr;
+    bool numa_known = false, numa = false;      // the GPU's NUMA node, looked up once
+    cpu_set_t node_cpus;
     hipStream_t h2d = nullptr, d2h = nullptr;
-    void* stage[2] = {nullptr, nullptr};        // pinned: one chunk's columns, back to back
-    size_t stage_cap[2] = {0, 0};
-    DeviceBuf d_stage[2];                       // where a slot lands on the device before it is scattered into the columns
+    void* stage[kSlots] = {nullptr, nullptr, nullptr};   // pinned: one chunk's columns, back to back
+    size_t stage_cap[kSlots] = {0, 0, 0};
+    DeviceBuf d_stage[kSlots];                  // where a slot lands on the device; the chunk's pass reads its columns HERE
     void* res = nullptr;                        // pinned: every chunk's packed result columns
     size_t res_cap = 0;
-    DeviceBuf d_res;
+    DeviceBuf d_res;                            // the passes write their results HERE, packed per chunk
     void* alle = nullptr;                       // pinned: the allele pool
     size_t alle_cap = 0;
     std::vector<hipEvent_t> ev;                 // four per chunk
+    bool ev_timed = false;                      // (UGVC_PIPE_TRACE: the events carry timestamps)
+    hipEvent_t ev_t0 = nullptr;
 };
 
 static PipeState* pipe_state(ugvc_ctx* ctx) {
@@ -176,11 +97,12 @@ void pipe_destroy(ugvc_ctx* ctx) {
     if (!ctx->pipe) return;
     PipeState* p = static_cast<PipeState*>(ctx->pipe);
     delete p->pool;
-    for (void* q : {p->stage[0], p->stage[1], p->res, p->alle})
+    for (void* q : {p->stage[0], p->stage[1], p->stage[2], p->res, p->alle})
         if (q) (void)hipHostFree(q);
-    for (DeviceBuf* b : {&p->d_stage[0], &p->d_stage[1], &p->d_res})
+    for (DeviceBuf* b : {&p->d_stage[0], &p->d_stage[1], &p->d_stage[2], &p->d_res})
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
+    if (p->ev_t0) (void)hipEventDestroy(p->ev_t0);
     if (p->h2d) (void)hipStreamDestroy(p->h2d);
     if (p->d2h) (void)hipStreamDestroy(p->d2h);
     delete p;
@@ -204,22 +126,57 @@ struct Col {
     size_t w;
 };
 
+// ---- one launch moves a chunk's fifteen segments (twelve columns out of the staging block, three result columns out of the
+// packed result block) into the resident columns - off the critical path: the pass has already read the staging block and
+// the results are already on their way to the host.  Every segment starts 16-byte aligned on both sides (chunks start at
+// multiples of 64 rows, slot offsets are multiples of 64 bytes).
+struct Seg {
+    const uint8_t* src;
+    uint8_t* dst;
+    uint64_t bytes;
+};
+struct SegTable {
+    Seg s[16];
+};
+
+__global__ void __launch_bounds__(256) pipe_place_kernel(SegTable t) {
+    const Seg s = t.s[blockIdx.y];
+    const uint64_t n16 = s.bytes >> 4;
+    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(s.src);
+    uint4* __restrict__ dst = reinterpret_cast<uint4*>(s.dst);
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256) dst[i] = src[i];
+    if (blockIdx.x == 0 && threadIdx.x < (unsigned)(s.bytes & 15)) s.dst[(n16 << 4) + threadIdx.x] = s.src[(n16 << 4) + threadIdx.x];
+}
+
 int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_results* out, int n_chunks) {
+    // UGVC_PIPE_TRACE=1: host and device timeline of the call on stderr (ms since entry; tools/pipe_trace.py reads it)
+    static const bool trace = getenv("UGVC_PIPE_TRACE") != nullptr;
+    const auto t_entry = std::chrono::steady_clock::now();
+    auto now_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count(); };
+    struct HostMark { int chunk; const char* what; double ms; };
+    std::vector<HostMark> marks;
+    auto mark = [&](int c, const char* what) { if (trace) marks.push_back({c, what, now_ms()}); };
+
+    constexpr int NS = PipeState::kSlots;
     const int64_t n = v->n;
     PipeState* ps = pipe_state(ctx);
     // pool and pinned staging live on the GPU's NUMA node: the calling thread is moved there for the duration of the call
-    // (it packs and hands over too) and put back on its own CPUs afterwards
-    cpu_set_t node_cpus, mine;
-    const bool numa = gpu_node_cpus(ctx->device, node_cpus) && sched_getaffinity(0, sizeof(mine), &mine) == 0;
+    // (it hands the chunks over) and put back on its own CPUs afterwards
+    if (!ps->numa_known) {
+        ps->numa = gpu_node_cpus(ctx->device, ps->node_cpus);
+        ps->numa_known = true;
+    }
+    cpu_set_t mine;
+    const bool numa = ps->numa && sched_getaffinity(0, sizeof(mine), &mine) == 0;
     struct Restore {
         bool on; cpu_set_t set;
         ~Restore() { if (on) (void)sched_setaffinity(0, sizeof(set), &set); }
     } restore{numa, mine};
-    if (numa) (void)sched_setaffinity(0, sizeof(node_cpus), &node_cpus);
+    if (numa) (void)sched_setaffinity(0, sizeof(ps->node_cpus), &ps->node_cpus);
     if (!ps->pool) {
         int want = (int)std::min<unsigned>(std::max(2u, std::thread::hardware_concurrency() / 2), 16u);
-        if (const char* e = getenv("UGVC_HOST_THREADS")) want = std::max(1, atoi(e));
-        ps->pool = new HostPool(want - 1, numa ? &node_cpus : nullptr);
+        if (const char* e = getenv("UGVC_HOST_THREADS")) want = std::max(2, atoi(e));
+        ps->pool = new HostPool(want - 1, numa ? &ps->node_cpus : nullptr);
     }
     if (!ps->h2d) UGVC_HIP(hipStreamCreateWithFlags(&ps->h2d, hipStreamNonBlocking));
     if (!ps->d2h) UGVC_HIP(hipStreamCreateWithFlags(&ps->d2h, hipStreamNonBlocking));
@@ -233,12 +190,27 @@ int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_
         if (ensure(*c.dst, (size_t)n * c.w)) return -1;
     if (ensure(ctx->v_alleles, (size_t)v->alleles_len + 16)) return -1;
     if (ensure(ctx->r_score, (size_t)n * 4) || ensure(ctx->r_filter, (size_t)n) || ensure(ctx->r_flags, (size_t)n)) return -1;
-    // chunk bounds: equal chunks (half-size first and last chunks - nothing overlaps the staging of the first nor the tail of
-    // the last - measured no better: 5.6 against 5.3 ms)
+    // chunk bounds (multiples of 64 rows): equal chunks, except that the first and the last are cut again into 1/4 + 1/4 + 1/2 -
+    // nothing overlaps the packing of the first chunk nor the pass + download of the last, so those two are kept short
+    // (UGVC_PIPE_TAPER=0: plain equal chunks)
     std::vector<int64_t> cb;
     {
+        const char* te = getenv("UGVC_PIPE_TAPER");
+        const bool taper = (te ? atoi(te) != 0 : true) && n_chunks >= 4;
         const int64_t unit = ((n + n_chunks - 1) / n_chunks + 63) & ~(int64_t)63;
-        for (int64_t at = 0; at < n; at += unit) cb.push_back(at);
+        const int64_t q = std::max<int64_t>(64, (unit / 4 + 63) & ~(int64_t)63);
+        std::vector<int64_t> sizes;
+        int64_t left = n;
+        auto take = [&](int64_t m) { m = std::min(m, left); if (m > 0) { sizes.push_back(m); left -= m; } };
+        if (taper) { take(q); take(q); take(unit - 2 * q); }
+        while (left > (taper ? unit : 0)) take(unit);
+        if (taper && left > 0) {
+            // the remainder (at most one unit): 1/2 + 1/4 + 1/4 of it
+            const int64_t h = (left / 2 + 63) & ~(int64_t)63, r = ((left - h) / 2 + 63) & ~(int64_t)63;
+            take(h); take(r); take(left);
+        }
+        int64_t at = 0;
+        for (int64_t m : sizes) { cb.push_back(at); at += m; }
         cb.push_back(n);
     }
     const int K = (int)cb.size() - 1;
@@ -247,137 +219,189 @@ int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_
     // a slot = one chunk's twelve columns back to back (64-byte aligned) | its three result columns: ONE copy each way per
     // chunk.  (Twelve copies per chunk - ~2 MB pieces - cost ~1 ms per hundred in fixed overheads: tools/calib/pcie_probe.hip,
     // 3.65 ms for one 200 MB copy against 4.64 ms for 96 pieces; measured on this call: 6.2 ms with per-column copies.)
-    const size_t slot_bytes = (size_t)rows_chunk * row_bytes + 64 * NC, res_bytes = (size_t)rows_chunk * 6 + 64 * 3;
-    for (int k = 0; k < 2; ++k) {
+    const size_t slot_bytes = (size_t)rows_chunk * row_bytes + 64 * NC + 256, res_bytes = (size_t)rows_chunk * 6 + 64 * 3;
+    for (int k = 0; k < NS; ++k) {
         if (pinned(ps->stage[k], ps->stage_cap[k], slot_bytes)) return -1;
         if (ensure(ps->d_stage[k], slot_bytes)) return -1;
     }
     if (pinned(ps->res, ps->res_cap, (size_t)K * res_bytes)) return -1;
     if (ensure(ps->d_res, (size_t)K * res_bytes)) return -1;
     if (pinned(ps->alle, ps->alle_cap, (size_t)v->alleles_len + 16)) return -1;
+    if (trace && !ps->ev_timed) {
+        for (hipEvent_t e : ps->ev) (void)hipEventDestroy(e);
+        ps->ev.clear();
+        ps->ev_timed = true;
+        UGVC_HIP(hipEventCreate(&ps->ev_t0));
+    }
     while (ps->ev.size() < (size_t)(4 * K)) {
         hipEvent_t e;
-        UGVC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        UGVC_HIP(hipEventCreateWithFlags(&e, ps->ev_timed ? hipEventDefault : hipEventDisableTiming));
         ps->ev.push_back(e);
     }
     auto ev_in = [&](int c) { return ps->ev[(size_t)(4 * c)]; };          // the chunk's slot has landed in device staging
-    auto ev_scat = [&](int c) { return ps->ev[(size_t)(4 * c + 1)]; };    // ... and has been scattered into the resident columns
-    auto ev_pass = [&](int c) { return ps->ev[(size_t)(4 * c + 2)]; };    // the pass over the chunk is done, results packed
-    auto ev_out = [&](int c) { return ps->ev[(size_t)(4 * c + 3)]; };     // the chunk's results are in pinned memory
+    auto ev_pass = [&](int c) { return ps->ev[(size_t)(4 * c + 1)]; };    // the pass over the chunk is done
+    auto ev_out = [&](int c) { return ps->ev[(size_t)(4 * c + 2)]; };     // the chunk's results are in pinned memory
+    auto ev_placed = [&](int c) { return ps->ev[(size_t)(4 * c + 3)]; };  // columns and results copied into the resident columns
 
     HostPool& pool = *ps->pool;
     const int T = pool.size();
-    // ---- the allele pool first (codes 0..4, 16 zero bytes behind it: allele tails are fetched with fixed-width loads)
-    {
-        uint8_t* al = static_cast<uint8_t*>(ps->alle);
-        const size_t len = (size_t)v->alleles_len;
-        pool.parallel_for(T, [&](int t) {
-            const size_t lo = len * (size_t)t / (size_t)T, hi = len * (size_t)(t + 1) / (size_t)T;
-            memcpy(al + lo, v->alleles + lo, hi - lo);
-        });
-        ::memset(al + len, 0, 16);
-        UGVC_HIP(hipMemcpyAsync(ctx->v_alleles.p, al, len + 16, hipMemcpyHostToDevice, ps->h2d));
-    }
-    // everything queued on the context stream so far (model uploads ...) precedes the first pass; the copy stream must
-    // not overwrite columns an earlier pass may still be reading
-    UGVC_HIP(hipStreamSynchronize(ctx->stream));
+    struct Burst {
+        HostPool& p;
+        explicit Burst(HostPool& q) : p(q) { p.burst(true); }
+        ~Burst() { p.burst(false); }
+    } burst_guard(pool);
+    const char* nt_env = getenv("UGVC_PIPE_NT");
+    const bool stream_stores = nt_env ? atoi(nt_env) != 0 : true;
+    mark(-1, "setup");
+    if (trace) UGVC_HIP(hipEventRecord(ps->ev_t0, ps->h2d));
 
-    FilterArgs base;
-    if (build_args(ctx, base, false)) return -1;
     std::atomic<int64_t> bad_row{INT64_MAX};
     std::atomic<int> bad_what{0};
-    int64_t n_indel_total = 0;
+    std::vector<std::atomic<int64_t>> chunk_indel((size_t)K);
+    for (auto& x : chunk_indel) x.store(0);
     const int n_contigs = ctx->n_contigs;
-    int rc = 0;
-    int copied_out = 0;                                    // chunks whose results have reached the caller's arrays
+    auto slot_offsets = [&](int64_t m, size_t (&off)[NC]) {
+        size_t used = 0;
+        for (int q = 0; q < NC; ++q) { off[q] = used; used += ((size_t)m * cols[q].w + 63) & ~(size_t)63; }
+        return used;
+    };
     auto res_off = [&](int c, int64_t m, size_t (&o)[3]) {
         o[0] = (size_t)c * res_bytes;
         o[1] = o[0] + (((size_t)m * 4 + 63) & ~(size_t)63);
         o[2] = o[1] + (((size_t)m + 63) & ~(size_t)63);
     };
-    auto copy_out = [&](int c) -> int {
-        UGVC_HIP(hipEventSynchronize(ev_out(c)));
+    // piece t of T of chunk c: validation of its rows (what the kernels rely on), then the copy into the chunk's pinned slot
+    auto pack_piece = [&](int c, int t) {
+        const int64_t a = cb[(size_t)c], m = cb[(size_t)c + 1] - a;
+        const int64_t lo = a + m * t / T, hi = a + m * (t + 1) / T;
+        if (hi <= lo) return;
+        uint8_t* st = static_cast<uint8_t*>(ps->stage[c % NS]);
+        size_t off[NC];
+        (void)slot_offsets(m, off);
+        int64_t ind = 0, row = -1;
+        if (const int what = validate_rows(v, lo, hi, n_contigs, &ind, &row)) {
+            int64_t cur = bad_row.load();
+            while (row < cur && !bad_row.compare_exchange_weak(cur, row)) {}
+            if (bad_row.load() == row) bad_what.store(what);
+            return;
+        }
+        chunk_indel[(size_t)c].fetch_add(ind);
+        for (int q = 0; q < NC; ++q) {
+            uint8_t* d = st + off[q] + (size_t)(lo - a) * cols[q].w;
+            const uint8_t* sp = static_cast<const uint8_t*>(cols[q].src) + (size_t)lo * cols[q].w;
+            if (stream_stores) copy_stream(d, sp, (size_t)(hi - lo) * cols[q].w);
+            else memcpy(d, sp, (size_t)(hi - lo) * cols[q].w);
+        }
+        if (stream_stores) copy_stream_fence();
+    };
+    // piece t of T of chunk c's results: pinned memory -> the caller's arrays
+    auto out_piece = [&](int c, int t) {
         const int64_t a = cb[(size_t)c], m = cb[(size_t)c + 1] - a;
         size_t o[3];
         res_off(c, m, o);
         const uint8_t* r = static_cast<const uint8_t*>(ps->res);
-        pool.parallel_for(T, [&](int t) {
-            const int64_t lo = m * t / T, hi = m * (t + 1) / T;
-            if (out->tree_score) memcpy(out->tree_score + a + lo, r + o[0] + (size_t)lo * 4, (size_t)(hi - lo) * 4);
-            if (out->filter) memcpy(out->filter + a + lo, r + o[1] + (size_t)lo, (size_t)(hi - lo));
-            if (out->flags) memcpy(out->flags + a + lo, r + o[2] + (size_t)lo, (size_t)(hi - lo));
-        });
-        return 0;
+        const int64_t lo = m * t / T, hi = m * (t + 1) / T;
+        if (out->tree_score) memcpy(out->tree_score + a + lo, r + o[0] + (size_t)lo * 4, (size_t)(hi - lo) * 4);
+        if (out->filter) memcpy(out->filter + a + lo, r + o[1] + (size_t)lo, (size_t)(hi - lo));
+        if (out->flags) memcpy(out->flags + a + lo, r + o[2] + (size_t)lo, (size_t)(hi - lo));
     };
-    for (int c = 0; c < K && !rc; ++c) {
-        const int64_t a = cb[(size_t)c], b = cb[(size_t)c + 1], m = b - a;
-        const int slot = c & 1;
-        if (c >= 2) UGVC_HIP(hipEventSynchronize(ev_in(c - 2)));        // the DMA out of this pinned slot (chunk c - 2) has finished
-        uint8_t* st = static_cast<uint8_t*>(ps->stage[slot]);
-        size_t off[NC], used = 0;
-        for (int q = 0; q < NC; ++q) { off[q] = used; used += ((size_t)m * cols[q].w + 63) & ~(size_t)63; }
-        std::atomic<int64_t> n_indel{0};
-        pool.parallel_for(T, [&](int t) {
-            const int64_t lo = a + m * t / T, hi = a + m * (t + 1) / T;
-            if (hi <= lo) return;
-            // validation of rows [lo, hi) (what the kernels rely on), then the copy
-            int64_t ind = 0;
-            for (int64_t i = lo; i < hi; ++i) {
-                int what = 0;
-                ind += v->ref_len[i] != v->alt_len[i] ? 1 : 0;
-                if (v->contig[i] >= n_contigs) what = 1;
-                else if (v->ref_len[i] == 0 || v->alt_len[i] == 0) what = 2;
-                else if ((int64_t)v->ref_off[i] + v->ref_len[i] > v->alleles_len || (int64_t)v->alt_off[i] + v->alt_len[i] > v->alleles_len) what = 3;
-                else if (v->pos[i] < 1) what = 4;
-                else if (i && (v->contig[i] < v->contig[i - 1] || (v->contig[i] == v->contig[i - 1] && v->pos[i] < v->pos[i - 1]))) what = 5;
-                if (what) {
-                    int64_t cur = bad_row.load();
-                    while (i < cur && !bad_row.compare_exchange_weak(cur, i)) {}
-                    if (bad_row.load() == i) bad_what.store(what);
-                    break;
-                }
+    // ---- head: the allele pool (codes 0..4, 16 zero bytes behind it: allele tails are fetched with fixed-width loads) and
+    // chunk 0 are packed in one go
+    {
+        uint8_t* al = static_cast<uint8_t*>(ps->alle);
+        const size_t len = (size_t)v->alleles_len;
+        pool.parallel_for(2 * T, [&](int task) {
+            if (task < T) {
+                const size_t lo = len * (size_t)task / (size_t)T, hi = len * (size_t)(task + 1) / (size_t)T;
+                memcpy(al + lo, v->alleles + lo, hi - lo);
+            } else {
+                pack_piece(0, task - T);
             }
-            n_indel.fetch_add(ind);
-            for (int q = 0; q < NC; ++q)
-                memcpy(st + off[q] + (size_t)(lo - a) * cols[q].w, static_cast<const uint8_t*>(cols[q].src) + (size_t)lo * cols[q].w,
-                       (size_t)(hi - lo) * cols[q].w);
         });
-        if (bad_row.load() != INT64_MAX) break;
-        n_indel_total += n_indel.load();
-        // ---- one DMA for the whole slot; the device copy of slot (c & 1) is free once chunk c - 2 has been scattered
+        ::memset(al + len, 0, 16);
+        mark(0, "head_packed");
+        // everything queued on the context stream so far (model uploads, an earlier resident pass ...) precedes the first copy:
+        // the copy stream must not overwrite the allele pool or columns such a pass may still be reading
+        UGVC_HIP(hipStreamSynchronize(ctx->stream));
+        UGVC_HIP(hipMemcpyAsync(ctx->v_alleles.p, al, len + 16, hipMemcpyHostToDevice, ps->h2d));
+    }
+    FilterArgs base;
+    if (build_args(ctx, base, false)) return -1;
+    mark(-1, "args");
+
+    int64_t n_indel_total = 0;
+    int rc = 0, issued = 0;
+    int job_pack = -1, job_out = -1;
+    const std::function<void(int)> job = [&](int task) {
+        if (task < T) { if (job_pack >= 0) pack_piece(job_pack, task); }
+        else if (job_out >= 0) out_piece(job_out, task - T);
+    };
+    for (int c = 0; c < K && !rc && bad_row.load() == INT64_MAX; ++c) {
+        const int64_t a = cb[(size_t)c], b = cb[(size_t)c + 1], m = b - a;
+        const int slot = c % NS;
+        size_t off[NC];
+        const size_t used = slot_offsets(m, off);
+        n_indel_total += chunk_indel[(size_t)c].load();
+        // ---- one DMA for the whole slot; the device block of this slot is free once chunk c - NS has been placed
+        uint8_t* st = static_cast<uint8_t*>(ps->stage[slot]);
         uint8_t* dst = static_cast<uint8_t*>(ps->d_stage[slot].p);
-        if (c >= 2) UGVC_HIP(hipStreamWaitEvent(ps->h2d, ev_scat(c - 2), 0));
+        if (c >= NS) UGVC_HIP(hipStreamWaitEvent(ps->h2d, ev_placed(c - NS), 0));
         UGVC_HIP(hipMemcpyAsync(dst, st, used, hipMemcpyHostToDevice, ps->h2d));
         UGVC_HIP(hipEventRecord(ev_in(c), ps->h2d));
-        // ---- on the context stream: scatter into the resident columns (device copies at HBM rate), then the pass over rows [a, b)
+        // ---- the pass over the chunk reads its columns where the DMA put them and writes its results packed
+        size_t o[3];
+        res_off(c, m, o);
+        uint8_t* dr = static_cast<uint8_t*>(ps->d_res.p);
         UGVC_HIP(hipStreamWaitEvent(ctx->stream, ev_in(c), 0));
-        for (int q = 0; q < NC; ++q)
-            UGVC_HIP(hipMemcpyAsync(static_cast<uint8_t*>(cols[q].dst->p) + (size_t)a * cols[q].w, dst + off[q], (size_t)m * cols[q].w,
-                                    hipMemcpyDeviceToDevice, ctx->stream));
-        UGVC_HIP(hipEventRecord(ev_scat(c), ctx->stream));
         FilterArgs fa = base;
         fa.n = m;
-        fa.contig += a; fa.pos += a; fa.ref_len += a; fa.alt_len += a; fa.ref_off += a; fa.alt_off += a;
-        fa.qual += a; fa.sor += a; fa.dp += a; fa.ad_ref += a; fa.ad_alt += a; fa.gq += a;
-        fa.score += a; fa.filter += a; fa.flags += a;
-        ctx->n_indel = n_indel.load() * K;                  // (sizes the indel tiles' table slices: the callset-wide rate, from this chunk)
+        fa.contig = reinterpret_cast<const uint16_t*>(dst + off[0]);
+        fa.pos = reinterpret_cast<const int32_t*>(dst + off[1]);
+        fa.ref_len = reinterpret_cast<const uint16_t*>(dst + off[2]);
+        fa.alt_len = reinterpret_cast<const uint16_t*>(dst + off[3]);
+        fa.ref_off = reinterpret_cast<const uint32_t*>(dst + off[4]);
+        fa.alt_off = reinterpret_cast<const uint32_t*>(dst + off[5]);
+        fa.qual = reinterpret_cast<const float*>(dst + off[6]);
+        fa.sor = reinterpret_cast<const float*>(dst + off[7]);
+        fa.dp = reinterpret_cast<const int32_t*>(dst + off[8]);
+        fa.ad_ref = reinterpret_cast<const int32_t*>(dst + off[9]);
+        fa.ad_alt = reinterpret_cast<const int32_t*>(dst + off[10]);
+        fa.gq = reinterpret_cast<const uint8_t*>(dst + off[11]);
+        fa.score = reinterpret_cast<float*>(dr + o[0]);
+        fa.filter = dr + o[1];
+        fa.flags = dr + o[2];
+        ctx->n_indel = chunk_indel[(size_t)c].load() * K;   // (sizes the indel tiles' table slices: the callset-wide rate, from this chunk)
         ctx->density_n = n;                                 // (table rows per tile are a property of the whole callset)
         rc = launch_score(ctx, fa);
         ctx->density_n = 0;
         if (rc) break;
-        // ---- the chunk's three result columns, packed, in one copy
-        size_t o[3];
-        res_off(c, m, o);
-        uint8_t* dr = static_cast<uint8_t*>(ps->d_res.p);
-        UGVC_HIP(hipMemcpyAsync(dr + o[0], ctx->r_score.as<float>() + a, (size_t)m * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        UGVC_HIP(hipMemcpyAsync(dr + o[1], ctx->r_filter.as<uint8_t>() + a, (size_t)m, hipMemcpyDeviceToDevice, ctx->stream));
-        UGVC_HIP(hipMemcpyAsync(dr + o[2], ctx->r_flags.as<uint8_t>() + a, (size_t)m, hipMemcpyDeviceToDevice, ctx->stream));
         UGVC_HIP(hipEventRecord(ev_pass(c), ctx->stream));
         UGVC_HIP(hipStreamWaitEvent(ps->d2h, ev_pass(c), 0));
         UGVC_HIP(hipMemcpyAsync(static_cast<uint8_t*>(ps->res) + o[0], dr + o[0], o[2] + (size_t)m - o[0], hipMemcpyDeviceToHost, ps->d2h));
         UGVC_HIP(hipEventRecord(ev_out(c), ps->d2h));
-        // results of a chunk two behind are long back: hand them to the caller while this one is in flight
-        if (c >= 2 && copy_out(copied_out++)) return -1;
+        // ---- behind the pass: columns and results into their resident places (what ugvc_filter_resident / ugvc_results_download
+        // / ugvc_feature_matrix find afterwards)
+        {
+            SegTable t;
+            for (int q = 0; q < NC; ++q)
+                t.s[q] = Seg{dst + off[q], static_cast<uint8_t*>(cols[q].dst->p) + (size_t)a * cols[q].w, (uint64_t)m * cols[q].w};
+            t.s[NC] = Seg{dr + o[0], reinterpret_cast<uint8_t*>(ctx->r_score.as<float>() + a), (uint64_t)m * 4};
+            t.s[NC + 1] = Seg{dr + o[1], ctx->r_filter.as<uint8_t>() + a, (uint64_t)m};
+            t.s[NC + 2] = Seg{dr + o[2], ctx->r_flags.as<uint8_t>() + a, (uint64_t)m};
+            hipLaunchKernelGGL(pipe_place_kernel, dim3(64, NC + 3), dim3(256), 0, ctx->stream, t);
+            UGVC_HIP(hipGetLastError());
+            UGVC_HIP(hipEventRecord(ev_placed(c), ctx->stream));
+        }
+        issued = c + 1;
+        mark(c, "issued");
+        // ---- while the chunk is in flight the pool packs the next one and hands an earlier one's results to the caller
+        job_pack = c + 1 < K ? c + 1 : -1;
+        job_out = c >= 2 ? c - 2 : -1;
+        if (job_pack >= NS) UGVC_HIP(hipEventSynchronize(ev_in(job_pack - NS)));   // the DMA out of that pinned slot has finished
+        if (job_out >= 0) UGVC_HIP(hipEventSynchronize(ev_out(job_out)));
+        mark(c, "job_start");
+        if (job_pack >= 0 || job_out >= 0) pool.parallel_for(2 * T, job);
+        mark(c, "job_end");
     }
     if (bad_row.load() != INT64_MAX || rc) {
         (void)hipStreamSynchronize(ps->h2d);
@@ -386,19 +410,30 @@ int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_
         if (rc) return -1;
         ctx->n = 0;
         ctx->scored = 0;
-        const int64_t i = bad_row.load();
-        switch (bad_what.load()) {
-            case 1: return fail("contig index out of range at row " + std::to_string(i));
-            case 2: return fail("empty allele at row " + std::to_string(i));
-            case 3: return fail("allele offset outside the pool at row " + std::to_string(i));
-            case 4: return fail("POS must be >= 1 at row " + std::to_string(i));
-            default: return fail("variants must be sorted by (contig, pos); row " + std::to_string(i));
-        }
+        // (name the row again on this thread: two pieces may have reported different rows at the same time)
+        int64_t i = bad_row.load(), ind = 0, row = i;
+        const int what = validate_rows(v, i, i + 1, n_contigs, &ind, &row);
+        return fail(std::string(row_error_text(what ? what : bad_what.load())) + std::to_string(i));
     }
-    while (copied_out < K)
-        if (copy_out(copied_out++)) return -1;
+    mark(K, "loop_end");
+    for (int c = std::max(0, issued - 2); c < issued; ++c) {
+        UGVC_HIP(hipEventSynchronize(ev_out(c)));
+        mark(c, "out_copy");
+        pool.parallel_for(T, [&](int t) { out_piece(c, t); });
+    }
     UGVC_HIP(hipStreamSynchronize(ps->h2d));
     UGVC_HIP(hipStreamSynchronize(ctx->stream));
+    mark(K, "done");
+    if (trace) {
+        for (const HostMark& m : marks) fprintf(stderr, "[pipe] host chunk %d %s %.3f\n", m.chunk, m.what, m.ms);
+        const char* names[4] = {"h2d_done", "pass_done", "d2h_done", "placed"};
+        for (int c = 0; c < K; ++c)
+            for (int q = 0; q < 4; ++q) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, ps->ev_t0, ps->ev[(size_t)(4 * c + q)]) == hipSuccess)
+                    fprintf(stderr, "[pipe] dev chunk %d %s %.3f\n", c, names[q], ms);
+            }
+    }
     ctx->n = n;
     ctx->n_indel = n_indel_total;
     ctx->scored = 1;

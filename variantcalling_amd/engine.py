@@ -287,10 +287,18 @@ class Engine:
         res = S.FilterResult(np.zeros(n, np.float32), np.zeros(n, np.uint8), np.zeros(n, np.uint8))
         return res, CResults(_p(res.tree_score, _f32p), _p(res.filter, _u8p), _p(res.flags, _u8p))
 
-    def filter_variants(self, vt: S.VariantTable) -> S.FilterResult:
-        """featurize -> lookup -> score -> FILTER for one table (H2D + kernel + D2H)."""
+    def filter_variants(self, vt: S.VariantTable, out: S.FilterResult | None = None) -> S.FilterResult:
+        """featurize -> lookup -> score -> FILTER for one table (H2D + kernel + D2H).  `out`: result arrays of the caller
+        (C-contiguous f32 / u8 / u8 of vt.n rows) to fill instead of fresh ones - a caller that scores callset after
+        callset keeps them: three fresh arrays are 30 MB of first-touch page faults per 5 M variants."""
         cv = self._cvariants(vt)
-        res, cr = self._alloc_results(vt.n)
+        if out is None:
+            res, cr = self._alloc_results(vt.n)
+        else:
+            for a, dt in ((out.tree_score, np.float32), (out.filter, np.uint8), (out.flags, np.uint8)):
+                if a.dtype != dt or a.shape != (vt.n,) or not a.flags.c_contiguous or not a.flags.writeable:
+                    raise ValueError("out: need writable C-contiguous tree_score f32 / filter u8 / flags u8 arrays of vt.n rows")
+            res, cr = out, CResults(_p(out.tree_score, _f32p), _p(out.filter, _u8p), _p(out.flags, _u8p))
         self._check(self.lib.ugvc_filter_variants(self._h, C.byref(cv), C.byref(cr)))
         self.n = vt.n
         return res
