@@ -225,15 +225,19 @@ int launch_pileup(ugvc_ctx* ctx) {
 // SEC statistic: multinomial_likelihood / multinomial_likelihood_ratio
 // (/root/reference/ugvc/utils/stats_utils.py:31-70): add-one corrected frequencies,
 // pmf(x; n, p) = exp(lgamma(n+1) + sum_i (x_i log p_i - lgamma(x_i+1))).
+// (libm's lgamma inlines into hundreds of instructions per call site; four inlined copies put the kernel at the 128-register
+// cap with 80 spilled registers - one out-of-line copy, same arithmetic)
+__device__ __attribute__((noinline)) double lgamma_call(double v) { return lgamma(v); }
+
 __device__ __forceinline__ double log_multinomial_pmf(const int32_t* x, const int32_t* e, int k) {
     double tot = 0.0;
     int n = 0;
     for (int i = 0; i < k; ++i) { tot += (double)e[i] + 1.0; n += x[i]; }
-    double lp = lgamma((double)n + 1.0);
+    double lp = lgamma_call((double)n + 1.0);
     for (int i = 0; i < k; ++i) {
         const double p = ((double)e[i] + 1.0) / tot;
         if (x[i] > 0) lp += (double)x[i] * log(p);
-        lp -= lgamma((double)x[i] + 1.0);
+        lp -= lgamma_call((double)x[i] + 1.0);
     }
     return lp;
 }

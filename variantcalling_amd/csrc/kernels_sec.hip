@@ -21,6 +21,8 @@
 #include <stdlib.h>
 #include <vector>
 
+#include <type_traits>
+
 #include "ugvc_prims.hpp"
 
 namespace ugvc {
@@ -29,8 +31,13 @@ constexpr int kSecMaxK = 8;
 
 constexpr int kSecLgTab = 4096;                                   // log(m!) for m = 0..4096 (host std::lgamma), beyond: lgamma()
 
+// (libm's lgamma / log inline into hundreds of instructions and dozens of registers at every call site: out of line - they
+// are reached only by depths beyond the tables)
+__device__ __attribute__((noinline)) double sec_lgamma_slow(int m) { return lgamma((double)m + 1.0); }
+__device__ __attribute__((noinline)) double sec_log_slow(long long m) { return log((double)m); }
+
 __device__ __forceinline__ double sec_log_fact(const double* __restrict__ tab, int m) {
-    return m <= kSecLgTab ? tab[m] : lgamma((double)m + 1.0);
+    return m <= kSecLgTab ? tab[m] : sec_lgamma_slow(m);
 }
 
 // log pmf(x; n, p(e)) and log pmf(x; n, p(x)) of stats_utils.py:47-70 share lgamma(n+1) - sum lgamma(x_i+1): every
@@ -106,7 +113,7 @@ __global__ __launch_bounds__(256) void sec_apply_kernel(const uint16_t* __restri
 // sec_log_pmf2 with log(x_i + 1), log(e_i + 1) and the logs of the two totals from a table of log(m) (every argument is a
 // small integer): log((e + 1) / tot) = log(e + 1) - log(tot) up to f64 rounding - eight libm logs per call become loads
 __device__ __forceinline__ double sec_log_int(const double* __restrict__ tab, long long m) {
-    return m <= kSecLgTab ? tab[kSecLgTab + 1 + m] : log((double)m);
+    return m <= kSecLgTab ? tab[kSecLgTab + 1 + m] : sec_log_slow(m);
 }
 
 __device__ __forceinline__ void sec_log_pmf2_tab(const int* x, const int* e, int k, const double* __restrict__ tab, double& lp_e, double& lp_x) {
@@ -133,7 +140,6 @@ __device__ __forceinline__ void sec_log_pmf2_tab(const int* x, const int* e, int
 // step by the whole wave - happens once per wave; a tile whose calls run past the staged keys searches from the carried
 // rank in HBM.  (sec_apply_kernel stays as the checker of this one: UGVC_SEC_SIMPLE=1 selects it.)
 constexpr int kSecStage = 128;
-constexpr int kSecBlock = 1024;                                   // 16 waves; two workgroups per CU by LDS
 constexpr int kSecLdsTab = 2048;                                  // log(m!) and log(m) for m <= 2048 in LDS (2 x 16 KB)
 
 // Round 3: what the round-2 kernel spent its time on was the log tables - twelve 8-byte gathers per hit from a 64 KB
@@ -149,8 +155,12 @@ __device__ __forceinline__ double sec_li(const double* lt, const double* __restr
     return m <= kSecLdsTab ? lt[kSecLdsTab + 1 + m] : sec_log_int(tab, m);
 }
 
-template <bool WANT_RATIO>
-__global__ __launch_bounds__(kSecBlock) void sec_apply_tiles_kernel(const uint16_t* __restrict__ contig, const int32_t* __restrict__ pos,
+// exp(lp_e) / exp(lp_x): two f64 exponentials and a division hold ~60 vector registers - out of line, because the scoring
+// mode reaches it only for a log ratio within 1e-9 of the threshold or an underflowing pmf
+__device__ __attribute__((noinline)) double sec_exact_ratio(double lp_e, double lp_x) { return exp(lp_e) / exp(lp_x); }
+
+template <bool WANT_RATIO, int KT, int BLOCK>                     // KT: the number of count classes when it is 2, 3 or 4 (loops unroll, counts stay in registers); 0 = any k
+__global__ __launch_bounds__(BLOCK) void sec_apply_tiles_kernel(const uint16_t* __restrict__ contig, const int32_t* __restrict__ pos,
                                                                     const int32_t* __restrict__ dp, const int32_t* __restrict__ adr,
                                                                     const int32_t* __restrict__ ada, int64_t n,
                                                                     const uint64_t* __restrict__ keys, const int32_t* __restrict__ expected,
@@ -158,9 +168,9 @@ __global__ __launch_bounds__(kSecBlock) void sec_apply_tiles_kernel(const uint16
                                                                     double log_min, int scale, double* __restrict__ ratio,
                                                                     uint8_t* __restrict__ is_sec, uint8_t* __restrict__ flags, int tiles_per_wave) {
     __shared__ double lt[2 * (kSecLdsTab + 1)];
-    __shared__ uint64_t stage_all[kSecBlock / 64][kSecStage];
-    __shared__ uint2 queue_all[kSecBlock / 64][128];
-    for (int q = threadIdx.x; q <= kSecLdsTab; q += kSecBlock) {
+    __shared__ uint64_t stage_all[BLOCK / 64][kSecStage];
+    __shared__ uint2 queue_all[BLOCK / 64][128];
+    for (int q = threadIdx.x; q <= kSecLdsTab; q += BLOCK) {
         lt[q] = lg_tab[q];
         lt[kSecLdsTab + 1 + q] = lg_tab[kSecLgTab + 1 + q];
     }
@@ -168,7 +178,7 @@ __global__ __launch_bounds__(kSecBlock) void sec_apply_tiles_kernel(const uint16
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint64_t* stage = stage_all[wave];
     const int64_t n_tiles = (n + 63) >> 6;
-    const int64_t t0 = ((int64_t)blockIdx.x * (kSecBlock / 64) + wave) * tiles_per_wave;
+    const int64_t t0 = ((int64_t)blockIdx.x * (BLOCK / 64) + wave) * tiles_per_wave;
     const int64_t t1 = t0 + tiles_per_wave < n_tiles ? t0 + tiles_per_wave : n_tiles;
     if (t0 >= t1) return;
     auto key_of = [&](int64_t i) { return ((uint64_t)contig[i] << 32) | (uint32_t)pos[i]; };
@@ -199,26 +209,27 @@ __global__ __launch_bounds__(kSecBlock) void sec_apply_tiles_kernel(const uint16
     int qn = 0;                                                      // hits waiting in the wave's queue (< 64 between tiles)
     // one hit: observed counts of call q.x against the expected counts of database row q.y
     auto work = [&](uint2 q) {
+        const int kk = KT ? KT : k;
         const int64_t ci = (int64_t)q.x, l2 = (int64_t)q.y;
         int a[kSecMaxK], e[kSecMaxK];
         const int r0 = adr[ci] > 0 ? adr[ci] : 0, a0 = ada[ci] > 0 ? ada[ci] : 0;
         a[0] = r0;
         a[1] = a0;
-        if (k > 2) { const int o = dp[ci] - r0 - a0; a[2] = o > 0 ? o : 0; }
-        for (int c = 3; c < k; ++c) a[c] = 0;
+        if (kk > 2) { const int o = dp[ci] - r0 - a0; a[2] = o > 0 ? o : 0; }
+        for (int c = 3; c < kk; ++c) a[c] = 0;
         long long s = 0, na = 0;
-        for (int c = 0; c < k; ++c) { e[c] = expected[l2 * k + c]; s += e[c]; na += a[c]; }
+        for (int c = 0; c < kk; ++c) { e[c] = expected[l2 * kk + c]; s += e[c]; na += a[c]; }
         if (scale && s > 0) {
             const double f = (double)na / (double)s;              // stats_utils.py:24-27: np.round(table * (n / sum))
-            for (int c = 0; c < k; ++c) e[c] = (int)rint((double)e[c] * f);
+            for (int c = 0; c < kk; ++c) e[c] = (int)rint((double)e[c] * f);
         }
         // sec_log_pmf2_tab with the LDS tables
         long long tot_e = 0, tot_x = 0;
         int nn = 0;
-        for (int c = 0; c < k; ++c) { tot_e += (long long)e[c] + 1; tot_x += (long long)a[c] + 1; nn += a[c]; }
+        for (int c = 0; c < kk; ++c) { tot_e += (long long)e[c] + 1; tot_x += (long long)a[c] + 1; nn += a[c]; }
         const double lte = sec_li(lt, lg_tab, tot_e), ltx = sec_li(lt, lg_tab, tot_x);
         double g = sec_lf(lt, lg_tab, nn), se = 0.0, sx = 0.0;
-        for (int c = 0; c < k; ++c) {
+        for (int c = 0; c < kk; ++c) {
             if (a[c] > 0) {
                 se += (double)a[c] * (sec_li(lt, lg_tab, (long long)e[c] + 1) - lte);
                 sx += (double)a[c] * (sec_li(lt, lg_tab, (long long)a[c] + 1) - ltx);
@@ -230,7 +241,7 @@ __global__ __launch_bounds__(kSecBlock) void sec_apply_tiles_kernel(const uint16
         double r = 0.0;
         uint8_t hit;
         if (exact) {
-            r = exp(lp_e) / exp(lp_x);
+            r = WANT_RATIO ? exp(lp_e) / exp(lp_x) : sec_exact_ratio(lp_e, lp_x);
             hit = r >= min_ratio ? 1 : 0;
         } else hit = d >= log_min ? 1 : 0;
         if (WANT_RATIO && ratio) ratio[ci] = r;
@@ -239,62 +250,66 @@ __global__ __launch_bounds__(kSecBlock) void sec_apply_tiles_kernel(const uint16
     };
     uint64_t s0, s1;
     fetch(Lb, s0, s1);
-    for (int64_t t = t0; t < t1; ++t) {
-        const int64_t i = t * 64 + lane;
-        const bool valid = i < n;
-        const int64_t ii = valid ? i : n - 1;
-        const uint64_t key = key_of(ii);
-        const int last = (int)((n - t * 64 < 64 ? n - t * 64 : 64) - 1);
-        stage[lane] = s0;
-        stage[64 + lane] = s1;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const uint64_t key_max = __shfl(key, last);
-        int64_t l2;
-        bool found;
-        if (stage[kSecStage - 1] >= key_max) {                    // the staged keys reach the tile's last call
-            int p = -1;
+    // ONE call site of work(): the loop runs on past the last tile until the queue is empty (two inlined copies of the f64
+    // arithmetic - one in the loop, one for the flush - cost 100 spilled vector registers at the 128-register cap)
+    for (int64_t t = t0; t < t1 || qn > 0; ++t) {
+        if (t < t1) {
+            const int64_t i = t * 64 + lane;
+            const bool valid = i < n;
+            const int64_t ii = valid ? i : n - 1;
+            const uint64_t key = key_of(ii);
+            const int last = (int)((n - t * 64 < 64 ? n - t * 64 : 64) - 1);
+            stage[lane] = s0;
+            stage[64 + lane] = s1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint64_t key_max = __shfl(key, last);
+            int64_t l2;
+            bool found;
+            if (stage[kSecStage - 1] >= key_max) {                    // the staged keys reach the tile's last call
+                int p = -1;
 #pragma unroll
-            for (int sb = 64; sb >= 1; sb >>= 1) p = stage[p + sb] < key ? p + sb : p;
-            const int r = p + 1;                                   // staged keys below this call's key
-            l2 = Lb + r;
-            found = stage[r] == key;
-        } else {
-            int64_t b = Lb, len = n_db - Lb;
-            while (len > 0) {
-                const int64_t half = len >> 1;
-                if (keys[b + half] < key) { b += half + 1; len -= half + 1; }
-                else len = half;
+                for (int sb = 64; sb >= 1; sb >>= 1) p = stage[p + sb] < key ? p + sb : p;
+                const int r = p + 1;                                   // staged keys below this call's key
+                l2 = Lb + r;
+                found = stage[r] == key;
+            } else {
+                int64_t b = Lb, len = n_db - Lb;
+                while (len > 0) {
+                    const int64_t half = len >> 1;
+                    if (keys[b + half] < key) { b += half + 1; len -= half + 1; }
+                    else len = half;
+                }
+                l2 = b;
+                found = l2 < n_db && keys[l2] == key;
             }
-            l2 = b;
-            found = l2 < n_db && keys[l2] == key;
+            __builtin_amdgcn_wave_barrier();
+            Lb = __shfl(l2, last);
+            if (t + 1 < t1) fetch(Lb, s0, s1);                          // in flight during this tile's arithmetic
+            // calls off the database: their outputs now; hits go to the wave's queue and are worked on 64 at a time - ~40 % of
+            // the lanes hit in every tile, so the f64 arithmetic below used to run for every wave with 60 % of its lanes idle
+            const bool go = found && valid;
+            if (valid && !go) {
+                if (WANT_RATIO && ratio) ratio[i] = __longlong_as_double(0x7ff8000000000000ll);
+                if (is_sec) is_sec[i] = 0;
+            }
+            const unsigned long long gm = __builtin_amdgcn_ballot_w64(go);
+            if (go) queue[qn + (int)__popcll(gm & ((1ull << lane) - 1))] = make_uint2((uint32_t)i, (uint32_t)l2);
+            qn += (int)__popcll(gm);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
-        Lb = __shfl(l2, last);
-        if (t + 1 < t1) fetch(Lb, s0, s1);                          // in flight during this tile's arithmetic
-        // calls off the database: their outputs now; hits go to the wave's queue and are worked on 64 at a time - ~40 % of
-        // the lanes hit in every tile, so the f64 arithmetic below used to run for every wave with 60 % of its lanes idle
-        const bool go = found && valid;
-        if (valid && !go) {
-            if (WANT_RATIO && ratio) ratio[i] = __longlong_as_double(0x7ff8000000000000ll);
-            if (is_sec) is_sec[i] = 0;
-        }
-        const unsigned long long gm = __builtin_amdgcn_ballot_w64(go);
-        if (go) queue[qn + (int)__popcll(gm & ((1ull << lane) - 1))] = make_uint2((uint32_t)i, (uint32_t)l2);
-        qn += (int)__popcll(gm);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (qn >= 64) {
-            work(queue[lane]);
+        if (qn >= 64 || (t + 1 >= t1 && qn > 0)) {
+            const int take = qn < 64 ? qn : 64;
+            if (lane < take) work(queue[lane]);
             const uint2 rest = queue[64 + lane];
             __builtin_amdgcn_wave_barrier();
             queue[lane] = rest;
-            qn -= 64;
+            qn -= take;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
     }
-    if (qn > 0 && lane < qn) work(queue[lane]);
 }
 
 __global__ void sec_iota_kernel(uint32_t* idx, int64_t n) {
@@ -436,13 +451,28 @@ int ugvc_sec_apply(ugvc_ctx* ctx, double min_ratio, int scale_expected, int mark
         } else {
             // consecutive tiles per wave: enough waves for 8 per SIMD on every CU
             const int64_t n_tiles = (n + 63) / 64;
-            const int64_t want_waves = (int64_t)ctx->n_cus * 32;
+            // workgroups of 512 threads: three per CU by LDS (49 KB each) and by registers (<= 80), and as many waves as are
+            // resident at once - one round, every wave the same number of tiles (UGVC_SEC_BLOCK / UGVC_SEC_WAVES: profiling)
+            const int blk = getenv("UGVC_SEC_BLOCK") ? atoi(getenv("UGVC_SEC_BLOCK")) : 512;
+            const int wpc = getenv("UGVC_SEC_WAVES") ? atoi(getenv("UGVC_SEC_WAVES")) : 24;
+            const int block = blk == 1024 ? 1024 : blk == 256 ? 256 : 512;
+            const int64_t want_waves = (int64_t)ctx->n_cus * std::max(wpc, 1);
             const int tpw = (int)std::max<int64_t>((n_tiles + want_waves - 1) / want_waves, 1);
             const int64_t n_waves = (n_tiles + tpw - 1) / tpw;
-            const unsigned grid = (unsigned)((n_waves + kSecBlock / 64 - 1) / (kSecBlock / 64));
+            const unsigned grid = (unsigned)((n_waves + block / 64 - 1) / (block / 64));
             const double log_min = min_ratio > 0.0 ? std::log(min_ratio) : -1e300;
-            auto kern = ratio ? sec_apply_tiles_kernel<true> : sec_apply_tiles_kernel<false>;
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(kSecBlock), 0, ctx->stream, ctx->v_contig.as<uint16_t>(),
+            auto pick_k = [&](auto want, auto bl) {
+                constexpr bool W = decltype(want)::value;
+                constexpr int B = decltype(bl)::value;
+                return ctx->sec_k == 2 ? sec_apply_tiles_kernel<W, 2, B> : ctx->sec_k == 3 ? sec_apply_tiles_kernel<W, 3, B>
+                     : ctx->sec_k == 4 ? sec_apply_tiles_kernel<W, 4, B> : sec_apply_tiles_kernel<W, 0, B>;
+            };
+            auto pick = [&](auto want) {
+                return block == 1024 ? pick_k(want, std::integral_constant<int, 1024>{})
+                     : block == 256 ? pick_k(want, std::integral_constant<int, 256>{}) : pick_k(want, std::integral_constant<int, 512>{});
+            };
+            auto kern = ratio ? pick(std::true_type{}) : pick(std::false_type{});
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, ctx->stream, ctx->v_contig.as<uint16_t>(),
                                ctx->v_pos.as<int32_t>(), ctx->v_dp.as<int32_t>(), ctx->v_adr.as<int32_t>(), ctx->v_ada.as<int32_t>(), n,
                                ctx->sec_keys.as<uint64_t>(), ctx->sec_exp.as<int32_t>(), ctx->sec_lgtab.as<double>(), ctx->n_sec, ctx->sec_k,
                                min_ratio, log_min, scale_expected, ratio ? d_r.as<double>() : nullptr, is_sec ? d_s.as<uint8_t>() : nullptr,
