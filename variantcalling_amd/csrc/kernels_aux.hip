@@ -91,23 +91,30 @@ __device__ __forceinline__ void pl_walk(Src src, Idx k0, Idx k1, Idx step, PlAcc
 // dword read), the (allele, strand) class counted one-hot in ONE 64-bit word of eight 8-bit fields (a 64-bit shift
 // and add instead of two selected 32-bit adds), flushed every 254 observations.
 __device__ __forceinline__ void pl_walk_staged(const uint16_t* stage, int k0, int k1, PlAcc& acc) {
-    auto one = [&](uint32_t o, unsigned long long& c8) {
-        c8 += 1ull << ((o & 7u) << 3);
-        const int a = (int)(o & 3u), bq = (int)(o >> 3);
-        acc.bq0 += a == 0 ? bq : 0;
-        acc.bq1 += a == 1 ? bq : 0;
+    // one observation given its class (allele | strand << 2) and base quality.  Round 3: the base-quality sums take their
+    // 0 / 1 factors from the one-hot word itself (bit 0 of lo | hi <=> allele 0, bit 8 <=> allele 1) and a multiply-add
+    // each, instead of two compares + two selects + two adds; the pair of a dword is taken apart with bit-field
+    // extracts instead of being split first (~11 vector instructions an observation, 14 before).
+    auto one = [&](uint32_t cls, uint32_t bq, unsigned long long& c8) {
+        const unsigned long long t = 1ull << (cls << 3);
+        c8 += t;
+        const uint32_t u = (uint32_t)t | (uint32_t)(t >> 32);
+        // (written as instructions: the compiler turns a multiplication by a 0 / 1 value back into compare + select)
+        const uint32_t is0 = u & 1u, is1 = __builtin_amdgcn_ubfe(u, 8, 1);
+        asm("v_mad_u32_u24 %0, %1, %2, %0" : "+v"(acc.bq0) : "v"(bq), "v"(is0));           // bq < 2^13
+        asm("v_mad_u32_u24 %0, %1, %2, %0" : "+v"(acc.bq1) : "v"(bq), "v"(is1));
     };
     int k = k0;
     while (k < k1) {
         unsigned long long c8 = 0;
         const int stop = k + 254 < k1 ? k + 254 : k1;
-        if ((k & 1) && k < stop) { one(stage[k], c8); ++k; }
+        if ((k & 1) && k < stop) { const uint32_t o = stage[k]; one(o & 7u, o >> 3, c8); ++k; }
         for (; k + 2 <= stop; k += 2) {
             const uint32_t w = *reinterpret_cast<const uint32_t*>(stage + k);
-            one(w & 0xFFFFu, c8);
-            one(w >> 16, c8);
+            one(w & 7u, __builtin_amdgcn_ubfe(w, 3, 13), c8);
+            one(__builtin_amdgcn_ubfe(w, 16, 3), w >> 19, c8);
         }
-        if (k < stop) { one(stage[k], c8); ++k; }
+        if (k < stop) { const uint32_t o = stage[k]; one(o & 7u, o >> 3, c8); ++k; }
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             acc.cf[a] += (int)((c8 >> (8 * a)) & 0xff);
