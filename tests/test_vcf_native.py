@@ -197,6 +197,30 @@ def test_block_boundaries_follow_the_python_writer(tmp_path):
     assert sizes[-1] == 0 and all(s == 65280 for s in sizes[:-2]) and 0 < sizes[-2] <= 65280
 
 
+@pytest.mark.parametrize("batch", [1, 7, 1000, 19_999, 20_000])
+def test_writer_batch_seams(tmp_path, monkeypatch, batch):
+    """The writer formats records in batches (2 M records; UGVC_VCF_WRITE_BATCH for this test) and carries the unfinished
+    BGZF block from one batch into the next: file and index are the same bytes for any batch size, gz and plain."""
+    line = b"chr1\t%d\t.\tA\tC\t1\t.\tK=" + b"x" * 30 + b"\n"
+    p = str(tmp_path / "m.vcf")
+    with open(p, "wb") as fh:
+        fh.write(b"##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n")
+        for k in range(20_000):
+            fh.write(line % (k + 1))
+    b = nv.read_vcf(p, ["chr1"])
+    n = b.table.n
+    rng = np.random.default_rng(3)
+    res = S.FilterResult(rng.random(n).astype(np.float32), (rng.random(n) < 0.5).astype(np.uint8), rng.integers(0, 8, n).astype(np.uint8))
+    monkeypatch.delenv("UGVC_VCF_WRITE_BATCH", raising=False)
+    for ext in (".vcf.gz", ".vcf"):
+        nv.write_filtered_vcf(str(tmp_path / ("whole" + ext)), b, res, n_threads=4)
+    monkeypatch.setenv("UGVC_VCF_WRITE_BATCH", str(batch))
+    for ext in (".vcf.gz", ".vcf"):
+        nv.write_filtered_vcf(str(tmp_path / ("cut" + ext)), b, res, n_threads=4)
+        assert open(str(tmp_path / ("cut" + ext)), "rb").read() == open(str(tmp_path / ("whole" + ext)), "rb").read()
+    assert open(str(tmp_path / "cut.vcf.gz.tbi"), "rb").read() == open(str(tmp_path / "whole.vcf.gz.tbi"), "rb").read()
+
+
 def test_fasta_reader_matches_the_python_reference(tmp_path):
     from variantcalling_amd.io import fasta
     text = (">chr1 first record description\nACGTNacgtn\nRYKM\n\n>chr2\r\nAC\r\nGT\r\n>empty\n>chrM\tmito\nTTTT")

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <atomic>
 #include <charconv>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -28,6 +29,20 @@ int fail(std::string m) {
     g_err = std::move(m);
     return -1;
 }
+
+// UGVC_VCF_TRACE=1: seconds per stage of the reader / writer on stderr
+struct StageTimer {
+    bool on = getenv("UGVC_VCF_TRACE") != nullptr;
+    const char* who;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    explicit StageTimer(const char* w) : who(w) {}
+    void lap(const char* what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[vcf] %s %-28s %.4f s\n", who, what, std::chrono::duration<double>(now - t).count());
+        t = now;
+    }
+};
 
 int pick_threads(int n_threads) {
     if (n_threads > 0) return std::min(n_threads, 256);
@@ -541,10 +556,29 @@ int bgzf_write_all(const std::string& data, const std::string& path) {
     return ok ? 0 : fail(path + ": write failed");
 }
 
+// INFO/END of a record (symbolic alleles): "END=" at the start of INFO [q, ie) or after a ';'; -1 when absent
+inline int64_t info_end_of(const char* q, const char* ie) {
+    for (const char* p = q; p + 4 <= ie;) {
+        if (memcmp(p, "END=", 4) == 0 && (p == q || p[-1] == ';')) {
+            int64_t v = 0;
+            const char* d = p + 4;
+            bool any = false;
+            while (d < ie && *d >= '0' && *d <= '9') { v = v * 10 + (*d - '0'); ++d; any = true; }
+            return any ? v : -1;
+        }
+        const char* nx = static_cast<const char*>(memchr(p, ';', (size_t)(ie - p)));
+        if (!nx) break;
+        p = nx + 1;
+    }
+    return -1;
+}
+
+// `info_end`: INFO/END per record in file order (-1: none), found by the writer's formatting threads while they had the
+// INFO field at hand - the index pass itself is one light serial loop (it re-read every record's text before: 0.27 s of a
+// 5 M-record write-back on one thread)
 int write_tbi(const ugvc_vcf* h, const char* out_path, const std::vector<int64_t>& row_of, const std::vector<uint32_t>& out_len,
-              size_t header_len, const std::vector<uint32_t>& blk_clen, int /*threads*/) {
+              const std::vector<int64_t>& info_end, size_t header_len, const std::vector<uint32_t>& blk_clen, int /*threads*/) {
     const int64_t n = h->n;
-    const char* base = h->text.data();
     constexpr uint64_t kBlk = 65280;
     std::vector<uint64_t> coff(blk_clen.size() + 1, 0);
     for (size_t b = 0; b < blk_clen.size(); ++b) coff[b + 1] = coff[b] + blk_clen[b];
@@ -564,29 +598,7 @@ int write_tbi(const ugvc_vcf* h, const char* out_path, const std::vector<int64_t
         const int c = h->contig[k];
         const int64_t beg = (int64_t)h->pos[k] - 1;
         int64_t end = beg + h->ref_len[k];
-        {   // INFO/END (symbolic alleles): "END=" at the start of INFO or after a ';'
-            const Span ln = h->rec_lines[(size_t)j];
-            const char* s = base + ln.off;
-            const char* e = s + ln.len;
-            int tabs = 0;
-            const char* q = s;
-            while (q < e && tabs < 7) { if (*q == '\t') ++tabs; ++q; }
-            const char* ie = static_cast<const char*>(memchr(q, '\t', (size_t)(e - q)));
-            if (!ie) ie = e;
-            for (const char* p = q; p + 4 <= ie;) {
-                if (memcmp(p, "END=", 4) == 0 && (p == q || p[-1] == ';')) {
-                    int64_t v = 0;
-                    const char* d = p + 4;
-                    bool any = false;
-                    while (d < ie && *d >= '0' && *d <= '9') { v = v * 10 + (*d - '0'); ++d; any = true; }
-                    if (any && v > beg) end = v;
-                    break;
-                }
-                const char* nx = static_cast<const char*>(memchr(p, ';', (size_t)(ie - p)));
-                if (!nx) break;
-                p = nx + 1;
-            }
-        }
+        if (info_end[(size_t)j] > beg) end = info_end[(size_t)j];
         if (beg < 0) return 1;
         if (c != cur_c) {
             if (tid_of[(size_t)c] >= 0) return 1;                 // contig seen before: not grouped, tabix would refuse
@@ -662,7 +674,9 @@ int ugvc_vcf_read(const char* path, const char* const* contig_names, int n_conti
     const int threads = pick_threads(n_threads);
     std::unique_ptr<ugvc_vcf> h(new ugvc_vcf());
     h->path = path;
+    StageTimer st("read");
     if (load_text(path, threads, h->text)) return -1;
+    st.lap("load + inflate");
     const char* base = h->text.data();
     const int64_t tn = (int64_t)h->text.size();
 
@@ -707,6 +721,7 @@ int ugvc_vcf_read(const char* path, const char* const* contig_names, int n_conti
     }
     const int64_t n = (int64_t)h->rec_lines.size();
     h->n = n;
+    st.lap("lines");
 
     // ---- tokenise (file order)
     std::unordered_map<std::string_view, int> contig_idx;
@@ -730,6 +745,7 @@ int ugvc_vcf_read(const char* path, const char* const* contig_names, int n_conti
         if (err_at[(size_t)p] != INT64_MAX) return fail(errs[(size_t)p]);     // parts are in file order: first error first
     if (is_mutect)
         for (int64_t k = 0; k < n; ++k) P.qual[(size_t)k] = 10.0f * P.tlod[(size_t)k];
+    st.lap("tokenise");
 
     // ---- stable order by (contig, pos)
     h->order.resize((size_t)n);
@@ -740,6 +756,7 @@ int ugvc_vcf_read(const char* path, const char* const* contig_names, int n_conti
     if (!std::is_sorted(key.begin(), key.end()))
         std::stable_sort(h->order.begin(), h->order.end(), [&](int64_t a, int64_t b) { return key[(size_t)a] < key[(size_t)b]; });
     std::vector<uint64_t>().swap(key);
+    st.lap("order");
 
     // ---- table columns
     h->contig.resize((size_t)n); h->gq.resize((size_t)n); h->gt.resize((size_t)n); h->has_id.resize((size_t)n);
@@ -758,6 +775,7 @@ int ugvc_vcf_read(const char* path, const char* const* contig_names, int n_conti
     }
     if (tot > 0xFFFFFFFFull) return fail(h->path + ": allele pool exceeds 4 GiB");
     h->alleles.resize((size_t)tot);
+    st.lap("allocate + allele offsets");
     uint8_t code[256];
     memset(code, 0, sizeof code);
     code['A'] = code['a'] = 1; code['C'] = code['c'] = 2; code['G'] = code['g'] = 3; code['T'] = code['t'] = 4;
@@ -778,6 +796,7 @@ int ugvc_vcf_read(const char* path, const char* const* contig_names, int n_conti
             for (int32_t q = 0; q < P.alt[j].len; ++q) d[q] = code[a[q]];
         }
     });
+    st.lap("columns");
     *out = h.release();
     return 0;
 }
@@ -839,33 +858,36 @@ int ugvc_vcf_write_filtered(const ugvc_vcf* h, const char* out_path, const float
         }
         for (auto& l : chrom) { stream.append(l); stream.push_back('\n'); }
     }
+    StageTimer st("write");
     std::vector<int64_t> row_of((size_t)n);
     for (int64_t k = 0; k < n; ++k) row_of[(size_t)h->order[(size_t)k]] = k;
+    st.lap("header + row map");
 
     bool io_ok = true;
     std::vector<uint32_t> blk_clen;                          // compressed size of every data block, file order
     std::vector<uint32_t> out_len((size_t)n);                // bytes of every output record line (with its newline)
+    std::vector<int64_t> info_end(gz && write_index ? (size_t)n : 0, -1);   // INFO/END per record, for the index
     const size_t header_len = stream.size();
     static const unsigned char kEof[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0,
                                            0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     constexpr size_t kBlk = 65280;
-    auto flush_blocks = [&](bool final) {                    // emit every full block of `stream` (all of it when final)
+    // emit every full 65280-byte block of data[0, size) (all of it when final); returns the bytes consumed
+    auto flush_blocks = [&](const char* data, size_t size, bool final) -> size_t {
         if (!gz) {
-            if (!stream.empty() && fwrite(stream.data(), 1, stream.size(), fh) != stream.size()) io_ok = false;
-            stream.clear();
-            return;
+            if (size && fwrite(data, 1, size, fh) != size) io_ok = false;
+            return size;
         }
-        const size_t nb = final ? (stream.size() + kBlk - 1) / kBlk : stream.size() / kBlk;
+        const size_t nb = final ? (size + kBlk - 1) / kBlk : size / kBlk;
         std::vector<std::string> comp(nb);
         std::atomic<int> bad{0};
         parallel_items((int64_t)nb, threads, [&](int64_t b) {
-            const size_t lo = (size_t)b * kBlk, len = std::min(kBlk, stream.size() - lo);
+            const size_t lo = (size_t)b * kBlk, len = std::min(kBlk, size - lo);
             z_stream zs;
             memset(&zs, 0, sizeof zs);
             if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { bad = 1; return; }
             std::string& o = comp[(size_t)b];
             o.resize(18 + deflateBound(&zs, (uLong)len) + 8);
-            zs.next_in = reinterpret_cast<unsigned char*>(const_cast<char*>(stream.data() + lo));
+            zs.next_in = reinterpret_cast<unsigned char*>(const_cast<char*>(data + lo));
             zs.avail_in = (uInt)len;
             zs.next_out = reinterpret_cast<unsigned char*>(&o[18]);
             zs.avail_out = (uInt)(o.size() - 26);
@@ -877,21 +899,24 @@ int ugvc_vcf_write_filtered(const ugvc_vcf* h, const char* out_path, const float
             memcpy(&o[0], hd, 16);
             const uint32_t bsize = (uint32_t)(clen + 25);
             o[16] = (char)(bsize & 0xff); o[17] = (char)(bsize >> 8);
-            const uint32_t crc = (uint32_t)crc32(0L, reinterpret_cast<const unsigned char*>(stream.data() + lo), (uInt)len);
+            const uint32_t crc = (uint32_t)crc32(0L, reinterpret_cast<const unsigned char*>(data + lo), (uInt)len);
             unsigned char* t = reinterpret_cast<unsigned char*>(&o[18 + clen]);
             for (int i = 0; i < 4; ++i) { t[i] = (unsigned char)(crc >> (8 * i)); t[4 + i] = (unsigned char)((uint32_t)len >> (8 * i)); }
             o.resize(18 + clen + 8);
         });
-        if (bad) { io_ok = false; return; }
+        if (bad) { io_ok = false; return 0; }
         for (auto& o : comp) {
             if (fwrite(o.data(), 1, o.size(), fh) != o.size()) io_ok = false;
             blk_clen.push_back((uint32_t)o.size());
         }
-        stream.erase(0, std::min(stream.size(), nb * kBlk));
+        return std::min(size, nb * kBlk);
     };
 
     // ---- records, in batches of file-order ranges
-    const int64_t batch = 1 << 18;
+    // (batches of 2 M records, ~360 MB of text: every batch starts its threads twice - 19 batches of 256 k records with 256
+    // threads each were ~10 000 thread starts, a third of the writer's time)
+    int64_t batch = 1 << 21;
+    if (const char* e = getenv("UGVC_VCF_WRITE_BATCH")) batch = std::max<int64_t>(1, atoll(e));      // (tests: batch seams on small files)
     for (int64_t b0 = 0; b0 < n && io_ok; b0 += batch) {
         const int64_t b1 = std::min(n, b0 + batch);
         const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(threads, (b1 - b0) / 1024));
@@ -919,6 +944,7 @@ int ugvc_vcf_write_filtered(const ugvc_vcf* h, const char* out_path, const float
                 const char* f6 = tab[5] + 1;
                 const char* f7 = tab[6] + 1;
                 const char* f7e = nt >= 8 ? tab[7] : e;
+                if (!info_end.empty()) info_end[(size_t)j] = info_end_of(f7, f7e);
                 o.append(s, (size_t)(f6 - s));
                 const unsigned fl = flags[k];
                 bool any = false;
@@ -955,14 +981,34 @@ int ugvc_vcf_write_filtered(const ugvc_vcf* h, const char* out_path, const float
                 out_len[(size_t)j] = (uint32_t)(o.size() - o_before);
             }
         });
-        for (auto& p : part) stream.append(p);
-        flush_blocks(false);
+        // what is left of the previous batch (less than a block) and the parts go to their places in ONE uninitialised
+        // buffer, in parallel (a serial append of ~45 MB per batch was a fifth of the writer's time at 5 M records;
+        // std::string::resize would zero-fill the buffer first)
+        st.lap("format");
+        std::vector<size_t> at((size_t)parts + 1, stream.size());
+        for (int p = 0; p < parts; ++p) at[(size_t)p + 1] = at[(size_t)p] + part[(size_t)p].size();
+        const size_t total = at[(size_t)parts];
+        std::unique_ptr<char[]> buf(new char[total ? total : 1]);
+        memcpy(buf.get(), stream.data(), stream.size());
+        char* dst = buf.get();
+        parallel_ranges(parts, std::min(parts, threads), [&](int, int64_t lo, int64_t hi) {
+            for (int64_t p = lo; p < hi; ++p) memcpy(dst + at[(size_t)p], part[(size_t)p].data(), part[(size_t)p].size());
+        });
+        st.lap("gather parts");
+        const size_t used = flush_blocks(buf.get(), total, false);
+        stream.assign(buf.get() + used, total - used);
+        st.lap("deflate + write");
     }
-    if (io_ok) flush_blocks(true);
+    if (io_ok) (void)flush_blocks(stream.data(), stream.size(), true);
     if (io_ok && gz && fwrite(kEof, 1, 28, fh) != 28) io_ok = false;
     if (fclose(fh) != 0) io_ok = false;
     if (!io_ok) return fail(std::string(out_path) + ": write failed");
-    if (gz && write_index) return write_tbi(h, out_path, row_of, out_len, header_len, blk_clen, threads);
+    st.lap("tail + close");
+    if (gz && write_index) {
+        const int rc = write_tbi(h, out_path, row_of, out_len, info_end, header_len, blk_clen, threads);
+        st.lap("tabix index");
+        return rc;
+    }
     return 0;
 }
 
