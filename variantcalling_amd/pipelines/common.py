@@ -3,6 +3,7 @@ configure one GPU context.  Host logic only; the compute is `engine.Engine` (lib
 from __future__ import annotations
 
 import logging
+import os
 
 import numpy as np
 
@@ -12,20 +13,39 @@ from ..io import bed
 logger = logging.getLogger("ugvc")
 
 
-def load_side_tables(reference_file, runs_file, annotate_intervals, blacklist_file):
+def load_side_tables(reference_file, runs_file, annotate_intervals, blacklist_file, also=None):
+    """Reference, homopolymer runs, annotation tracks, blacklist - read CONCURRENTLY (the native readers release the GIL;
+    each is threaded itself, but none keeps a large host busy alone: FASTA encode, four interval files and a 100 MB BGZF are
+    0.3-0.6 s one after the other).  The interval files need the contig names: with a `.fai` beside the FASTA they start at
+    once, otherwise when the FASTA has been read.  `also`: {name: f(contig_names)} extra readers that need only the names
+    (the callset VCF of filter_variants_pipeline) - their results come back as a dict in fifth place."""
+    from concurrent.futures import ThreadPoolExecutor
     from ..io import vcf_native                        # threaded native readers (libugvc_vcf.so); io.fasta / io.bed are their references
-    ref = vcf_native.read_fasta(reference_file)
-    if ref.n_contigs > 65535:
-        # the contig column is u16; production hg38 has 3 366 contigs
-        # (test/resources/unit/vcfbed/test_vcftools/header.txt), nothing is dropped below this bound
-        raise ValueError(f"{reference_file}: {ref.n_contigs} contigs; the engine indexes at most 65535")
-    # homopolymer runs are disjoint by nature; book-ended runs of different bases must stay separate
-    runs = vcf_native.read_intervals(runs_file, ref.names, merge=False) if runs_file else None
-    tracks = [vcf_native.read_intervals(p, ref.names, merge=True) for p in (annotate_intervals or [])]
-    if len(tracks) > S.MAX_TRACKS:
+    if len(annotate_intervals or []) > S.MAX_TRACKS:
         raise ValueError(f"at most {S.MAX_TRACKS} --annotate_intervals files are supported")
-    bl = bed.read_blacklist(blacklist_file, ref.names) if blacklist_file else None
-    return ref, runs, tracks, bl
+    also = also or {}
+    with ThreadPoolExecutor(max_workers=8) as pool:
+        f_ref = pool.submit(vcf_native.read_fasta, reference_file)
+        names = vcf_native.read_fasta_names(reference_file) if os.path.exists(reference_file + ".fai") else None
+        if names is None:
+            names = f_ref.result().names
+        # homopolymer runs are disjoint by nature; book-ended runs of different bases must stay separate
+        f_runs = pool.submit(vcf_native.read_intervals, runs_file, names, False) if runs_file else None
+        f_tracks = [pool.submit(vcf_native.read_intervals, p, names, True) for p in (annotate_intervals or [])]
+        f_bl = pool.submit(bed.read_blacklist, blacklist_file, names) if blacklist_file else None
+        f_also = {k: pool.submit(f, names) for k, f in also.items()}
+        ref = f_ref.result()
+        if list(ref.names) != list(names):
+            raise ValueError(f"{reference_file}.fai does not list the contigs of {reference_file}")
+        if ref.n_contigs > 65535:
+            # the contig column is u16; production hg38 has 3 366 contigs
+            # (test/resources/unit/vcfbed/test_vcftools/header.txt), nothing is dropped below this bound
+            raise ValueError(f"{reference_file}: {ref.n_contigs} contigs; the engine indexes at most 65535")
+        runs = f_runs.result() if f_runs else None
+        tracks = [f.result() for f in f_tracks]
+        bl = f_bl.result() if f_bl else None
+        extra = {k: f.result() for k, f in f_also.items()}
+    return (ref, runs, tracks, bl, extra) if also else (ref, runs, tracks, bl)
 
 
 def cg_insertion_mask(vt: S.VariantTable) -> np.ndarray:

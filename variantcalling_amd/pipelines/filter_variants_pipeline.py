@@ -65,20 +65,33 @@ def run(argv: list[str]):
     grp = dist.Group()
     device = args.device if grp.world == 1 else grp.local_rank
     n_threads = 0 if grp.world == 1 else max(1, (os.cpu_count() or 1) // max(grp.local_world, 1))
-    logger.info("reading side tables")
-    ref, runs, tracks, bl = common.load_side_tables(args.reference_file, args.runs_file, args.annotate_intervals,
-                                                    args.blacklist)
-    # an estimator fitted on a named frame finds its interval columns by BED stem (`LCR-hs38`, `exome.twist`, ...)
-    forests = model_io.load_model_file(args.model_file, args.model_name, track_names=[t.name for t in tracks])
-    common.check_model_tracks(forests, len(tracks), "filter_variants_pipeline")
-    lap("side tables + model")
-    logger.info("reading %s", args.input_file)
-    vcf = vcfio.read_vcf(args.input_file, ref.names, is_mutect=args.is_mutect, n_threads=n_threads)
-    lap("VCF -> columns (native codec)")
+    # the GPU context (HIP runtime start-up: 0.1-0.3 s) comes up on a thread of its own while the inputs are read; reference,
+    # side tables and the callset VCF are read concurrently (common.load_side_tables)
+    from concurrent.futures import ThreadPoolExecutor
+    ctx_pool = ThreadPoolExecutor(max_workers=1)
+    f_eng = ctx_pool.submit(Engine, device)
+    logger.info("reading side tables and %s", args.input_file)
+    try:
+        ref, runs, tracks, bl, extra = common.load_side_tables(
+            args.reference_file, args.runs_file, args.annotate_intervals, args.blacklist,
+            also={"vcf": lambda names: vcfio.read_vcf(args.input_file, names, is_mutect=args.is_mutect, n_threads=n_threads)})
+        vcf = extra["vcf"]
+        # an estimator fitted on a named frame finds its interval columns by BED stem (`LCR-hs38`, `exome.twist`, ...)
+        forests = model_io.load_model_file(args.model_file, args.model_name, track_names=[t.name for t in tracks])
+        common.check_model_tracks(forests, len(tracks), "filter_variants_pipeline")
+    except BaseException:
+        try:
+            f_eng.result().close()
+        except Exception:                                   # (no GPU / no library: the input error is the one to report)
+            pass
+        ctx_pool.shutdown()
+        raise
+    lap("reference + side tables + model + VCF -> columns (concurrent, native codec)")
     hp_len, hp_dist = args.hpol_filter_length_dist
     # one row per ALT allele (multi-allelic records, spanning deletions: io/multiallelic.py), one verdict per record
     table, base_row = multiallelic.expand(vcf)
-    with Engine(device) as eng:
+    with f_eng.result() as eng:
+        ctx_pool.shutdown()
         if grp.world == 1:
             configure(eng, ref, runs, tracks, bl, forests, args.flow_order, hp_len, hp_dist, True)
             lap("context + uploads (reference, tables, model)")
