@@ -853,6 +853,7 @@ int ugvc_vcf_write_filtered(const ugvc_vcf* h, const char* out_path, const float
     FILE* fh = fopen(out_path, "wb");
     if (!fh) return fail(std::string(out_path) + ": cannot open for writing");
 
+    StageTimer st("write");
     // ---- header
     std::string stream;
     {
@@ -881,7 +882,6 @@ int ugvc_vcf_write_filtered(const ugvc_vcf* h, const char* out_path, const float
         }
         for (auto& l : chrom) { stream.append(l); stream.push_back('\n'); }
     }
-    StageTimer st("write");
     std::vector<int64_t> row_of((size_t)n);
     for (int64_t k = 0; k < n; ++k) row_of[(size_t)h->order[(size_t)k]] = k;
     st.lap("header + row map");
@@ -939,10 +939,12 @@ int ugvc_vcf_write_filtered(const ugvc_vcf* h, const char* out_path, const float
             deflateEnd(&zs);
         });
         if (bad) { io_ok = false; return 0; }
+        st.lap("  deflate");
         for (auto& o : comp) {
             if (fwrite(o.data(), 1, o.size(), fh) != o.size()) io_ok = false;
             blk_clen.push_back((uint32_t)o.size());
         }
+        st.lap("  file write");
         return std::min(size, nb * kBlk);
     };
 
@@ -1052,7 +1054,7 @@ int ugvc_vcf_write_filtered(const ugvc_vcf* h, const char* out_path, const float
 // Side tables: FASTA -> base codes, BED / interval_list -> (contig, start, end) rows
 // ------------------------------------------------------------------------------------------------------------
 struct ugvc_fasta {
-    std::vector<uint8_t> codes;
+    std::vector<uint8_t, NoInitAlloc<uint8_t>> codes;         // (every byte is written by the encode pass: no zero-fill of 3 GB first)
     std::vector<int64_t> off;
     std::string names;
 };
@@ -1067,8 +1069,10 @@ int ugvc_fasta_read(const char* path, int n_threads, ugvc_fasta** out) {
     if (!path || !out) return fail("NULL argument");
     *out = nullptr;
     const int threads = pick_threads(n_threads);
+    StageTimer st("fasta");
     TextBuf text;
     if (load_text(path, threads, text)) return -1;
+    st.lap("load");
     const char* base = text.data();
     const int64_t tn = (int64_t)text.size();
     if (tn == 0 || base[0] != '>') return fail(std::string(path) + ": not a FASTA file");
@@ -1104,13 +1108,13 @@ int ugvc_fasta_read(const char* path, int n_threads, ugvc_fasta** out) {
         seq_lo[k] = std::min(e + 1, tn);
         seq_hi[k] = k + 1 < nrec ? hdr[k + 1] : tn;
     }
-    // work items: <= 8 MB pieces of every record's sequence range; count, prefix, encode
+    // work items: <= 2 MB pieces of every record's sequence range; count, prefix, encode
     struct Piece { int64_t lo, hi, out; size_t rec; };
     std::vector<Piece> pieces;
     for (size_t k = 0; k < nrec; ++k)
-        for (int64_t q = seq_lo[k]; q < seq_hi[k] || q == seq_lo[k]; q += (int64_t)8 << 20) {
-            pieces.push_back(Piece{q, std::min(seq_hi[k], q + ((int64_t)8 << 20)), 0, k});
-            if (q + ((int64_t)8 << 20) >= seq_hi[k]) break;
+        for (int64_t q = seq_lo[k]; q < seq_hi[k] || q == seq_lo[k]; q += (int64_t)2 << 20) {
+            pieces.push_back(Piece{q, std::min(seq_hi[k], q + ((int64_t)2 << 20)), 0, k});
+            if (q + ((int64_t)2 << 20) >= seq_hi[k]) break;
         }
     std::vector<int64_t> cnt(pieces.size());
     parallel_items((int64_t)pieces.size(), threads, [&](int64_t i) {
@@ -1127,6 +1131,7 @@ int ugvc_fasta_read(const char* path, int n_threads, ugvc_fasta** out) {
         h->off[pieces[i].rec + 1] = run;
     }
     for (size_t k = 1; k <= nrec; ++k) h->off[k] = std::max(h->off[k], h->off[k - 1]);   // records without sequence
+    st.lap("headers + count");
     h->codes.resize((size_t)run);
     uint8_t code[256];
     memset(code, 0, sizeof code);
@@ -1139,6 +1144,7 @@ int ugvc_fasta_read(const char* path, int n_threads, ugvc_fasta** out) {
             if (ch != '\n' && ch != '\r') *d++ = code[ch];
         }
     });
+    st.lap("encode");
     *out = h.release();
     return 0;
 }

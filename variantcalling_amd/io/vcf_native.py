@@ -87,6 +87,32 @@ def _arr(ptr, n, dtype):
     return np.frombuffer(buf, dtype=dtype, count=n).copy()
 
 
+class _Owner:
+    """Keeps a native handle alive for as long as a numpy view of its memory is (no copy of a 3 GB reference)."""
+
+    def __init__(self, lib, handle, free):
+        self._lib, self._h, self._free = lib, handle, free
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                getattr(self._lib, self._free)(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def _view(ptr, n, dtype, owner):
+    """numpy view (read-only) of library-owned memory; `owner` (an _Owner) is released with the last view."""
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype)
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    buf._owner = owner
+    a = np.frombuffer(buf, dtype=dtype, count=n)
+    a.flags.writeable = False
+    return a
+
+
 class NativeVcfFile:
     """Same attributes as io.vcf.VcfFile; `records` / `orig_filter` are materialised on first use."""
 
@@ -190,25 +216,22 @@ def read_fasta(path: str, contigs: list | None = None, n_threads: int = 0) -> S.
     h = C.c_void_p()
     if lib.ugvc_fasta_read(os.fsencode(path), int(n_threads), C.byref(h)):
         raise ValueError(_err(lib))
-    try:
-        v = _FastaView()
-        lib.ugvc_fasta_get_view(h, C.byref(v))
-        names = C.string_at(v.names, v.names_bytes).decode().split("\n") if v.n_contigs else []
-        off = _arr(v.contig_off, int(v.n_contigs) + 1, np.int64)
-        if contigs is None:
-            codes = _arr(v.codes, int(v.total), np.uint8)
-        else:
-            keep = [k for k, nm in enumerate(names) if nm in contigs]
-            if not keep:
-                raise ValueError(f"{path}: no sequences read")
-            buf = (C.c_char * int(v.total)).from_address(v.codes) if v.total else b""
-            whole = np.frombuffer(buf, dtype=np.uint8, count=int(v.total))
-            codes = np.concatenate([whole[off[k]: off[k + 1]] for k in keep])
-            sizes = [int(off[k + 1] - off[k]) for k in keep]
-            off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
-            names = [names[k] for k in keep]
-    finally:
-        lib.ugvc_fasta_free(h)
+    owner = _Owner(lib, h, "ugvc_fasta_free")
+    v = _FastaView()
+    lib.ugvc_fasta_get_view(h, C.byref(v))
+    names = C.string_at(v.names, v.names_bytes).decode().split("\n") if v.n_contigs else []
+    off = _arr(v.contig_off, int(v.n_contigs) + 1, np.int64)
+    if contigs is None:
+        codes = _view(v.codes, int(v.total), np.uint8, owner)     # the encoded genome stays where the reader put it
+    else:
+        keep = [k for k, nm in enumerate(names) if nm in contigs]
+        if not keep:
+            raise ValueError(f"{path}: no sequences read")
+        whole = _view(v.codes, int(v.total), np.uint8, owner)
+        codes = np.concatenate([whole[off[k]: off[k + 1]] for k in keep])
+        sizes = [int(off[k + 1] - off[k]) for k in keep]
+        off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        names = [names[k] for k in keep]
     return S.Reference(codes, off, names)
 
 
