@@ -370,7 +370,8 @@ int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_
         fa.score = reinterpret_cast<float*>(dr + o[0]);
         fa.filter = dr + o[1];
         fa.flags = dr + o[2];
-        ctx->n_indel = chunk_indel[(size_t)c].load() * K;   // (sizes the indel tiles' table slices: the callset-wide rate, from this chunk)
+        // (sizes the indel tiles' table slices: the callset-wide count, estimated from this chunk's share - chunks differ in size)
+        ctx->n_indel = (int64_t)((double)chunk_indel[(size_t)c].load() * (double)n / (double)m);
         ctx->density_n = n;                                 // (table rows per tile are a property of the whole callset)
         rc = launch_score(ctx, fa);
         ctx->density_n = 0;
