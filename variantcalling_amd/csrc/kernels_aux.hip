@@ -99,20 +99,29 @@ __device__ __forceinline__ void pl_walk_staged(const uint16_t* stage, int k0, in
         const unsigned long long t = 1ull << (cls << 3);
         c8 += t;
         const uint32_t u = (uint32_t)t | (uint32_t)(t >> 32);
-        // (written as instructions: the compiler turns a multiplication by a 0 / 1 value back into compare + select)
-        const uint32_t is0 = u & 1u, is1 = __builtin_amdgcn_ubfe(u, 8, 1);
-        asm("v_mad_u32_u24 %0, %1, %2, %0" : "+v"(acc.bq0) : "v"(bq), "v"(is0));           // bq < 2^13
-        asm("v_mad_u32_u24 %0, %1, %2, %0" : "+v"(acc.bq1) : "v"(bq), "v"(is1));
+        // (written as instructions: the compiler turns a multiplication by a 0 / 1 value back into compare + select; the 0 / 1
+        // factors are bytes 0 and 1 of `u`, picked by the multiplier's operand selector - no extract instructions)
+        uint32_t x0, x1;
+        asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(x0) : "v"(bq), "v"(u));
+        asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(x1) : "v"(bq), "v"(u));
+        acc.bq0 += (int)x0;                                                                  // bq < 2^13
+        acc.bq1 += (int)x1;
     };
     int k = k0;
     while (k < k1) {
         unsigned long long c8 = 0;
         const int stop = k + 254 < k1 ? k + 254 : k1;
         if ((k & 1) && k < stop) { const uint32_t o = stage[k]; one(o & 7u, o >> 3, c8); ++k; }
-        for (; k + 2 <= stop; k += 2) {
-            const uint32_t w = *reinterpret_cast<const uint32_t*>(stage + k);
-            one(w & 7u, __builtin_amdgcn_ubfe(w, 3, 13), c8);
-            one(__builtin_amdgcn_ubfe(w, 16, 3), w >> 19, c8);
+        {   // (one induction variable - the LDS address - instead of an index, a bound test on index + 2 and the address)
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(stage + k);
+            const int np = (stop - k) >> 1;
+            const uint32_t* pe = p + np;
+            for (; p != pe; ++p) {
+                const uint32_t w = *p;
+                one(w & 7u, __builtin_amdgcn_ubfe(w, 3, 13), c8);
+                one(__builtin_amdgcn_ubfe(w, 16, 3), w >> 19, c8);
+            }
+            k += 2 * np;
         }
         if (k < stop) { const uint32_t o = stage[k]; one(o & 7u, o >> 3, c8); ++k; }
 #pragma unroll
