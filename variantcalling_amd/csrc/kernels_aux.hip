@@ -30,7 +30,8 @@ namespace ugvc {
 // (per-observation binary search + 12 shuffles per chunk) took 773 us.
 constexpr int kPlBlock = 256;
 constexpr int kPlLociPerBlock = 256;
-constexpr int kPlCap = 12288;          // staged observations per workgroup (24 KB)
+constexpr int kPlCap = 12288;          // staged observations per workgroup, at most (24 KB); the launch picks 8192 / 10240 / 12288
+                                       // by the longest 256-locus span of the table (fewer LDS bytes = more workgroups per CU)
 constexpr int kPlDeep = 2048;
 
 struct PileupArgs {
@@ -148,17 +149,17 @@ __device__ __forceinline__ void pl_store(const PileupArgs& a, int64_t l, const P
     a.sor[l] = sor_from_table(rf, rr, af, ar);
 }
 
-template <bool COMPACT>
+template <bool COMPACT, int CAP>
 __global__ __launch_bounds__(kPlBlock) void pileup_kernel(const PileupArgs a) {
     auto off_at = [&](int64_t l) -> int64_t { return COMPACT ? (int64_t)a.off32[l] : a.off[l]; };
-    __shared__ __attribute__((aligned(16))) uint16_t stage[kPlCap + 8];
+    __shared__ __attribute__((aligned(16))) uint16_t stage[CAP + 8];
     __shared__ int red[10];
     const int tid = threadIdx.x;
     const int64_t l0 = (int64_t)blockIdx.x * kPlLociPerBlock;
     const int nl = (int)((a.n_loci - l0) < kPlLociPerBlock ? (a.n_loci - l0) : kPlLociPerBlock);
     const int64_t o0 = off_at(l0), o1 = off_at(l0 + nl);
     const int64_t base = o0 & ~(int64_t)7;                    // 16-byte aligned start of the staged span
-    const bool staged = o1 - base <= kPlCap;
+    const bool staged = o1 - base <= CAP;
     if (staged) {
         const uint4* src = reinterpret_cast<const uint4*>(a.obs + base);      // obs buffer is padded by 16 bytes
         uint4* dst = reinterpret_cast<uint4*>(stage);
@@ -219,19 +220,22 @@ int launch_pileup(ugvc_ctx* ctx) {
     int32_t* o = ctx->pl_out.as<int32_t>();
     const int64_t n = ctx->pl_n;
     const unsigned grid = (unsigned)((n + kPlLociPerBlock - 1) / kPlLociPerBlock);
+    const char* cap_env = getenv("UGVC_PL_CAP");                          // (profiling: staging capacity 8192 / 10240 / 12288)
     if (ctx->pl_compact) {
         // [bq_ref u32 | bq_alt u32 | sor f32 | five u16 count columns]: 22 bytes per locus
         a.bq_ref = o; a.bq_alt = o + n;
         a.sor = reinterpret_cast<float*>(o + 2 * n);
         uint16_t* h = reinterpret_cast<uint16_t*>(o + 3 * n);
         for (int q = 0; q < 5; ++q) a.c16[q] = h + (size_t)q * n;
-        hipLaunchKernelGGL(pileup_kernel<true>, dim3(grid), dim3(kPlBlock), 0, ctx->stream, a);
+        const int cap = cap_env ? atoi(cap_env) : (ctx->pl_span <= 8192 ? 8192 : ctx->pl_span <= 10240 ? 10240 : kPlCap);
+        auto kern = cap <= 8192 ? pileup_kernel<true, 8192> : cap <= 10240 ? pileup_kernel<true, 10240> : pileup_kernel<true, kPlCap>;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kPlBlock), 0, ctx->stream, a);
     } else {
         a.ref_fwd = o; a.ref_rev = o + n; a.alt_fwd = o + 2 * n; a.alt_rev = o + 3 * n;
         a.other = o + 4 * n; a.dp = o + 5 * n; a.bq_ref = o + 6 * n; a.bq_alt = o + 7 * n;
         a.vaf = reinterpret_cast<float*>(o + 8 * n);
         a.sor = reinterpret_cast<float*>(o + 9 * n);
-        hipLaunchKernelGGL(pileup_kernel<false>, dim3(grid), dim3(kPlBlock), 0, ctx->stream, a);
+        hipLaunchKernelGGL((pileup_kernel<false, kPlCap>), dim3(grid), dim3(kPlBlock), 0, ctx->stream, a);
     }
     UGVC_HIP(hipGetLastError());
     return 0;
@@ -362,6 +366,13 @@ int ugvc_pileup_upload(ugvc_ctx* ctx, const int64_t* offsets, const uint16_t* ob
     int64_t deepest = 0;
     for (int64_t i = 0; i < n_loci; ++i) deepest = std::max(deepest, offsets[i + 1] - offsets[i]);
     ctx->pl_compact = (deepest <= 65535 && m < ((int64_t)1 << 32)) ? 1 : 0;
+    // the longest span of observations one workgroup (256 consecutive loci) stages, from its 16-byte aligned start
+    int64_t span = 0;
+    for (int64_t l0 = 0; l0 < n_loci; l0 += kPlLociPerBlock) {
+        const int64_t l1 = std::min(n_loci, l0 + kPlLociPerBlock);
+        span = std::max(span, offsets[l1] - (offsets[l0] & ~(int64_t)7));
+    }
+    ctx->pl_span = span;
     if (ctx->pl_compact) {
         std::vector<uint32_t> o32((size_t)n_loci + 1);
         for (int64_t i = 0; i <= n_loci; ++i) o32[(size_t)i] = (uint32_t)offsets[i];

@@ -125,7 +125,7 @@ struct ugvc_ctx {
     ugvc::DeviceBuf r_score, r_filter, r_flags, x_mat, x_group;
     int scored = 0;                    // the resident result columns hold a scoring pass over the resident variants
     // pileup
-    int64_t pl_n = 0, pl_obs = 0;
+    int64_t pl_n = 0, pl_obs = 0, pl_span = 0;   // pl_span: longest staged span of a 256-locus workgroup (picks the LDS capacity)
     ugvc::DeviceBuf pl_off, pl_off32, pl_obsb, pl_out;
     int pl_compact = 0;              // device layout of the pileup table (kernels_aux.hip)
     // SEC database (kernels_sec.hip): sorted locus keys, every 64th key, k expected counts per locus
