@@ -398,6 +398,7 @@ def run_c5(args):
     eng.upload_variants(cs.variants)
     X, group = eng.feature_matrix()
     N = X.shape[0]
+    eng.set_kernel_variant(args.variant)                        # (profiling bits of the feature-matrix launch; 0 in every reported run)
     # BASELINE.md C5 "feature-build GB/s": the resident N x F matrix built `steps` times back to back (device events, no
     # download); algorithmic bytes = the scoring pass's 121.6 B read per variant + 4 F written
     eng.timed_feature_matrix(2)

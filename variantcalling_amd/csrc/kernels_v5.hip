@@ -435,7 +435,7 @@ __device__ __forceinline__ void issue_slices(const V5Args& v, const Brk<NT>& bk,
 // tiles write the lane's RAW feature values (schema.BASE_FEATURES order) instead of ranking them and walking - no model
 // is needed, nothing but X and `group` is written.  A row is 4 F bytes: 16-byte stores when F is a multiple of 4.
 __device__ __forceinline__ void store_feature_row(const FilterArgs& a, uint32_t i, bool live, const float (&x)[kMaxFeatures], int group) {
-    if (!live) return;
+    if (!live || (a.ablate & 4194304)) return;                   // (profiling bit: the matrix is not written)
     const int F = UGVC_N_BASE_FEATURES + a.n_tracks;
     float* row = a.X + (size_t)i * (size_t)F;
     if ((F & 3) == 0) {
@@ -448,6 +448,39 @@ __device__ __forceinline__ void store_feature_row(const FilterArgs& a, uint32_t 
             if (f < F) row[f] = x[f];
     }
     if (a.group) a.group[i] = (uint8_t)group;
+}
+
+// The same rows, COALESCED: a lane-per-row store puts 64 separate 16-byte pieces, 80 bytes apart, into every store
+// instruction (~40 cache lines touched per instruction, five instructions per tile - measured: 57 of the 187 us of a 2 M-row
+// build, `--variant 4194304` against 0).  Here the tile's rows go through the wave's LDS scratch row-major - which IS the
+// order of the matrix in memory - and lane j of store k writes 16-byte piece 64 k + j of that image (row = piece / (F/4)):
+// consecutive lanes write consecutive addresses wherever the tile's rows are neighbours in the callset (they mostly are:
+// a tile is 64 consecutive rows of one class).  LDS: 64 F floats + 64 row indices behind them at `base`.
+template <int F>
+__device__ __forceinline__ void store_feature_rows_tile(const FilterArgs& a, uint32_t base, int lane, uint32_t i, bool live,
+                                                        const float (&x)[kMaxFeatures], int group) {
+    static_assert(F % 4 == 0 && F <= kMaxFeatures, "16-byte pieces");
+    if (a.ablate & 4194304) return;                              // (profiling bit: the matrix is not written)
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int Q = F / 4;
+    constexpr uint32_t kIds = 64u * F * 4u;
+    __builtin_amdgcn_wave_barrier();                             // (the tile's staged slices are dead; LDS runs a wave's accesses in order)
+    const uint32_t rb = base + (uint32_t)lane * (uint32_t)(F * 4);
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+        *(UGVC_LDS f32x4*)(uintptr_t)(rb + 16u * q) = f32x4{x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
+    lds_st32(base + kIds + 4u * (uint32_t)lane, live ? (int32_t)i : -1);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+        const uint32_t p = (uint32_t)(k * 64 + lane);
+        const uint32_t r = p / (uint32_t)Q, q = p - r * (uint32_t)Q;
+        const uint32_t id = lds_u32(base + kIds + 4u * r);
+        const f32x4 val = *(UGVC_LDS const f32x4*)(uintptr_t)(base + 16u * p);
+        if (id != ~0u) *reinterpret_cast<f32x4*>(a.X + (size_t)id * (size_t)F + 4u * q) = val;
+    }
+    if (live && a.group) a.group[i] = (uint8_t)group;
+    __builtin_amdgcn_wave_barrier();                             // (before the next tile stages its slices here)
 }
 
 // ---- SNP / MNP tile: features of 64 substitutions (ref_len == alt_len) ---------------------------------
@@ -679,7 +712,8 @@ __device__ __forceinline__ void featurize_snp_tile(const V5Args& v, const Scratc
         x[16] = jo.close_run ? 1.f : 0.f;
 #pragma unroll
         for (int t = 0; t < UGVC_MAX_TRACKS; ++t) x[UGVC_N_BASE_FEATURES + t] = (jo.trk >> t) & 1u ? 1.f : 0.f;
-        store_feature_row(a, i, live, x, 0);
+        if constexpr (((UGVC_N_BASE_FEATURES + NTRK) & 3) == 0) store_feature_rows_tile<UGVC_N_BASE_FEATURES + NTRK>(a, sc.base, lane, i, live, x, 0);
+        else store_feature_row(a, i, live, x, 0);
         return;
     }
     // ---- codes -> the wave's code planes (the staged slices are dead: LDS executes a wave's accesses in order)
@@ -1058,7 +1092,8 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
         x[16] = jo.close_run ? 1.f : 0.f;
 #pragma unroll
         for (int t = 0; t < UGVC_MAX_TRACKS; ++t) x[UGVC_N_BASE_FEATURES + t] = (jo.trk >> t) & 1u ? 1.f : 0.f;
-        store_feature_row(a, i, live, x, group);
+        if constexpr (((UGVC_N_BASE_FEATURES + NTRK) & 3) == 0) store_feature_rows_tile<UGVC_N_BASE_FEATURES + NTRK>(a, sc.base, lane, i, live, x, group);
+        else store_feature_row(a, i, live, x, group);
         return;
     }
     // ---- codes of the lane's own group
@@ -1696,6 +1731,10 @@ int launch_feature_matrix_v5(ugvc_ctx* ctx, const FilterArgs& a) {
     v.n_waves = 16;
     v.n_indel_waves = 8;
     v.indel_w = 768;                                              // without the walk an indel tile costs about three SNP tiles
+    // every wave's LDS scratch also holds a tile's rows on their way out (store_feature_rows_tile): 64 F floats + 64 indices
+    const int rows_lds = (64 * kMaxFeatures * 4 + 256 + 63) & ~63;
+    v.scratch_bytes = std::max(v.scratch_bytes, rows_lds);
+    v.scratch_indel = std::max(v.scratch_indel, rows_lds);
     if (const char* e = getenv("UGVC_FM_INDEL_W")) v.indel_w = std::max(1, (int)(atof(e) * 256.0));      // (profiling)
     if (lds5_bytes(v, v.n_waves) > 158 * 1024) return fail("internal: feature-matrix scratch does not fit LDS");
     const unsigned n_wg = (unsigned)((a.n + v.rows_wg - 1) / v.rows_wg);
