@@ -282,7 +282,7 @@ def test_chunk_pipeline_boundary(engine, frozen_models):
     would - a resident pass and a download give the same columns, and the feature matrix of the resident callset equals the
     oracle's; (iii) a row that breaks the sort order in a LATER chunk is reported by its row number; (iv) the next valid call is unaffected."""
     import copy
-    from variantcalling_amd import synth
+    from variantcalling_amd import schema as S, synth
     O = _oracle()
     cs = synth.make_callset(300_011, genome_len=150_000_000, n_contigs=5, seed=99)
     forests = frozen_models[RF]
@@ -307,6 +307,14 @@ def test_chunk_pipeline_boundary(engine, frozen_models):
     with pytest.raises(RuntimeError, match=f"row {row}$"):
         engine.filter_variants(bad)
     _assert_same(engine.filter_variants(vt), exp, "after the failed call")
+    # the caller's result arrays, reused from call to call (no fresh 30 MB of numpy per 5 M variants)
+    keep = S.FilterResult(np.full(vt.n, 7, np.float32), np.full(vt.n, 7, np.uint8), np.full(vt.n, 7, np.uint8))
+    assert engine.filter_variants(vt, out=keep) is keep
+    _assert_same(keep, exp, "out=")
+    with pytest.raises(ValueError, match="out:"):
+        engine.filter_variants(vt, out=S.FilterResult(np.zeros(vt.n, np.float64), keep.filter, keep.flags))
+    with pytest.raises(ValueError, match="out:"):
+        engine.filter_variants(vt, out=S.FilterResult(keep.tree_score[:-1], keep.filter[:-1], keep.flags[:-1]))
 
 
 def test_golden_fixture_outputs(engine, frozen_models):
