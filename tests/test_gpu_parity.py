@@ -307,6 +307,28 @@ def test_chunk_pipeline_boundary(engine, frozen_models):
     with pytest.raises(RuntimeError, match=f"row {row}$"):
         engine.filter_variants(bad)
     _assert_same(engine.filter_variants(vt), exp, "after the failed call")
+    # the same callset with the allele pool laid out the OTHER way round (every row's ALT in front of its REF): the boundary
+    # call ships ref_off / alt_off only when they do not follow from the lengths (csrc/pipeline.hip: canonical pools have
+    # them rebuilt on the device) - both ways must give the same rows, and the resident offsets must be usable afterwards
+    rl, al = vt.ref_len.astype(np.int64), vt.alt_len.astype(np.int64)
+    start = np.cumsum(rl + al) - (rl + al)
+    swapped = copy.copy(vt)
+    swapped.alt_off = start.astype(np.uint32)
+    swapped.ref_off = (start + al).astype(np.uint32)
+    pool = np.zeros(int((rl + al).sum()), np.uint8)
+    for k in range(int(max(rl.max(), al.max()))):
+        m = np.flatnonzero(al > k)
+        pool[swapped.alt_off[m].astype(np.int64) + k] = vt.alleles[vt.alt_off[m].astype(np.int64) + k]
+        m = np.flatnonzero(rl > k)
+        pool[swapped.ref_off[m].astype(np.int64) + k] = vt.alleles[vt.ref_off[m].astype(np.int64) + k]
+    swapped.alleles = pool
+    assert np.array_equal(vt.ref_off.astype(np.int64) + rl, vt.alt_off.astype(np.int64))        # the synthetic pool is canonical
+    _assert_same(engine.filter_variants(swapped), exp, "non-canonical allele pool")
+    X2, g2 = engine.feature_matrix()
+    assert np.array_equal(X2, f["X"]) and np.array_equal(g2, f["group"])
+    _assert_same(engine.filter_variants(vt), exp, "canonical again")
+    X3, _ = engine.feature_matrix()
+    assert np.array_equal(X3, f["X"])
     # the caller's result arrays, reused from call to call (no fresh 30 MB of numpy per 5 M variants)
     keep = S.FilterResult(np.full(vt.n, 7, np.float32), np.full(vt.n, 7, np.uint8), np.full(vt.n, 7, np.uint8))
     assert engine.filter_variants(vt, out=keep) is keep

@@ -63,6 +63,23 @@ int validate_rows(const ugvc_variants* v, int64_t lo, int64_t hi, int n_contigs,
     return 0;
 }
 
+// Is the allele pool laid out the way a VCF reader leaves it - every row's REF then ALT, row after row, no gaps?  Then
+// ref_off / alt_off of rows [lo, hi) follow from the lengths and the first row's offset, and the boundary call does not
+// ship them (8 of a row's 39 bytes).  Row i is compared with row i - 1 for i > first (the chunk's first row: its offset is
+// the chunk's base, handed to the device as a number).
+__attribute__((target_clones("avx512f", "avx2", "default")))
+static unsigned block_not_canonical(const uint16_t* __restrict__ rl, const uint16_t* __restrict__ al, const uint32_t* __restrict__ ro,
+                                    const uint32_t* __restrict__ ao, int64_t lo, int64_t hi, int64_t first) {
+    unsigned bad = 0;
+    for (int64_t i = lo; i < hi; ++i) bad |= (unsigned)((uint64_t)ro[i] + rl[i] != (uint64_t)ao[i]);
+    for (int64_t i = std::max(lo, first + 1); i < hi; ++i) bad |= (unsigned)((uint64_t)ao[i - 1] + al[i - 1] != (uint64_t)ro[i]);
+    return bad;
+}
+
+bool offsets_canonical(const ugvc_variants* v, int64_t lo, int64_t hi, int64_t first) {
+    return !block_not_canonical(v->ref_len, v->alt_len, v->ref_off, v->alt_off, lo, hi, first);
+}
+
 // memcpy whose destination is not read before it is written and not kept in the cache: a column piece goes from the caller's
 // array into a pinned staging slot that only the DMA engine reads next (streaming stores: two memory transfers per byte
 // instead of three).  Pieces below 4 KB and CPUs without AVX2 take memcpy.

@@ -35,6 +35,7 @@ int launch_score(ugvc_ctx* ctx, const FilterArgs& a);
 // host_rows.cpp (g++, vectorised)
 int validate_rows(const ugvc_variants* v, int64_t lo, int64_t hi, int n_contigs, int64_t* n_indel, int64_t* row);
 const char* row_error_text(int what);
+bool offsets_canonical(const ugvc_variants* v, int64_t lo, int64_t hi, int64_t first);
 void copy_stream(void* dst, const void* src, size_t n);
 void copy_stream_fence();
 
@@ -81,6 +82,7 @@ struct PipeState {
     void* res = nullptr;                        // pinned: every chunk's packed result columns
     size_t res_cap = 0;
     DeviceBuf d_res;                            // the passes write their results HERE, packed per chunk
+    DeviceBuf d_sums[kSlots];                   // allele-offset reconstruction: one sum per 4096 rows of a chunk
     void* alle = nullptr;                       // pinned: the allele pool
     size_t alle_cap = 0;
     std::vector<hipEvent_t> ev;                 // four per chunk
@@ -99,7 +101,7 @@ void pipe_destroy(ugvc_ctx* ctx) {
     delete p->pool;
     for (void* q : {p->stage[0], p->stage[1], p->stage[2], p->res, p->alle})
         if (q) (void)hipHostFree(q);
-    for (DeviceBuf* b : {&p->d_stage[0], &p->d_stage[1], &p->d_stage[2], &p->d_res})
+    for (DeviceBuf* b : {&p->d_stage[0], &p->d_stage[1], &p->d_stage[2], &p->d_res, &p->d_sums[0], &p->d_sums[1], &p->d_sums[2]})
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     if (p->ev_t0) (void)hipEventDestroy(p->ev_t0);
@@ -148,6 +150,65 @@ __global__ void __launch_bounds__(256) pipe_place_kernel(SegTable t) {
     if (blockIdx.x == 0 && threadIdx.x < (unsigned)(s.bytes & 15)) s.dst[(n16 << 4) + threadIdx.x] = s.src[(n16 << 4) + threadIdx.x];
 }
 
+// ---- allele offsets that are not shipped.  When a chunk's pool is laid out canonically (host_rows.cpp: every row's REF
+// then ALT, row after row - what a VCF reader leaves behind) ref_off / alt_off are an exclusive scan of ref_len + alt_len
+// from the chunk's first offset: 8 of a row's 39 bytes stay off the host link.  Two small launches per chunk, in front of
+// its pass: sums of 4096-row blocks, then every block adds the sums in front of it to its own scan.  u32 arithmetic as in
+// the columns themselves (a pool is at most 4 GiB).
+constexpr int kOffRows = 16;                                     // rows per thread; a block of 256 threads covers 4096 rows
+
+__global__ void __launch_bounds__(256) pipe_offsets_sum_kernel(const uint16_t* __restrict__ rl, const uint16_t* __restrict__ al, int64_t m,
+                                                               uint32_t* __restrict__ sums) {
+    __shared__ uint32_t part[4];
+    const int64_t r0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * kOffRows;
+    uint32_t s = 0;
+    for (int q = 0; q < kOffRows; ++q)
+        if (r0 + q < m) s += (uint32_t)rl[r0 + q] + al[r0 + q];
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ void __launch_bounds__(256) pipe_offsets_fill_kernel(const uint16_t* __restrict__ rl, const uint16_t* __restrict__ al, int64_t m,
+                                                                uint32_t base, const uint32_t* __restrict__ sums, uint32_t* __restrict__ ro,
+                                                                uint32_t* __restrict__ ao) {
+    __shared__ uint32_t wave_tot[4];
+    __shared__ uint32_t before;
+    // the blocks in front of this one (a chunk has at most a few hundred)
+    uint32_t pre = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) pre += sums[b];
+    for (int d = 32; d >= 1; d >>= 1) pre += __shfl_xor(pre, d);
+    if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = pre;
+    __syncthreads();
+    if (threadIdx.x == 0) before = base + wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    __syncthreads();
+    const int64_t r0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * kOffRows;
+    uint32_t len[kOffRows], mine = 0;
+    for (int q = 0; q < kOffRows; ++q) {
+        len[q] = r0 + q < m ? (uint32_t)rl[r0 + q] + al[r0 + q] : 0u;
+        mine += len[q];
+    }
+    // exclusive scan of the threads' totals: inside the wave by shuffles, across the four waves through LDS
+    uint32_t incl = mine;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+    }
+    __syncthreads();                                             // (wave_tot is reused)
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t at = before + incl - mine;
+    for (int w = 0; w < wave; ++w) at += wave_tot[w];
+    for (int q = 0; q < kOffRows; ++q)
+        if (r0 + q < m) {
+            ro[r0 + q] = at;
+            ao[r0 + q] = at + rl[r0 + q];
+            at += len[q];
+        }
+}
+
 int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_results* out, int n_chunks) {
     // UGVC_PIPE_TRACE=1: host and device timeline of the call on stderr (ms since entry; tools/pipe_trace.py reads it)
     static const bool trace = getenv("UGVC_PIPE_TRACE") != nullptr;
@@ -180,10 +241,14 @@ int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_
     }
     if (!ps->h2d) UGVC_HIP(hipStreamCreateWithFlags(&ps->h2d, hipStreamNonBlocking));
     if (!ps->d2h) UGVC_HIP(hipStreamCreateWithFlags(&ps->d2h, hipStreamNonBlocking));
+    // (the two allele-offset columns sit at the END of a slot: a chunk whose pool is canonical is shipped without them)
     const Col cols[] = {{v->contig, &ctx->v_contig, 2}, {v->pos, &ctx->v_pos, 4},   {v->ref_len, &ctx->v_rl, 2}, {v->alt_len, &ctx->v_al, 2},
-                        {v->ref_off, &ctx->v_ro, 4},    {v->alt_off, &ctx->v_ao, 4}, {v->qual, &ctx->v_qual, 4},  {v->sor, &ctx->v_sor, 4},
-                        {v->dp, &ctx->v_dp, 4},         {v->ad_ref, &ctx->v_adr, 4}, {v->ad_alt, &ctx->v_ada, 4}, {v->gq, &ctx->v_gq, 1}};
+                        {v->qual, &ctx->v_qual, 4},     {v->sor, &ctx->v_sor, 4},   {v->dp, &ctx->v_dp, 4},      {v->ad_ref, &ctx->v_adr, 4},
+                        {v->ad_alt, &ctx->v_ada, 4},    {v->gq, &ctx->v_gq, 1},     {v->ref_off, &ctx->v_ro, 4}, {v->alt_off, &ctx->v_ao, 4}};
     constexpr int NC = sizeof(cols) / sizeof(cols[0]);
+    constexpr int kColRo = NC - 2, kColAo = NC - 1;
+    const char* dv_env = getenv("UGVC_PIPE_DERIVE");
+    const bool derive_offsets = dv_env ? atoi(dv_env) != 0 : true;
     size_t row_bytes = 0;
     for (const Col& c : cols) row_bytes += c.w;
     for (const Col& c : cols)
@@ -223,6 +288,7 @@ int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_
     for (int k = 0; k < NS; ++k) {
         if (pinned(ps->stage[k], ps->stage_cap[k], slot_bytes)) return -1;
         if (ensure(ps->d_stage[k], slot_bytes)) return -1;
+        if (ensure(ps->d_sums[k], ((size_t)rows_chunk / (256 * kOffRows) + 2) * 4)) return -1;
     }
     if (pinned(ps->res, ps->res_cap, (size_t)K * res_bytes)) return -1;
     if (ensure(ps->d_res, (size_t)K * res_bytes)) return -1;
@@ -259,6 +325,8 @@ int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_
     std::atomic<int> bad_what{0};
     std::vector<std::atomic<int64_t>> chunk_indel((size_t)K);
     for (auto& x : chunk_indel) x.store(0);
+    std::vector<std::atomic<int>> chunk_canon((size_t)K);      // 1: the chunk's allele offsets follow from the lengths
+    for (auto& x : chunk_canon) x.store(derive_offsets ? 1 : 0);
     const int n_contigs = ctx->n_contigs;
     auto slot_offsets = [&](int64_t m, size_t (&off)[NC]) {
         size_t used = 0;
@@ -270,14 +338,12 @@ int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_
         o[1] = o[0] + (((size_t)m * 4 + 63) & ~(size_t)63);
         o[2] = o[1] + (((size_t)m + 63) & ~(size_t)63);
     };
-    // piece t of T of chunk c: validation of its rows (what the kernels rely on), then the copy into the chunk's pinned slot
-    auto pack_piece = [&](int c, int t) {
+    // piece t of T of chunk c, first the checks - the rows are what the kernels rely on; do the allele offsets follow from
+    // the lengths (then they are neither copied nor shipped) - then, in a second job, the copy into the chunk's pinned slot
+    auto check_piece = [&](int c, int t) {
         const int64_t a = cb[(size_t)c], m = cb[(size_t)c + 1] - a;
         const int64_t lo = a + m * t / T, hi = a + m * (t + 1) / T;
         if (hi <= lo) return;
-        uint8_t* st = static_cast<uint8_t*>(ps->stage[c % NS]);
-        size_t off[NC];
-        (void)slot_offsets(m, off);
         int64_t ind = 0, row = -1;
         if (const int what = validate_rows(v, lo, hi, n_contigs, &ind, &row)) {
             int64_t cur = bad_row.load();
@@ -286,7 +352,17 @@ int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_
             return;
         }
         chunk_indel[(size_t)c].fetch_add(ind);
-        for (int q = 0; q < NC; ++q) {
+        if (chunk_canon[(size_t)c].load(std::memory_order_relaxed) && !offsets_canonical(v, lo, hi, a)) chunk_canon[(size_t)c].store(0);
+    };
+    auto pack_piece = [&](int c, int t) {
+        const int64_t a = cb[(size_t)c], m = cb[(size_t)c + 1] - a;
+        const int64_t lo = a + m * t / T, hi = a + m * (t + 1) / T;
+        if (hi <= lo) return;
+        uint8_t* st = static_cast<uint8_t*>(ps->stage[c % NS]);
+        size_t off[NC];
+        (void)slot_offsets(m, off);
+        const int nc = chunk_canon[(size_t)c].load() ? kColRo : NC;
+        for (int q = 0; q < nc; ++q) {
             uint8_t* d = st + off[q] + (size_t)(lo - a) * cols[q].w;
             const uint8_t* sp = static_cast<const uint8_t*>(cols[q].src) + (size_t)lo * cols[q].w;
             if (stream_stores) copy_stream(d, sp, (size_t)(hi - lo) * cols[q].w);
@@ -315,9 +391,10 @@ int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_
                 const size_t lo = len * (size_t)task / (size_t)T, hi = len * (size_t)(task + 1) / (size_t)T;
                 memcpy(al + lo, v->alleles + lo, hi - lo);
             } else {
-                pack_piece(0, task - T);
+                check_piece(0, task - T);
             }
         });
+        if (bad_row.load() == INT64_MAX) pool.parallel_for(T, [&](int task) { pack_piece(0, task); });
         ::memset(al + len, 0, 16);
         mark(0, "head_packed");
         // everything queued on the context stream so far (model uploads, an earlier resident pass ...) precedes the first copy:
@@ -333,9 +410,10 @@ int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_
     int rc = 0, issued = 0;
     int job_pack = -1, job_out = -1;
     const std::function<void(int)> job = [&](int task) {
-        if (task < T) { if (job_pack >= 0) pack_piece(job_pack, task); }
+        if (task < T) { if (job_pack >= 0) check_piece(job_pack, task); }
         else if (job_out >= 0) out_piece(job_out, task - T);
     };
+    const std::function<void(int)> job2 = [&](int task) { pack_piece(job_pack, task); };
     for (int c = 0; c < K && !rc && bad_row.load() == INT64_MAX; ++c) {
         const int64_t a = cb[(size_t)c], b = cb[(size_t)c + 1], m = b - a;
         const int slot = c % NS;
@@ -346,27 +424,38 @@ int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_
         uint8_t* st = static_cast<uint8_t*>(ps->stage[slot]);
         uint8_t* dst = static_cast<uint8_t*>(ps->d_stage[slot].p);
         if (c >= NS) UGVC_HIP(hipStreamWaitEvent(ps->h2d, ev_placed(c - NS), 0));
-        UGVC_HIP(hipMemcpyAsync(dst, st, used, hipMemcpyHostToDevice, ps->h2d));
+        const bool canon = chunk_canon[(size_t)c].load() != 0;
+        UGVC_HIP(hipMemcpyAsync(dst, st, canon ? off[kColRo] : used, hipMemcpyHostToDevice, ps->h2d));
         UGVC_HIP(hipEventRecord(ev_in(c), ps->h2d));
         // ---- the pass over the chunk reads its columns where the DMA put them and writes its results packed
         size_t o[3];
         res_off(c, m, o);
         uint8_t* dr = static_cast<uint8_t*>(ps->d_res.p);
         UGVC_HIP(hipStreamWaitEvent(ctx->stream, ev_in(c), 0));
+        if (canon) {
+            const unsigned nb = (unsigned)((m + 256 * kOffRows - 1) / (256 * kOffRows));
+            uint32_t* sums = ps->d_sums[slot].as<uint32_t>();
+            const uint16_t* rl_d = reinterpret_cast<const uint16_t*>(dst + off[2]);
+            const uint16_t* al_d = reinterpret_cast<const uint16_t*>(dst + off[3]);
+            hipLaunchKernelGGL(pipe_offsets_sum_kernel, dim3(nb), dim3(256), 0, ctx->stream, rl_d, al_d, m, sums);
+            hipLaunchKernelGGL(pipe_offsets_fill_kernel, dim3(nb), dim3(256), 0, ctx->stream, rl_d, al_d, m, v->ref_off[a], (const uint32_t*)sums,
+                               reinterpret_cast<uint32_t*>(dst + off[kColRo]), reinterpret_cast<uint32_t*>(dst + off[kColAo]));
+            UGVC_HIP(hipGetLastError());
+        }
         FilterArgs fa = base;
         fa.n = m;
         fa.contig = reinterpret_cast<const uint16_t*>(dst + off[0]);
         fa.pos = reinterpret_cast<const int32_t*>(dst + off[1]);
         fa.ref_len = reinterpret_cast<const uint16_t*>(dst + off[2]);
         fa.alt_len = reinterpret_cast<const uint16_t*>(dst + off[3]);
-        fa.ref_off = reinterpret_cast<const uint32_t*>(dst + off[4]);
-        fa.alt_off = reinterpret_cast<const uint32_t*>(dst + off[5]);
-        fa.qual = reinterpret_cast<const float*>(dst + off[6]);
-        fa.sor = reinterpret_cast<const float*>(dst + off[7]);
-        fa.dp = reinterpret_cast<const int32_t*>(dst + off[8]);
-        fa.ad_ref = reinterpret_cast<const int32_t*>(dst + off[9]);
-        fa.ad_alt = reinterpret_cast<const int32_t*>(dst + off[10]);
-        fa.gq = reinterpret_cast<const uint8_t*>(dst + off[11]);
+        fa.qual = reinterpret_cast<const float*>(dst + off[4]);
+        fa.sor = reinterpret_cast<const float*>(dst + off[5]);
+        fa.dp = reinterpret_cast<const int32_t*>(dst + off[6]);
+        fa.ad_ref = reinterpret_cast<const int32_t*>(dst + off[7]);
+        fa.ad_alt = reinterpret_cast<const int32_t*>(dst + off[8]);
+        fa.gq = reinterpret_cast<const uint8_t*>(dst + off[9]);
+        fa.ref_off = reinterpret_cast<const uint32_t*>(dst + off[kColRo]);
+        fa.alt_off = reinterpret_cast<const uint32_t*>(dst + off[kColAo]);
         fa.score = reinterpret_cast<float*>(dr + o[0]);
         fa.filter = dr + o[1];
         fa.flags = dr + o[2];
@@ -402,6 +491,7 @@ int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_
         if (job_out >= 0) UGVC_HIP(hipEventSynchronize(ev_out(job_out)));
         mark(c, "job_start");
         if (job_pack >= 0 || job_out >= 0) pool.parallel_for(2 * T, job);
+        if (job_pack >= 0 && bad_row.load() == INT64_MAX) pool.parallel_for(T, job2);
         mark(c, "job_end");
     }
     if (bad_row.load() != INT64_MAX || rc) {
