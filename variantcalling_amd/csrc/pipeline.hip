@@ -338,8 +338,24 @@ int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_
         o[1] = o[0] + (((size_t)m * 4 + 63) & ~(size_t)63);
         o[2] = o[1] + (((size_t)m + 63) & ~(size_t)63);
     };
-    // piece t of T of chunk c, first the checks - the rows are what the kernels rely on; do the allele offsets follow from
-    // the lengths (then they are neither copied nor shipped) - then, in a second job, the copy into the chunk's pinned slot
+    // piece t of T of chunk c: the checks - the rows are what the kernels rely on; do the allele offsets follow from the
+    // lengths (then they are neither copied nor shipped) - and the copy of the ten other columns into the chunk's pinned
+    // slot in the same job; the two offset columns follow in a second job only where a chunk needs them
+    auto copy_cols = [&](int c, int t, int q0, int q1) {
+        const int64_t a = cb[(size_t)c], m = cb[(size_t)c + 1] - a;
+        const int64_t lo = a + m * t / T, hi = a + m * (t + 1) / T;
+        if (hi <= lo) return;
+        uint8_t* st = static_cast<uint8_t*>(ps->stage[c % NS]);
+        size_t off[NC];
+        (void)slot_offsets(m, off);
+        for (int q = q0; q < q1; ++q) {
+            uint8_t* d = st + off[q] + (size_t)(lo - a) * cols[q].w;
+            const uint8_t* sp = static_cast<const uint8_t*>(cols[q].src) + (size_t)lo * cols[q].w;
+            if (stream_stores) copy_stream(d, sp, (size_t)(hi - lo) * cols[q].w);
+            else memcpy(d, sp, (size_t)(hi - lo) * cols[q].w);
+        }
+        if (stream_stores) copy_stream_fence();
+    };
     auto check_piece = [&](int c, int t) {
         const int64_t a = cb[(size_t)c], m = cb[(size_t)c + 1] - a;
         const int64_t lo = a + m * t / T, hi = a + m * (t + 1) / T;
@@ -353,23 +369,9 @@ int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_
         }
         chunk_indel[(size_t)c].fetch_add(ind);
         if (chunk_canon[(size_t)c].load(std::memory_order_relaxed) && !offsets_canonical(v, lo, hi, a)) chunk_canon[(size_t)c].store(0);
+        copy_cols(c, t, 0, kColRo);
     };
-    auto pack_piece = [&](int c, int t) {
-        const int64_t a = cb[(size_t)c], m = cb[(size_t)c + 1] - a;
-        const int64_t lo = a + m * t / T, hi = a + m * (t + 1) / T;
-        if (hi <= lo) return;
-        uint8_t* st = static_cast<uint8_t*>(ps->stage[c % NS]);
-        size_t off[NC];
-        (void)slot_offsets(m, off);
-        const int nc = chunk_canon[(size_t)c].load() ? kColRo : NC;
-        for (int q = 0; q < nc; ++q) {
-            uint8_t* d = st + off[q] + (size_t)(lo - a) * cols[q].w;
-            const uint8_t* sp = static_cast<const uint8_t*>(cols[q].src) + (size_t)lo * cols[q].w;
-            if (stream_stores) copy_stream(d, sp, (size_t)(hi - lo) * cols[q].w);
-            else memcpy(d, sp, (size_t)(hi - lo) * cols[q].w);
-        }
-        if (stream_stores) copy_stream_fence();
-    };
+    auto pack_piece = [&](int c, int t) { copy_cols(c, t, kColRo, NC); };       // (the offset columns of a non-canonical chunk)
     // piece t of T of chunk c's results: pinned memory -> the caller's arrays
     auto out_piece = [&](int c, int t) {
         const int64_t a = cb[(size_t)c], m = cb[(size_t)c + 1] - a;
@@ -394,7 +396,7 @@ int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_
                 check_piece(0, task - T);
             }
         });
-        if (bad_row.load() == INT64_MAX) pool.parallel_for(T, [&](int task) { pack_piece(0, task); });
+        if (bad_row.load() == INT64_MAX && !chunk_canon[0].load()) pool.parallel_for(T, [&](int task) { pack_piece(0, task); });
         ::memset(al + len, 0, 16);
         mark(0, "head_packed");
         // everything queued on the context stream so far (model uploads, an earlier resident pass ...) precedes the first copy:
@@ -491,7 +493,7 @@ int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_
         if (job_out >= 0) UGVC_HIP(hipEventSynchronize(ev_out(job_out)));
         mark(c, "job_start");
         if (job_pack >= 0 || job_out >= 0) pool.parallel_for(2 * T, job);
-        if (job_pack >= 0 && bad_row.load() == INT64_MAX) pool.parallel_for(T, job2);
+        if (job_pack >= 0 && bad_row.load() == INT64_MAX && !chunk_canon[(size_t)job_pack].load()) pool.parallel_for(T, job2);
         mark(c, "job_end");
     }
     if (bad_row.load() != INT64_MAX || rc) {
