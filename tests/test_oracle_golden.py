@@ -246,6 +246,18 @@ def test_xgboost_json_flattening():
         exp = np.array([b + np.float32(-0.4) + np.float32(-0.1), b + np.float32(0.6) + np.float32(0.3),
                         b + np.float32(0.6) + np.float32(0.2), b + np.float32(-0.4) + np.float32(0.2)], np.float32)
         assert np.array_equal(m, exp)
+    # newer writers store base_score as a one-entry vector; categorical splits and multi-target models are refused
+    import copy
+    d2 = copy.deepcopy(doc)
+    d2["learner"]["learner_model_param"]["base_score"] = "[2.5E-1]"
+    assert abs(model_io.flatten_xgb_json(d2).base_score - np.log(0.25 / 0.75)) < 1e-12
+    d2["learner"]["learner_model_param"]["base_score"] = "[2.5E-1,5E-1]"
+    with pytest.raises(ValueError, match="multi-target"):
+        model_io.flatten_xgb_json(d2)
+    d3 = copy.deepcopy(doc)
+    d3["learner"]["gradient_booster"]["model"]["trees"][0]["split_type"] = [1, 0, 0]
+    with pytest.raises(ValueError, match="categorical"):
+        model_io.flatten_xgb_json(d3)
 
 
 # ------------------------------------------------------------------ two restatements agree

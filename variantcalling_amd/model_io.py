@@ -170,7 +170,20 @@ def flatten_xgb_json(doc: dict | str) -> S.FlatForest:
     if isinstance(doc, str):
         doc = json.loads(doc)
     learner = doc["learner"]
-    base = float(learner["learner_model_param"]["base_score"])
+    bs = learner["learner_model_param"]["base_score"]
+    if isinstance(bs, str):                                     # "5E-1"; newer writers: "[5E-1]" (one entry per target)
+        inner = bs.strip().lstrip("[").rstrip("]").split(",")
+        if len(inner) != 1:
+            raise ValueError("multi-target XGBoost models are not supported (base_score has several entries)")
+        bs = inner[0]
+    elif isinstance(bs, (list, tuple)):
+        if len(bs) != 1:
+            raise ValueError("multi-target XGBoost models are not supported (base_score has several entries)")
+        bs = bs[0]
+    base = float(bs)
+    for tr in learner["gradient_booster"]["model"]["trees"]:
+        if tr.get("categories") or any(int(x) != 0 for x in tr.get("split_type", [])):
+            raise ValueError("categorical splits are not supported (the hot path's features are numeric)")
     base = min(max(base, 1e-7), 1 - 1e-7)
     margin0 = float(np.log(base / (1.0 - base)))
     feats, thrs, lefts, rights, roots, leaves = [], [], [], [], [], []
