@@ -152,6 +152,79 @@ __global__ __launch_bounds__(1024) void k_visit(uint32_t* out, uint64_t* cyc, in
     if (lane == 0) cyc[blockIdx.x * (blockDim.x >> 6) + (tid >> 6)] = t1 - t0;
 }
 
+// D (round 3, second try): no scalar register in the visit at all.  Node word = rank << 16 | plane offset; the code is read
+// into the HIGH half of a register (ds_read_u16_d16_hi: the low half is written as zero on sramecc parts), so
+//   d = node - code_hi   is negative  <=>  code > rank   (the plane offset in the low half cannot flip the sign),
+//   x' = v_alignbit(x, d, 31) = 2 x + (d < 0):
+// v_lshl_add (address), ds_read_b32, v_add_u16 (code address: planes below 64 KB), ds_read_u16_d16_hi, v_sub_u32, v_alignbit
+// = 12.8 cycles by the per-instruction table against 16.9 for A.  MODE 1: the same without the LDS reads.
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_visit_d(uint32_t* out, uint64_t* cyc, int iters) {
+    extern __shared__ uint32_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    // planes FIRST (16 waves x 22 x 128 bytes = 45056 bytes: addresses below 64 KB), the 8192 node words behind them
+    uint16_t* planes = reinterpret_cast<uint16_t*>(lds) + (tid >> 6) * 22 * 64;
+    for (int f = 0; f < 22; ++f) planes[f * 64 + lane] = (uint16_t)((tid * 131 + f * 977) & 0x7fff);
+    uint32_t* nodes = lds + 45056 / 4;
+    for (int q = tid; q < 8192; q += blockDim.x) nodes[q] = ((uint32_t)(0x2000 + (q * 37 & 0x3fff)) << 16) | ((uint32_t)((q * 7) % 22) * 128u);
+    __syncthreads();
+    const uint32_t nodes_b = (uint32_t)(uintptr_t)(LDSAS uint32_t*)nodes;
+    uint32_t planes_lane = (uint32_t)(uintptr_t)(LDSAS uint16_t*)planes + 2u * (uint32_t)lane;
+    uint32_t mask = 2047u;
+    asm volatile("" : "+v"(planes_lane), "+v"(mask));
+    uint32_t x[16];
+    const uint64_t t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) x[q] = 32u + q + (it & 1);
+        uint32_t c[16];                                     // (zeroed once per walk: the d16_hi reads only ever write the high halves)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) c[q] = 0;
+#pragma unroll
+        for (int lvl = 0; lvl < 6; ++lvl) {
+            uint32_t w[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                uint32_t ad;
+                asm volatile("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(ad) : "v"(x[q]), "s"(nodes_b));
+                w[q] = MODE == 1 ? ad : l32(ad);
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                uint32_t p;
+                asm volatile("v_add_u16 %0, %1, %2" : "=v"(p) : "v"(w[q]), "v"(planes_lane));
+                if (MODE == 1) c[q] = p << 16;
+                else asm volatile("ds_read_u16_d16_hi %0, %1" : "+v"(c[q]) : "v"(p));
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                if (MODE == 0) {
+                    // LDS returns in order: result q is there once at most 15 - q reads are outstanding
+                    switch (q) {
+                        case 0: asm volatile("s_waitcnt lgkmcnt(15)"); break; case 1: asm volatile("s_waitcnt lgkmcnt(14)"); break;
+                        case 2: asm volatile("s_waitcnt lgkmcnt(13)"); break; case 3: asm volatile("s_waitcnt lgkmcnt(12)"); break;
+                        case 4: asm volatile("s_waitcnt lgkmcnt(11)"); break; case 5: asm volatile("s_waitcnt lgkmcnt(10)"); break;
+                        case 6: asm volatile("s_waitcnt lgkmcnt(9)"); break; case 7: asm volatile("s_waitcnt lgkmcnt(8)"); break;
+                        case 8: asm volatile("s_waitcnt lgkmcnt(7)"); break; case 9: asm volatile("s_waitcnt lgkmcnt(6)"); break;
+                        case 10: asm volatile("s_waitcnt lgkmcnt(5)"); break; case 11: asm volatile("s_waitcnt lgkmcnt(4)"); break;
+                        case 12: asm volatile("s_waitcnt lgkmcnt(3)"); break; case 13: asm volatile("s_waitcnt lgkmcnt(2)"); break;
+                        case 14: asm volatile("s_waitcnt lgkmcnt(1)"); break; default: asm volatile("s_waitcnt lgkmcnt(0)"); break;
+                    }
+                }
+                uint32_t d;
+                asm volatile("v_sub_u32 %0, %1, %2" : "=v"(d) : "v"(w[q]), "v"(c[q]));
+                asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(x[q]) : "v"(d));
+                asm volatile("v_and_b32 %0, %0, %1" : "+v"(x[q]) : "v"(mask));
+            }
+        }
+    }
+    const uint64_t t1 = __builtin_readcyclecounter();
+    uint32_t r = 0;
+    for (int q = 0; q < 16; ++q) r ^= x[q];
+    out[blockIdx.x * blockDim.x + tid] = r;
+    if (lane == 0) cyc[blockIdx.x * (blockDim.x >> 6) + (tid >> 6)] = t1 - t0;
+}
+
 using K = void (*)(uint32_t*, uint64_t*, int);
 
 static void run(K k, const char* name, int waves_per_simd, double instr_per_rep, size_t lds = 0, int iters = 4000, double reps = 64) {
@@ -197,6 +270,10 @@ int main() {
     run(k_visit<2>, "visit C (B + 16-bit plane add)", 4, 1, lds, 400, 96);
     run(k_visit<3>, "visit A, VALU only (no LDS reads)", 4, 1, lds, 400, 96);
     run(k_visit<4>, "visit, LDS only (2 reads + 2 cheap)", 4, 1, lds, 400, 96);
+    run(k_visit_d<0>, "visit D (sub + alignbit, no SGPR)", 4, 1, lds, 400, 96);
+    run(k_visit_d<1>, "visit D, VALU only", 4, 1, lds, 400, 96);
+    run(k_visit<0>, "visit A (again)", 4, 1, lds, 400, 96);
+    run(k_visit_d<0>, "visit D (again)", 4, 1, lds, 400, 96);
     run(k_visit<0>, "visit A", 2, 1, lds, 400, 96);
     run(k_visit<3>, "visit A, VALU only", 2, 1, lds, 400, 96);
     run(k_visit<4>, "visit, LDS only", 2, 1, lds, 400, 96);
