@@ -92,6 +92,9 @@ const char* ugvc_last_error(void);
 int ugvc_ctx_create(int device_id, ugvc_ctx** out);
 int ugvc_ctx_destroy(ugvc_ctx* ctx);
 int ugvc_device_info(ugvc_ctx* ctx, char* name, int name_cap, int* n_cus, int64_t* hbm_bytes);
+/* One integer property of the context's device: what = 0 peak engine clock in kHz (hipDeviceProp_t::clockRate), 1 compute
+ * units, 2 peak memory clock in kHz, 3 LDS bytes per workgroup.  bench.py prices its instruction-issue floor with it. */
+int ugvc_device_attr(ugvc_ctx* ctx, int what, int64_t* out);
 int ugvc_sync(ugvc_ctx* ctx);
 
 /* ---- resident side tables --------------------------------------------------------------
@@ -129,7 +132,13 @@ int ugvc_model_clear(ugvc_ctx* ctx, int group);
 /* ---- the hot path ----------------------------------------------------------------------
  * ugvc_filter_variants: annotate_concordance + blacklist apply + model predict + FILTER
  *   (call pattern ugvc/pipelines/run_no_gt_report.py:92-94,314).
- *   Synchronous: H2D of the columns, one fused kernel, D2H of the three result columns.
+ *   Synchronous for the caller; inside, a chunk pipeline (csrc/pipeline.hip): host threads check and pack row chunks
+ *   into pinned slots while one DMA per chunk brings the previous one in, the scoring pass (one fused kernel per chunk;
+ *   two launches when the indel forests are handed to a second kernel) runs on it and one DMA brings its three result
+ *   columns back.  On return the callset and its results are resident, as after upload + ugvc_filter_resident.  On ANY
+ *   error the context is left empty (n = 0).  Host threads: the pool and the calling thread move to the GPU's NUMA node
+ *   for the duration of the call UNLESS the caller's affinity mask is already restricted (taskset, per-rank core
+ *   binding), which is respected; UGVC_NO_NUMA=1 switches the placement off.
  * Resident form (inputs stay in HBM; used by bench.py and for pipelining):
  *   ugvc_variants_upload -> ugvc_filter_resident (async launch) -> ugvc_results_download.
  * ugvc_timed_filter: `iters` back-to-back launches bracketed by hipEvents on the context
@@ -231,6 +240,9 @@ int ugvc_sec_db_build(ugvc_ctx* ctx, const uint64_t* keys, const int32_t* counts
                       uint64_t* out_keys, int32_t* out_expected, int64_t* out_n);
 int ugvc_sec_db_upload(ugvc_ctx* ctx, const uint64_t* keys, const int32_t* expected, int64_t n_db, int k);
 int ugvc_sec_apply(ugvc_ctx* ctx, double min_ratio, int scale_expected, int mark, double* ratio, uint8_t* is_sec);
+/* `iters` mark-only applications (as ugvc_sec_apply(..., mark = 1, NULL, NULL)) back to back between two events on the
+ * context stream: total milliseconds of kernel time. */
+int ugvc_timed_sec_apply(ugvc_ctx* ctx, double min_ratio, int scale_expected, int iters, float* ms_total);
 
 /* ---- is_homopolymer_snp + VAF gate (/root/reference/ugvc/pipelines/vcfbed/
  * calibrate_bridging_snvs.py:9-66,110-126): out_pass[i]=1 when the record is un-filtered. */

@@ -244,6 +244,26 @@ def test_old_scikit_learn_tree_state_is_read_as_data(tmp_path):
     assert np.array_equal(O.forest_predict(f, X[:400])[1], want)     # count-valued leaves normalised as 1.2's predict_proba does
 
 
+class _RaisesValueError:
+    """A pickle whose load raises a ValueError that has nothing to do with scikit-learn's tree state."""
+    def __reduce__(self):
+        return (int, ("not a number",))
+
+
+def test_unrelated_value_error_keeps_its_message(tmp_path):
+    """only `Tree.__setstate__`'s incompatible-array ValueError sends a pickle down the legacy path; any other
+    ValueError is raised as it is (once), not replaced by "no scikit-learn estimator found"."""
+    raw = pickle.dumps({"m": _RaisesValueError()})
+    path = str(tmp_path / "broken.model.pkl")
+    open(path, "wb").write(raw)
+    with pytest.raises(ValueError, match="invalid literal"):
+        model_io.load_model_file(path)
+    with pytest.raises(ValueError, match="invalid literal"):
+        legacy_pickle.load(raw)
+    assert legacy_pickle.is_tree_state_mismatch(ValueError("node array from the pickle has an incompatible dtype:\n- expected: x"))
+    assert not legacy_pickle.is_tree_state_mismatch(ValueError("invalid literal for int() with base 10: 'x'"))
+
+
 def test_model_file_maps_annotation_columns_by_bed_stem(tmp_path):
     """`load_model_file(..., track_names=...)` - what filter_variants_pipeline passes for --annotate_intervals -
     resolves a model's named interval column; without the stems the same file is refused by name."""

@@ -1,35 +1,55 @@
-"""Turn the rocprofv3 PMC passes of tools/gpu_profile.sh into profiles/hbm_traffic.json.
+"""Turn rocprofv3 PMC passes (tools/gpu_profile.sh) into one entry of profiles/hbm_traffic.json.
 
-HBM bytes per scoring pass = 2 x FETCH_SIZE + WRITE_SIZE summed over the kernels of the pass (counter
-unit: KB).  The factor 2 is the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md (FETCH_SIZE tallies
-128-byte requests at 64 bytes), re-measured here on known byte counts (tools/calib, profiles/r01_calibration.txt:
-0.500 x for 4- and 16-byte/lane streaming reads; WRITE_SIZE 1.000 x).
-Usage: python tools/make_traffic_json.py gpurun_out/prof_<tag> [profiles/hbm_traffic.json]"""
+HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE summed over the kernels of the workload (counter unit: KB).  The
+factor 2 is the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md (FETCH_SIZE tallies 128-byte requests at 64
+bytes), re-measured here on known byte counts (tools/calib, profiles/r01_calibration.txt: 0.500 x for 4- and
+16-byte/lane streaming reads; WRITE_SIZE 1.000 x).
+
+The file is keyed by what was measured - "<workload>:<units>:<world>", e.g. "filter:4999706:1", "c2:1000000:1",
+"pileup:5000000:1", "sec_apply:4999706:1", "c5_feature_build:2000000:1" - and bench.py prints `roofline.traffic` only for the
+key it is running (the 5 M-pass figure used to appear on every line).
+
+Usage: python tools/make_traffic_json.py <prof dir> --key filter:4999706:1 [--kernels substr,substr] [--dst profiles/hbm_traffic.json]"""
+import argparse
 import csv
 import glob
 import json
 import os
-import sys
 
-d = sys.argv[1]
-dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(__file__), "..", "profiles", "hbm_traffic.json")
+ap = argparse.ArgumentParser()
+ap.add_argument("dir")
+ap.add_argument("--key", required=True)
+ap.add_argument("--kernels", default="", help="comma-separated substrings: only kernels whose name contains one of them count")
+ap.add_argument("--dst", default=os.path.join(os.path.dirname(__file__), "..", "profiles", "hbm_traffic.json"))
+a = ap.parse_args()
+want = [k for k in a.kernels.split(",") if k]
 per = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    for f in glob.glob(os.path.join(d, f"pmc_{c}", "**", "*counter_collection.csv"), recursive=True):
+    for f in glob.glob(os.path.join(a.dir, f"pmc_{c}", "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0].replace("void ", "")       # template instantiations print a return type
-            if k.startswith("ugvc::"):
+            if k.startswith("ugvc::") and (not want or any(w in k for w in want)):
                 per.setdefault(k, {}).setdefault(c, []).append(float(r["Counter_Value"]))
 head = os.path.join(os.path.dirname(__file__), "..", "profiles", "HEAD")
-out = {"source": d, "commit": open(head).read().strip() if os.path.exists(head) else None,
-       "unit": "bytes per scoring pass (5 M variants, 1 GPU)", "fetch_correction": 2.0, "kernels": {}}
+entry = {"source": a.dir, "commit": open(head).read().strip() if os.path.exists(head) else None,
+         "unit": "HBM bytes per launch of the workload's kernels: 2 x FETCH_SIZE + WRITE_SIZE (KB counters), mean over the traced launches",
+         "kernels": {}}
 tot = 0.0
 for k, cs in sorted(per.items()):
     fk = sum(cs.get("FETCH_SIZE", [0])) / max(1, len(cs.get("FETCH_SIZE", [0])))
     wk = sum(cs.get("WRITE_SIZE", [0])) / max(1, len(cs.get("WRITE_SIZE", [0])))
     b = 2.0 * fk * 1024 + wk * 1024
-    out["kernels"][k] = {"FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "hbm_bytes": b}
+    entry["kernels"][k] = {"FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "hbm_bytes": b, "launches_traced": len(cs.get("FETCH_SIZE", []))}
     tot += b
-out["bytes_per_launch_5M"] = tot
-json.dump(out, open(dst, "w"), indent=1)
-print(json.dumps(out, indent=1))
+entry["bytes_per_launch"] = tot if per else None
+doc = {}
+if os.path.exists(a.dst):
+    try:
+        doc = json.load(open(a.dst))
+    except Exception:
+        doc = {}
+if "workloads" not in doc:
+    doc = {"fetch_correction": 2.0, "workloads": {}}
+doc["workloads"][a.key] = entry
+json.dump(doc, open(a.dst, "w"), indent=1)
+print(a.key, json.dumps(entry, indent=1))

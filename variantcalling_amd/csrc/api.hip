@@ -189,6 +189,20 @@ int ugvc_ctx_destroy(ugvc_ctx* ctx) {
     return 0;
 }
 
+int ugvc_device_attr(ugvc_ctx* ctx, int what, int64_t* out) {
+    if (!ctx || !out) return fail("NULL argument");
+    hipDeviceProp_t prop;
+    UGVC_HIP(hipGetDeviceProperties(&prop, ctx->device));
+    switch (what) {
+        case 0: *out = prop.clockRate; break;
+        case 1: *out = prop.multiProcessorCount; break;
+        case 2: *out = prop.memoryClockRate; break;
+        case 3: *out = (int64_t)prop.sharedMemPerBlock; break;
+        default: return fail("ugvc_device_attr: unknown attribute " + std::to_string(what));
+    }
+    return 0;
+}
+
 int ugvc_device_info(ugvc_ctx* ctx, char* name, int name_cap, int* n_cus, int64_t* hbm_bytes) {
     if (!ctx) return fail("ctx is NULL");
     hipDeviceProp_t prop;

@@ -488,4 +488,18 @@ int ugvc_sec_apply(ugvc_ctx* ctx, double min_ratio, int scale_expected, int mark
     return rc;
 }
 
+// `iters` mark-only applications back to back between two events on the context stream (what bench.py --workload sec_apply
+// reports: kernel time without the host's launch latency)
+int ugvc_timed_sec_apply(ugvc_ctx* ctx, double min_ratio, int scale_expected, int iters, float* ms_total) {
+    if (!ctx || !ms_total || iters < 1) return fail("bad arguments");
+    UGVC_HIP(hipSetDevice(ctx->device));
+    UGVC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    for (int it = 0; it < iters; ++it)
+        if (ugvc_sec_apply(ctx, min_ratio, scale_expected, 1, nullptr, nullptr)) return -1;
+    UGVC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    UGVC_HIP(hipEventSynchronize(ctx->ev1));
+    UGVC_HIP(hipEventElapsedTime(ms_total, ctx->ev0, ctx->ev1));
+    return 0;
+}
+
 }  // extern "C"

@@ -992,11 +992,11 @@ int launch_forest3(ugvc_ctx* ctx, const V2Args& v, const FilterArgs& a) {
         // trees in flight per lane: 8 (16 measured slower: 345 vs 324 us per 5M pass - the LDS pipeline, not
         // the dependent latency, bounds the walk); kernel variant bit 11 selects 16
         const K2 fn = !fast ? forest3_kernel<false, 8> : ((a.ablate & 2048) ? forest3_kernel<true, 16> : forest3_kernel<true, 8>);
-        static bool attr_set = false;
-        if (!attr_set) {
+        static bool attr_set[64] = {};                           // (function attributes are per device, as in kernels_v5.hip)
+        if (!attr_set[ctx->device & 63]) {
             for (K2 f : {(K2)forest3_kernel<false, 8>, (K2)forest3_kernel<true, 8>, (K2)forest3_kernel<true, 16>})
                 UGVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
-            attr_set = true;
+            attr_set[ctx->device & 63] = true;
         }
         hipLaunchKernelGGL(fn, dim3((unsigned)ctx->n_cus), dim3(n_waves * 64), lds, ctx->stream, v);
     }

@@ -652,7 +652,9 @@ int v5_fill_args(ugvc_ctx* ctx, V5Args& v, const FilterArgs& a, bool scoring) {
         p = PackedGroupView{};
         v.used5[gi] = 0;
         for (int f = 0; f < kMaxFeatures; ++f) v.cap5[gi][f] = 0;
-        if (!g.set || !g.ok5) continue;
+        // (a feature-matrix launch - scoring == false - ranks and walks nothing: no forest, no threshold table in its LDS
+        // budget, so a model the scoring pass would hand to v3 for size cannot make it fail)
+        if (!g.set || !g.ok5 || !scoring) continue;
         p.ok = 1; p.kind = g.kind; p.T = g.T; p.D = g.D; p.base = g.base; p.n_pairs = g.n_pairs;
         p.n_planes = kMaxFeatures;
         p.pairs = g.d_pairs.as<double2>();
@@ -666,8 +668,8 @@ int v5_fill_args(ugvc_ctx* ctx, V5Args& v, const FilterArgs& a, bool scoring) {
     }
     v.thr = s->thr.as<float>();
     v.desc3 = s->desc3.as<uint2>();
-    v.thr_lds_len = s->thr_lds_len;
-    v.thr0_len = s->thr0_len;
+    v.thr_lds_len = scoring ? s->thr_lds_len : 0;
+    v.thr0_len = scoring ? s->thr0_len : 0;
     v.thr_bits = 0;
     for (int gi = 1; gi < UGVC_N_GROUPS; ++gi)
         for (int f : {0, 1, 5}) {
@@ -675,7 +677,7 @@ int v5_fill_args(ugvc_ctx* ctx, V5Args& v, const FilterArgs& a, bool scoring) {
             v.thr_bits = std::max(v.thr_bits, m > 0 ? 32 - __builtin_clz((unsigned)m) : 0);
         }
     v.eyt = s->eyt.as<float>();
-    v.eyt_len = s->eyt_len;
+    v.eyt_len = scoring ? s->eyt_len : 0;
     v.gcr = s->gcr.as<uint16_t>();
     for (int k = 0; k < 3; ++k) { v.eyt_off[k] = s->eyt_off[k]; v.eyt_bits[k] = s->eyt_bits[k]; }
     v.css_lut = s->css.as<uint8_t>();

@@ -16,6 +16,7 @@
 // inside the whole callset; afterwards the context is in the same state as after upload + ugvc_filter_resident
 // (columns and results resident, `scored` set).
 #include <sched.h>
+#include <unistd.h>
 #include <string.h>
 
 #include <atomic>
@@ -227,8 +228,16 @@ int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_
         ps->numa = gpu_node_cpus(ctx->device, ps->node_cpus);
         ps->numa_known = true;
     }
+    // (a launcher's or user's CPU binding wins: when the calling thread's affinity mask is already restricted - taskset, a
+    // per-rank core binding - neither it nor the pool threads are moved; UGVC_NO_NUMA=1 switches the placement off)
     cpu_set_t mine;
-    const bool numa = ps->numa && sched_getaffinity(0, sizeof(mine), &mine) == 0;
+    bool numa = ps->numa && sched_getaffinity(0, sizeof(mine), &mine) == 0;
+    if (numa) {
+        const long online = sysconf(_SC_NPROCESSORS_ONLN);
+        cpu_set_t inter;
+        CPU_AND(&inter, &mine, &ps->node_cpus);
+        if ((online > 0 && CPU_COUNT(&mine) < online) || CPU_COUNT(&inter) == 0) numa = false;
+    }
     struct Restore {
         bool on; cpu_set_t set;
         ~Restore() { if (on) (void)sched_setaffinity(0, sizeof(set), &set); }
@@ -404,6 +413,22 @@ int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_
         UGVC_HIP(hipStreamSynchronize(ctx->stream));
         UGVC_HIP(hipMemcpyAsync(ctx->v_alleles.p, al, len + 16, hipMemcpyHostToDevice, ps->h2d));
     }
+    // every error exit below leaves the context EMPTY (earlier chunks have already been placed into the resident columns: a
+    // later ugvc_filter_resident / ugvc_results_download must not see a mixed callset) with the three streams idle - the
+    // pinned slots may still be in flight otherwise
+    struct Fail {
+        ugvc_ctx* c; PipeState* p; bool armed;
+        ~Fail() {
+            if (!armed) return;
+            (void)hipStreamSynchronize(p->h2d);
+            (void)hipStreamSynchronize(c->stream);
+            (void)hipStreamSynchronize(p->d2h);
+            c->n = 0; c->n_indel = 0; c->scored = 0; c->density_n = 0;
+        }
+    } fail_guard{ctx, ps, true};
+    // kernel selection (32-bit offset limits of v5 / fm5 / v3) is decided on THIS callset's size, not the previous one's
+    ctx->n = n;
+    ctx->scored = 0;
     FilterArgs base;
     if (build_args(ctx, base, false)) return -1;
     mark(-1, "args");
@@ -501,8 +526,6 @@ int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipStreamSynchronize(ps->d2h);
         if (rc) return -1;
-        ctx->n = 0;
-        ctx->scored = 0;
         // (name the row again on this thread: two pieces may have reported different rows at the same time)
         int64_t i = bad_row.load(), ind = 0, row = i;
         const int what = validate_rows(v, i, i + 1, n_contigs, &ind, &row);
@@ -527,6 +550,7 @@ int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_
                     fprintf(stderr, "[pipe] dev chunk %d %s %.3f\n", c, names[q], ms);
             }
     }
+    fail_guard.armed = false;
     ctx->n = n;
     ctx->n_indel = n_indel_total;
     ctx->scored = 1;

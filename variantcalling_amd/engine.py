@@ -50,6 +50,7 @@ ABI = {
     "ugvc_ctx_create": (C.c_int, [C.c_int, C.POINTER(_ctx)]),
     "ugvc_ctx_destroy": (C.c_int, [_ctx]),
     "ugvc_device_info": (C.c_int, [_ctx, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
+    "ugvc_device_attr": (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_int64)]),
     "ugvc_sync": (C.c_int, [_ctx]),
     "ugvc_ref_upload": (C.c_int, [_ctx, _u8p, C.c_int64, _i64p, C.c_int]),
     "ugvc_runs_upload": (C.c_int, [_ctx, _i32p, _i32p, _i32p, C.c_int64, C.c_int, C.c_int, C.c_int]),
@@ -85,6 +86,7 @@ ABI = {
     "ugvc_sec_db_build": (C.c_int, [_ctx, _u64p, _i32p, C.c_int64, C.c_int, _u64p, _i32p, _i64p]),
     "ugvc_sec_db_upload": (C.c_int, [_ctx, _u64p, _i32p, C.c_int64, C.c_int]),
     "ugvc_sec_apply": (C.c_int, [_ctx, C.c_double, C.c_int, C.c_int, _f64p, _u8p]),
+    "ugvc_timed_sec_apply": (C.c_int, [_ctx, C.c_double, C.c_int, C.c_int, _f32p]),
     "ugvc_bridging_snvs": (C.c_int, [_ctx, C.POINTER(CVariants), _u8p, _i32p, _i32p, _i32p,
                                      C.POINTER(CBridgingParams), _u8p, _u8p]),
     "ugvc_timed_feature_matrix": (C.c_int, [_ctx, C.c_int, _f32p]),
@@ -169,6 +171,12 @@ class Engine:
         cus, mem = C.c_int(), C.c_int64()
         self._check(self.lib.ugvc_device_info(self._h, name, 256, C.byref(cus), C.byref(mem)))
         return dict(name=name.value.decode(), n_cus=cus.value, hbm_bytes=mem.value)
+
+    def device_attr(self, what: str) -> int:
+        """One integer property of the device: "clock_khz", "n_cus", "mem_clock_khz", "lds_bytes"."""
+        out = C.c_int64()
+        self._check(self.lib.ugvc_device_attr(self._h, ("clock_khz", "n_cus", "mem_clock_khz", "lds_bytes").index(what), C.byref(out)))
+        return int(out.value)
 
     def sync(self):
         self._check(self.lib.ugvc_sync(self._h))
@@ -444,6 +452,12 @@ class Engine:
         return ratio, hit.astype(bool)
 
     # ---- calibrate_bridging_snvs
+    def timed_sec_apply(self, iters: int, min_ratio: float = 0.05, scale_expected: bool = True) -> float:
+        """Total milliseconds of `iters` mark-only SEC applications (device events on the context stream)."""
+        ms = C.c_float()
+        self._check(self.lib.ugvc_timed_sec_apply(self._h, float(min_ratio), int(scale_expected), int(iters), C.byref(ms)))
+        return float(ms.value)
+
     def bridging_snvs(self, vt: S.VariantTable, is_pass, ad_alt_sum, bg_ad_alt_sum, bg_dp,
                       min_query_hmer_size=5, min_initial_qual=5, min_tumor_vaf=0.2, max_normal_vaf=0.1,
                       min_normal_depth=10, min_distance_from_edge=0):

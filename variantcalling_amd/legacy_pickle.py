@@ -82,13 +82,24 @@ class _ShimUnpickler(pickle.Unpickler):
         return _holder_class(module, name)
 
 
+def is_tree_state_mismatch(exc: BaseException) -> bool:
+    """scikit-learn's `Tree.__setstate__` refusing the node / value arrays of another generation's pickle (the messages of
+    sklearn/tree/_tree.pyx: "node array from the pickle has an incompatible dtype", "... value array ...", "Wrong dimensions
+    for node array from the pickle")."""
+    msg = str(exc)
+    return isinstance(exc, ValueError) and "from the pickle" in msg and ("array" in msg or "n_classes" in msg)
+
+
 def load(path_or_bytes):
     """The object graph of a pickle, absent classes as Holders."""
     raw = path_or_bytes if isinstance(path_or_bytes, (bytes, bytearray)) else open(path_or_bytes, "rb").read()
     try:
         return _ShimUnpickler(io.BytesIO(raw)).load()
-    except ValueError:
-        # an estimator pickled by another scikit-learn generation: keep the compiled trees as data (see above)
+    except ValueError as exc:
+        # an estimator pickled by another scikit-learn generation: keep the compiled trees as data (see above).  Any OTHER
+        # ValueError (a corrupt or unrelated pickle) is the caller's to see as it is, not after a second unpickling.
+        if not is_tree_state_mismatch(exc):
+            raise
         up = _ShimUnpickler(io.BytesIO(raw))
         up.hold_trees = True
         return up.load()

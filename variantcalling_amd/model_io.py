@@ -326,11 +326,14 @@ def load_model_file(path: str, model_name: str | None = None, track_names: list 
         try:
             with open(path, "rb") as fh:
                 raw = pickle.load(fh)
-        except (ImportError, AttributeError, ValueError):
+        except (ImportError, AttributeError, ValueError) as exc:
             # a pickle of the reference's own model classes (ugbio_filtering.*, absent here), or of estimators of another
-            # scikit-learn generation (ValueError from Tree.__setstate__): read the data without the classes and pull
-            # the estimators out of the object graph (legacy_pickle.py)
+            # scikit-learn generation (ValueError from Tree.__setstate__ - and only that ValueError: a corrupt pickle keeps
+            # its own message): read the data without the classes and pull the estimators out of the object graph
+            # (legacy_pickle.py)
             from . import legacy_pickle
+            if isinstance(exc, ValueError) and not legacy_pickle.is_tree_state_mismatch(exc):
+                raise
             raw = legacy_pickle.find_estimators(legacy_pickle.load(path), S.GROUP_NAMES)
             if not raw:
                 raise ValueError(f"{path}: no scikit-learn estimator found in the pickle")
