@@ -256,7 +256,30 @@ class SynthCallset:
 
 def make_callset(n_variants: int, genome_len: int | None = None, seed: int = 20260116,
                  snv_only: bool = False, n_contigs: int = 24) -> SynthCallset:
-    """C2 (snv_only) / C3 callset; side tables scale with N/5M so per-variant bytes are fixed."""
+    """C2 (snv_only) / C3 callset; side tables scale with N/5M so per-variant bytes are fixed.
+    UGVC_SYNTH_CACHE=<dir> (measurement scripts only): the generated callset is kept there as a pickle and re-read by later
+    processes - a profiling session runs bench.py a dozen times on the same 5 M-variant callset, ~50 s of generation each."""
+    cache = os.environ.get("UGVC_SYNTH_CACHE")
+    if cache:
+        import pickle
+        path = os.path.join(cache, f"callset_{n_variants}_{genome_len}_{seed}_{int(snv_only)}_{n_contigs}.pkl")
+        if os.path.exists(path):
+            with open(path, "rb") as fh:
+                return pickle.load(fh)
+        os.environ.pop("UGVC_SYNTH_CACHE")
+        try:
+            cs = make_callset(n_variants, genome_len, seed, snv_only, n_contigs)
+        finally:
+            os.environ["UGVC_SYNTH_CACHE"] = cache
+        try:
+            os.makedirs(cache, exist_ok=True)
+            tmp = path + f".{os.getpid()}.tmp"
+            with open(tmp, "wb") as fh:
+                pickle.dump(cs, fh, protocol=5)
+            os.replace(tmp, path)
+        except OSError:
+            pass
+        return cs
     if genome_len is None:
         genome_len = int(HG38_LENGTHS.sum() * min(1.0, n_variants / 5_000_000))
         genome_len = max(genome_len, 2_000_000)
