@@ -1143,35 +1143,46 @@ template <int NTM>
 __device__ __forceinline__ void walk_forest(const PackedGroupView& pg, uint32_t hi_b, uint32_t last_b, uint32_t p1_b,
                                             uint32_t planes_lane_b, float& score, uint8_t& filt) {
     const int T = pg.T, D = pg.D, H = (1 << D) >> 1;
+    // The p1 table sits at LDS address 0 (first table of the image, no static __shared__ in either kernel - both trap at
+    // entry otherwise): a payload IS the address of the leaf's class-1 probability.  (Written as `p1_b + payload` the add
+    // survives as `v_add 0`: the LDS address is assigned after the optimiser has run.)
+    (void)p1_b;
+    // (the last level's entry of heap node I is I - T H: the subtraction is folded into the table's base)
+    const uint32_t last_base = (uint32_t)rfl((int)(last_b - 8u * (uint32_t)(T * H)));
+    const uint32_t* __restrict__ roots = pg.roots;
     double a1 = 0.0;
     int t = 0;
+    auto one_tree = [&](int tt) -> uint32_t {
+        if (D == 1) return stump_payload(last_b, planes_lane_b, tt);
+        uint32_t pi[1];
+        walk6<1>(hi_b, last_base, planes_lane_b, roots, tt, T, D, pi);
+        return pi[0];
+    };
+    if (D > 1) {
     if (NTM > 8) {
         // more trees in flight per lane: in the fused kernel only part of a CU's waves walk at any time, so a walking
         // wave has to keep more LDS requests outstanding to fill the pipeline
         for (; t + NTM <= T; t += NTM) {
             uint32_t pi[NTM];
-            walk4<NTM>(hi_b, last_b, planes_lane_b, t, D, H, pi);
+            walk6<NTM>(hi_b, last_base, planes_lane_b, roots, t, T, D, pi);
             double pv[NTM];
 #pragma unroll
-            for (int q = 0; q < NTM; ++q) pv[q] = lds_f64(p1_b + 8u * pi[q]);
+            for (int q = 0; q < NTM; ++q) pv[q] = lds_f64(pi[q]);
 #pragma unroll
             for (int q = 0; q < NTM; ++q) a1 += pv[q];
         }
     }
     for (; t + 8 <= T; t += 8) {
         uint32_t pi[8];
-        walk4<8>(hi_b, last_b, planes_lane_b, t, D, H, pi);
+        walk6<8>(hi_b, last_base, planes_lane_b, roots, t, T, D, pi);
         double pv[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) pv[q] = lds_f64(p1_b + 8u * pi[q]);
+        for (int q = 0; q < 8; ++q) pv[q] = lds_f64(pi[q]);
 #pragma unroll
         for (int q = 0; q < 8; ++q) a1 += pv[q];
     }
-    for (; t < T; ++t) {
-        uint32_t pi[1];
-        walk4<1>(hi_b, last_b, planes_lane_b, t, D, H, pi);
-        a1 += lds_f64(p1_b + 8u * pi[0]);
     }
+    for (; t < T; ++t) a1 += lds_f64(one_tree(t));
     const double half = 0.5 * (double)T, band = pg.band;
     score = (float)(a1 / (double)T);
     filt = a1 > half ? UGVC_FILTER_PASS : UGVC_FILTER_LOW_SCORE;
@@ -1180,14 +1191,36 @@ __device__ __forceinline__ void walk_forest(const PackedGroupView& pg, uint32_t 
     if (__builtin_amdgcn_ballot_w64(fabs(a1 - half) <= band) != 0) {
         double b0 = 0.0, b1 = 0.0;
         for (int tt = 0; tt < T; ++tt) {
-            uint32_t pi[1];
-            walk4<1>(hi_b, last_b, planes_lane_b, tt, D, H, pi);
-            const double2 pv = pg.pairs[pi[0]];
+            const double2 pv = pg.pairs[one_tree(tt) >> 3];
             b0 += pv.x; b1 += pv.y;
         }
         const double q0 = b0 / (double)T, q1 = b1 / (double)T;
         if (fabs(a1 - half) <= band) filt = q1 > q0 ? UGVC_FILTER_PASS : UGVC_FILTER_LOW_SCORE;
     }
+}
+
+// A forest's three tables (hi | last | p1, each padded to 16 bytes) -> one contiguous LDS image, 16 bytes per thread and
+// trip.  The first KB trips' loads are ALL issued before the first store: written as a plain loop with a three-way source
+// select the copy ran one dependent round trip per trip (six for the 91 KB SNP forest: ~9 us of every launch at any size).
+template <int KB>
+__device__ __forceinline__ void fill_forest_lds(unsigned char* dst, const uint4* s0, size_t n0, const uint4* s1, size_t n1, const uint4* s2,
+                                                size_t n2, int tid, int nthreads) {
+    const size_t total = n0 + n1 + n2;
+    uint4* d = reinterpret_cast<uint4*>(dst);
+    auto src = [&](size_t q) -> const uint4* { return q < n0 ? s0 + q : (q < n0 + n1 ? s1 + (q - n0) : s2 + (q - n0 - n1)); };
+    uint4 r[KB];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+        const size_t q = (size_t)tid + (size_t)k * nthreads;
+        r[k] = make_uint4(0, 0, 0, 0);
+        if (q < total) r[k] = *src(q);
+    }
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+        const size_t q = (size_t)tid + (size_t)k * nthreads;
+        if (q < total) d[q] = r[k];
+    }
+    for (size_t q = (size_t)tid + (size_t)KB * nthreads; q < total; q += nthreads) d[q] = *src(q);
 }
 
 // LDS of a workgroup: group forest (hi | last | p1, 16-byte padded) | group 0's level-order threshold trees | the
@@ -1203,24 +1236,15 @@ __device__ __forceinline__ Lds5 lds5_fill(unsigned char* smem, const V5Args& v, 
     const size_t n_hi = with_forest ? ((size_t)pg.T << pg.D) / 2 : 0;
     const size_t b_hi = (n_hi * 4 + 15) & ~(size_t)15, b_last = (n_hi * 8 + 15) & ~(size_t)15;
     const size_t b_p1 = with_forest ? (((size_t)pg.n_pairs * 8 + 15) & ~(size_t)15) : 0;
-    L.hi_b = lds_addr(smem);
-    L.last_b = lds_addr(smem + b_hi);
-    L.p1_b = lds_addr(smem + b_hi + b_last);
+    // (p1 FIRST: its base is a compile-time LDS address - the walk's final read takes the payload as its address and the
+    // base in the instruction's offset field)
+    L.p1_b = lds_addr(smem);
+    L.hi_b = lds_addr(smem + b_p1);
+    L.last_b = lds_addr(smem + b_p1 + b_hi);
     off = b_hi + b_last + b_p1;
-    if (with_forest) {
-        const uint4* s0 = reinterpret_cast<const uint4*>(pg.hi4);
-        const uint4* s1 = reinterpret_cast<const uint4*>(pg.last4);
-        const uint4* s2 = reinterpret_cast<const uint4*>(pg.p1);
-        uint4* d0 = reinterpret_cast<uint4*>(smem);
-        uint4* d1 = reinterpret_cast<uint4*>(smem + b_hi);
-        uint4* d2 = reinterpret_cast<uint4*>(smem + b_hi + b_last);
-        const size_t n0 = b_hi / 16, n1 = b_last / 16, n2 = b_p1 / 16;
-        for (size_t q = tid; q < n0 + n1 + n2; q += nthreads) {
-            if (q < n0) d0[q] = s0[q];
-            else if (q < n0 + n1) d1[q - n0] = s1[q - n0];
-            else d2[q - n0 - n1] = s2[q - n0 - n1];
-        }
-    }
+    if (with_forest)
+        fill_forest_lds<6>(smem, reinterpret_cast<const uint4*>(pg.p1), b_p1 / 16, reinterpret_cast<const uint4*>(pg.hi4), b_hi / 16,
+                           reinterpret_cast<const uint4*>(pg.last4), b_last / 16, tid, nthreads);
     float* eyt_l = reinterpret_cast<float*>(smem + off);
     for (int q = tid; q < v.eyt_len / 4; q += nthreads) reinterpret_cast<float4*>(eyt_l)[q] = reinterpret_cast<const float4*>(v.eyt)[q];
     L.eyt_b = lds_addr(eyt_l);
@@ -1280,7 +1304,6 @@ static size_t lds5_bytes(const V5Args& v, int n_waves) {
 template <int NTRK, int NTW, bool WX = false>
 __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ unsigned wcnt[2][kK2Threads / 64];
     constexpr int NT = 1 + NTRK;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = rfl(tid >> 6);
@@ -1289,6 +1312,7 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
 #ifdef UGVC_PHASE_CLOCK
     const uint64_t k_begin = __builtin_readcyclecounter();
 #endif
+    if (lds_addr(smem) != 0u) __builtin_trap();                  // (walk_forest: payloads are absolute LDS addresses)
     const int64_t r0 = (int64_t)blockIdx.x * v.rows_wg;
     if (r0 >= a.n) return;                                       // (uniform: before the first barrier)
     const int64_t r1 = min(r0 + (int64_t)v.rows_wg, a.n);
@@ -1302,34 +1326,46 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
     const int64_t m = (r1 - r0 + n_waves - 1) / n_waves;
     const int64_t w0 = r0 + (int64_t)wave * m, w1 = min(w0 + m, r1);
     constexpr int U = 8;
-    int rl0[U], al0[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int64_t r = w0 + 64 * u + lane;
-        rl0[u] = al0[u] = -1;
-        if (r < w1) { rl0[u] = a.ref_len[r]; al0[u] = a.alt_len[r]; }
-    }
-    const Lds5 L = lds5_fill(smem, v, has0, tid, blockDim.x, !WX);
-    unsigned cs = 0, ci = 0;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        cs += (unsigned)__popcll(__ballot(rl0[u] >= 0 && rl0[u] == al0[u]));
-        ci += (unsigned)__popcll(__ballot(rl0[u] >= 0 && rl0[u] != al0[u]));
-    }
-    for (int64_t g = w0 + 64 * U; g < w1; g += 64 * U) {
-        int rl[U], al[U];
+    // The lane's class in each of the wave's first 32 groups of 64 rows, two bits per group (bit 0 substitution, bit 1
+    // indel): the list pass below reads them back instead of the columns (round 3 re-read every group but the first
+    // eight: two more dependent round trips of a 5 M-variant launch's prologue).
+    uint32_t cls[2] = {0u, 0u};
+    int rl[U], al[U];
+    auto load_classes = [&](int64_t g, int (&x)[U], int (&y)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t r = g + 64 * u + lane;
-            rl[u] = al[u] = -1;
-            if (r < w1) { rl[u] = a.ref_len[r]; al[u] = a.alt_len[r]; }
+            x[u] = y[u] = -1;
+            if (r < w1) { x[u] = a.ref_len[r]; y[u] = a.alt_len[r]; }
         }
+    };
+    load_classes(w0, rl, al);                                    // (requested BEFORE the LDS fill: their round trip runs under it)
+    const Lds5 L = lds5_fill(smem, v, has0, tid, blockDim.x, !WX);
+    unsigned cs = 0, ci = 0;
+    {
+        int gi = 0;
+        for (int64_t g = w0;; g += 64 * U, gi += U) {
+            int rln[U], aln[U];
+            const bool more = g + 64 * U < w1;
+            if (more) load_classes(g + 64 * U, rln, aln);        // the next batch is in flight while this one is counted
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            cs += (unsigned)__popcll(__ballot(rl[u] >= 0 && rl[u] == al[u]));
-            ci += (unsigned)__popcll(__ballot(rl[u] >= 0 && rl[u] != al[u]));
+            for (int u = 0; u < U; ++u) {
+                const bool snp = rl[u] >= 0 && rl[u] == al[u], ind = rl[u] >= 0 && rl[u] != al[u];
+                cs += (unsigned)__popcll(__ballot(snp));
+                ci += (unsigned)__popcll(__ballot(ind));
+                const int k = gi + u;
+                const uint32_t two = (snp ? 1u : 0u) | (ind ? 2u : 0u);
+                if (k < 16) cls[0] |= two << (2 * k);
+                else if (k < 32) cls[1] |= two << (2 * (k - 16));
+            }
+            if (!more) break;
+#pragma unroll
+            for (int u = 0; u < U; ++u) { rl[u] = rln[u]; al[u] = aln[u]; }
         }
     }
+    // (no static __shared__ in this kernel: the dynamic LDS then starts at address 0, the forest's p1 table with it, and the
+    // walk's final read needs no base added to its payload - ugvc_walk.hpp: walk6; the per-wave counts live behind gtab)
+    unsigned (*wcnt)[kK2Threads / 64] = reinterpret_cast<unsigned (*)[kK2Threads / 64]>(smem + (L.gtab_b - lds_addr(smem)) + 128);
     if (lane == 0) { wcnt[0][wave] = cs; wcnt[1][wave] = ci; }
     __syncthreads();
     unsigned ps = 0, pi = 0, ns_l = 0, ni_l = 0;
@@ -1344,27 +1380,26 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
     uint32_t* __restrict__ li = v.indel_idx + (size_t)blockIdx.x * v.list_stride;
     {
         const unsigned long long below = (1ull << lane) - 1;
-        for (int64_t g = w0; g < w1; g += 64 * U) {
-            int rl[U], al[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int64_t r = g + 64 * u + lane;
-                rl[u] = rl0[u]; al[u] = al0[u];
-                if (g != w0) {
-                    rl[u] = al[u] = -1;
-                    if (r < w1) { rl[u] = a.ref_len[r]; al[u] = a.alt_len[r]; }
-                }
+        int gi = 0;
+        for (int64_t g = w0; g < w1; g += 64, ++gi) {
+            bool snp, ind;
+            if (gi < 32) {
+                const uint32_t two = (cls[gi >> 4] >> (2 * (gi & 15))) & 3u;
+                snp = (two & 1u) != 0;
+                ind = (two & 2u) != 0;
+            } else {                                             // (a wave with more than 2048 rows: a launch of > 8 M variants)
+                const int64_t r = g + lane;
+                int x = -1, y = -1;
+                if (r < w1) { x = a.ref_len[r]; y = a.alt_len[r]; }
+                snp = x >= 0 && x == y;
+                ind = x >= 0 && x != y;
             }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const bool snp = rl[u] >= 0 && rl[u] == al[u], ind = rl[u] >= 0 && rl[u] != al[u];
-                const unsigned long long ms = __ballot(snp), mi = __ballot(ind);
-                const uint32_t r = (uint32_t)(g + 64 * u + lane);
-                if (snp) ls[ps + (unsigned)__popcll(ms & below)] = r;
-                if (ind) li[pi + (unsigned)__popcll(mi & below)] = r;
-                ps += (unsigned)__popcll(ms);
-                pi += (unsigned)__popcll(mi);
-            }
+            const unsigned long long ms = __ballot(snp), mi = __ballot(ind);
+            const uint32_t r = (uint32_t)(g + lane);
+            if (snp) ls[ps + (unsigned)__popcll(ms & below)] = r;
+            if (ind) li[pi + (unsigned)__popcll(mi & below)] = r;
+            ps += (unsigned)__popcll(ms);
+            pi += (unsigned)__popcll(mi);
         }
         if (wave == n_waves - 1) {                               // padding of the last tile of either list
             ls[ns_l + lane] = ~0u;
@@ -1537,8 +1572,10 @@ __global__ __launch_bounds__(kK2Threads) void forest5_kernel(const V5Args v) {
     uint64_t f_ready = 0, f_walk = 0, f_last = 0;
     int f_chunks = 0;
 #endif
-    __shared__ unsigned shard_off[kShards + 1];
-    __shared__ unsigned totals[UGVC_N_GROUPS];
+    // (no static __shared__: see fused5_kernel; the launch adds 1088 bytes behind the forest and the code planes for these)
+    if (lds_addr(smem) != 0u) __builtin_trap();                  // (walk_forest: payloads are absolute LDS addresses)
+    unsigned* const shard_off = reinterpret_cast<unsigned*>(smem + v.forest_lds_tail);       // [kShards + 1]
+    unsigned* const totals = shard_off + kShards + 4;                                         // [UGVC_N_GROUPS]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int n_waves = blockDim.x >> 6;
@@ -1597,22 +1634,10 @@ __global__ __launch_bounds__(kK2Threads) void forest5_kernel(const V5Args v) {
     const size_t n_hi = (size_t)pg.T * H;
     const size_t b_hi = (n_hi * 4 + 15) & ~(size_t)15, b_last = (n_hi * 8 + 15) & ~(size_t)15;
     const size_t b_p1 = ((size_t)pg.n_pairs * 8 + 15) & ~(size_t)15;
-    {
-        const uint4* s0 = reinterpret_cast<const uint4*>(pg.hi4);
-        const uint4* s1 = reinterpret_cast<const uint4*>(pg.last4);
-        const uint4* s2 = reinterpret_cast<const uint4*>(pg.p1);
-        uint4* d0 = reinterpret_cast<uint4*>(smem);
-        uint4* d1 = reinterpret_cast<uint4*>(smem + b_hi);
-        uint4* d2 = reinterpret_cast<uint4*>(smem + b_hi + b_last);
-        const size_t n0 = b_hi / 16, n1 = b_last / 16, n2 = b_p1 / 16;
-        for (size_t q = tid; q < n0 + n1 + n2; q += blockDim.x) {
-            if (q < n0) d0[q] = s0[q];
-            else if (q < n0 + n1) d1[q - n0] = s1[q - n0];
-            else d2[q - n0 - n1] = s2[q - n0 - n1];
-        }
-    }
+    fill_forest_lds<6>(smem, reinterpret_cast<const uint4*>(pg.p1), b_p1 / 16, reinterpret_cast<const uint4*>(pg.hi4), b_hi / 16,
+                       reinterpret_cast<const uint4*>(pg.last4), b_last / 16, tid, blockDim.x);
     __syncthreads();
-    const uint32_t hi_b = lds_addr(smem), last_b = lds_addr(smem + b_hi), p1_b = lds_addr(smem + b_hi + b_last);
+    const uint32_t p1_b = lds_addr(smem), hi_b = lds_addr(smem + b_p1), last_b = lds_addr(smem + b_p1 + b_hi);
     const int hslot = ((lane & 31) << 1) | (lane >> 5);
     const uint32_t planes_b = lds_addr(smem + b_hi + b_last + b_p1) + (uint32_t)(wave * kMaxFeatures * 128);
     const uint32_t planes_lane_b = planes_b + 2u * (uint32_t)hslot;
@@ -1690,10 +1715,6 @@ using K5 = void (*)(const V5Args);
 // 16 trees in flight per lane (8 measured 4 % slower: 506 vs 485 us; kernel variant bit 28 selects 8 for the 3-track kernel)
 static K5 fused5_for(int n_tracks, bool narrow = false) {
     if (narrow && n_tracks == 3) return fused5_kernel<3, 8>;
-    static const int ntw = getenv("UGVC_NTW") ? atoi(getenv("UGVC_NTW")) : 0;          // (profiling: trees in flight, 3-track kernel)
-    if (n_tracks == 3 && ntw == 10) return fused5_kernel<3, 10>;
-    if (n_tracks == 3 && ntw == 20) return fused5_kernel<3, 20>;
-    if (n_tracks == 3 && ntw == 12) return fused5_kernel<3, 12>;
     switch (n_tracks) {
         case 0: return fused5_kernel<0, 16>;
         case 1: return fused5_kernel<1, 16>;
@@ -1780,7 +1801,8 @@ int launch_filter_v5(ugvc_ctx* ctx, const FilterArgs& a) {
             if (need + 1088 <= 158 * 1024) { n_waves = w; lds = need; break; }
         }
         if (n_waves == 0) return fail("internal: packed forest does not fit LDS");
-        hipLaunchKernelGGL(forest5_kernel, dim3((unsigned)ctx->n_cus), dim3(n_waves * 64), lds, ctx->stream, v);
+        v.forest_lds_tail = (int)lds;
+        hipLaunchKernelGGL(forest5_kernel, dim3((unsigned)ctx->n_cus), dim3(n_waves * 64), lds + 1088, ctx->stream, v);
         if (step("forest5")) return -1;
     }
     UGVC_HIP(hipGetLastError());

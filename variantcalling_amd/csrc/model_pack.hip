@@ -18,11 +18,11 @@ struct V2Group {
     std::vector<uint16_t> leaf_idx;
     std::vector<double> pairs;
     std::vector<float> leaf_f32;
-    std::vector<uint32_t> hi5, last5;   // v5: raw-code node tables in the single-sum layout
+    std::vector<uint32_t> hi5, last5, roots5;   // v5: raw-code node tables, one heap over all trees (pack_group5)
     int cap5[kMaxFeatures];
     uint32_t used5 = 0;
     bool ok5 = false;
-    DeviceBuf d_hi5, d_last5;
+    DeviceBuf d_hi5, d_last5, d_roots5;
     std::vector<uint32_t> hi4;          // single-sum layout (ugvc_v2.hpp)
     std::vector<uint32_t> last4;        // 2 dwords per entry
     std::vector<double> p1;
@@ -74,13 +74,13 @@ void v2_destroy(ugvc_ctx* ctx) {
     for (auto& r : s->rec) if (r.p) (void)hipFree(r.p);
     for (auto& r : s->rec5) if (r.p) (void)hipFree(r.p);
     for (auto& g : s->g)
-        for (DeviceBuf* b : {&g.d_nodes, &g.d_leaf_idx, &g.d_pairs, &g.d_leaf_f32, &g.d_plane_desc, &g.d_hi4, &g.d_last4, &g.d_p1, &g.d_hi5, &g.d_last5}) if (b->p) (void)hipFree(b->p);
+        for (DeviceBuf* b : {&g.d_nodes, &g.d_leaf_idx, &g.d_pairs, &g.d_leaf_f32, &g.d_plane_desc, &g.d_hi4, &g.d_last4, &g.d_p1, &g.d_hi5, &g.d_last5, &g.d_roots5}) if (b->p) (void)hipFree(b->p);
     delete s;
     ctx->v2 = nullptr;
 }
 
 static void release_group(V2Group& g) {          // device tables of the previous model of this group, then a clean slate
-    for (DeviceBuf* b : {&g.d_nodes, &g.d_leaf_idx, &g.d_pairs, &g.d_leaf_f32, &g.d_plane_desc, &g.d_hi4, &g.d_last4, &g.d_p1, &g.d_hi5, &g.d_last5})
+    for (DeviceBuf* b : {&g.d_nodes, &g.d_leaf_idx, &g.d_pairs, &g.d_leaf_f32, &g.d_plane_desc, &g.d_hi4, &g.d_last4, &g.d_p1, &g.d_hi5, &g.d_last5, &g.d_roots5})
         if (b->p) (void)hipFree(b->p);
     g = V2Group();
 }
@@ -261,14 +261,28 @@ static bool pack_group5(V2Group& g) {
     const size_t H = (size_t)1 << (D - 1);
     std::vector<uint32_t> nodes5((size_t)T << D, 0xFFFFu);      // padded node: rank 65535 on plane 0 -> always left
     for (int t = 0; t < T; ++t) fill_dense5(g, nodes5, t, g.roots[t], 1);
+    // Round 4: ONE heap over all trees of the group.  Node (tree t, level d, position j in the level) sits at dword
+    // I = (T + t) 2^d + j - the T roots are the nodes T .. 2T-1 of a heap whose top is virtual - so a child is 2 I + c for
+    // EVERY tree: the walk carries I alone, one scalar base serves all trees in flight (round 3: one per tree, sixteen
+    // SGPRs of a kernel that spills them), and the roots are consecutive dwords a scalar load brings in (roots5, padded:
+    // a batch of 16 trees is one 64-byte s_load).  Levels 0 .. D-2 live in hi5[T H] (entries below T unused), level D-1 in
+    // last5 as {node word, left payload | right payload << 16}, entry I - T H = t H + j.  A payload is the BYTE offset
+    // 8 * (index of the leaf's class-1 probability in p1): p1 is the first table of the LDS image, so the payload is the
+    // address of the final 8-byte read (the instruction's offset field carries the table's base) - one vector instruction
+    // less per tree; hence n_pairs <= 8192 (any forest that fits the LDS has fewer: 12 T H + 8 n_pairs bytes).
+    if (g.n_pairs > 8192) return false;
     g.hi5.assign((size_t)T * H, 0xFFFFu);
     g.last5.assign((size_t)T * H * 2, 0u);
+    g.roots5.assign(((size_t)T + 15) / 16 * 16 + 16, 0xFFFFu);
     for (int t = 0; t < T; ++t) {
-        for (size_t i = 1; i < H; ++i) g.hi5[(size_t)t * H + i] = nodes5[((size_t)t << D) + i];
+        for (int d = 0; d + 1 < D; ++d)
+            for (size_t j = 0; j < ((size_t)1 << d); ++j)
+                g.hi5[(((size_t)T + t) << d) + j] = nodes5[((size_t)t << D) + ((size_t)1 << d) + j];
+        g.roots5[(size_t)t] = nodes5[((size_t)t << D) + 1];
         for (size_t e = 0; e < H; ++e) {
             g.last5[2 * ((size_t)t * H + e)] = nodes5[((size_t)t << D) + H + e];
-            g.last5[2 * ((size_t)t * H + e) + 1] = (uint32_t)g.leaf_idx[((size_t)t << D) + 2 * e] |
-                                                  ((uint32_t)g.leaf_idx[((size_t)t << D) + 2 * e + 1] << 16);
+            g.last5[2 * ((size_t)t * H + e) + 1] = (uint32_t)g.leaf_idx[((size_t)t << D) + 2 * e] * 8u |
+                                                  (((uint32_t)g.leaf_idx[((size_t)t << D) + 2 * e + 1] * 8u) << 16);
         }
     }
     g.hi5.resize((g.hi5.size() + 3) & ~(size_t)3, 0xFFFFu);
@@ -479,6 +493,7 @@ int finalize_pack(ugvc_ctx* ctx) {
                 if (g.ok5) {
                     if (upload(ctx, g.d_hi5, g.hi5.data(), g.hi5.size() * 4)) return -1;
                     if (upload(ctx, g.d_last5, g.last5.data(), g.last5.size() * 4)) return -1;
+                    if (upload(ctx, g.d_roots5, g.roots5.data(), g.roots5.size() * 4)) return -1;
                 }
             } else if (upload(ctx, g.d_leaf_f32, g.leaf_f32.data(), g.leaf_f32.size() * 4)) return -1;
         }
@@ -662,6 +677,7 @@ int v5_fill_args(ugvc_ctx* ctx, V5Args& v, const FilterArgs& a, bool scoring) {
         p.band = g.band4;
         p.hi4 = g.d_hi5.as<uint32_t>();
         p.last4 = g.d_last5.as<uint2>();
+        p.roots = g.d_roots5.as<uint32_t>();
         p.p1 = g.d_p1.as<double>();
         v.used5[gi] = g.used5;
         for (int f = 0; f < kMaxFeatures; ++f) v.cap5[gi][f] = g.cap5[f];

@@ -56,6 +56,7 @@ struct PackedGroupView {
     const uint32_t* hi4;          // T * 2^(D-1)
     const uint2* last4;           // T * 2^(D-1)
     const double* p1;             // n_pairs
+    const uint32_t* roots;        // v5 (round 4): the T root node words, 64-byte aligned, padded to whole batches of 16
 };
 
 struct V2Args {
@@ -92,7 +93,7 @@ constexpr int kRec5Dwords = 12;               // raw record: 20 codes (u16, by f
 constexpr int kTile5 = 64;                    // variants per tile = one wave
 constexpr int kMinRowsWg5 = 1024;             // a workgroup of the fused kernel owns at least this many rows
 constexpr int kJoin5 = UGVC_MAX_TRACKS + 2;   // runs, tracks, blacklist
-constexpr int kGtabBytes = 128;               // LDS: per indel group clamps + float slice descriptors
+constexpr int kGtabBytes = 256;               // LDS: per indel group clamps + float slice descriptors (128 B) | the prologue's per-wave class counts (128 B)
 constexpr int kBlCap5 = 64;                   // staged blacklist keys per SNP tile
 
 struct V5Args {
@@ -128,6 +129,7 @@ struct V5Args {
     int n_waves;
     int n_indel_waves;                   // waves of a fused workgroup that work on indel tiles
     int indel_w;                         // cost of an indel tile relative to an SNP tile, in 1/256 (the wave role split follows it)
+    int forest_lds_tail;                 // forest5_kernel: byte offset of its shard-offset / total words in the dynamic LDS
 };
 
 int v5_fill_args(ugvc_ctx* ctx, V5Args& v, const FilterArgs& a, bool scoring = true);

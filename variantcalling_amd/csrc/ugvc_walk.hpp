@@ -195,4 +195,79 @@ __device__ __forceinline__ void walk4(uint32_t hi_b, uint32_t last_b, uint32_t p
     for (int k = 0; k < NT; ++k) pidx[k] = pick_half(code[k], wl[k].x, wl[k].y);
 }
 
+// ---- round 4: the walk over ONE heap for all trees of a group (model_pack.hip: pack_group5) -------------------------
+// Node (tree t, level d, position j) = dword I = (T + t) 2^d + j of the `hi` table, child = 2 I + c for every tree: the
+// state of a walk is I alone and one scalar base serves all trees in flight.  The ROOT words of the batch come from a scalar
+// load (wave-uniform: no LDS read, no per-lane address), I after the root = 2 (T + t + k) + c is one v_addc with the tree's
+// offset as an inline constant; the last level's payload IS the byte offset of the leaf's class-1 probability in p1.
+typedef uint32_t u32x16_t __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x8_t __attribute__((ext_vector_type(8)));
+#define UGVC_CONST_AS __attribute__((address_space(4)))
+
+template <int K2>
+__device__ __forceinline__ uint32_t base_plus_const_plus_carry(uint32_t base, unsigned long long mask) {
+    uint32_t out;
+    unsigned long long cout;
+    asm("v_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(out), "=s"(cout) : "v"(base), "n"(K2), "s"(mask));
+    return out;
+}
+
+template <int NT>
+__device__ __forceinline__ void walk6(uint32_t hi_b, uint32_t last_base, uint32_t planes_lane_b, const uint32_t* roots, int t, int T, int D,
+                                      uint32_t (&pay)[NT]) {
+    static_assert(NT <= 16, "sixteen trees in flight at most (inline constants of the root step)");
+    uint32_t I[NT];
+    {                                                            // (D >= 2: a depth-1 forest is walked by stump_payload)
+        uint32_t rw[NT];
+        if constexpr (NT == 16) {
+            const u32x16_t r = *(const UGVC_CONST_AS u32x16_t*)(uintptr_t)(roots + t);      // (t is a multiple of 16: 64-byte aligned)
+#pragma unroll
+            for (int k = 0; k < NT; ++k) rw[k] = r[k];
+        } else if constexpr (NT == 8) {
+            const u32x8_t r = *(const UGVC_CONST_AS u32x8_t*)(uintptr_t)(roots + t);        // (t is a multiple of 8)
+#pragma unroll
+            for (int k = 0; k < NT; ++k) rw[k] = r[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < NT; ++k) rw[k] = *(const UGVC_CONST_AS uint32_t*)(uintptr_t)(roots + t + k);
+        }
+        uint32_t code[NT];
+#pragma unroll
+        for (int k = 0; k < NT; ++k) code[k] = lds_u16(planes_lane_b + (rw[k] >> 16));
+        const uint32_t vb2 = 2u * (uint32_t)(T + t);
+        unsigned long long m[NT];
+#pragma unroll
+        for (int k = 0; k < NT; ++k) m[k] = __builtin_amdgcn_ballot_w64(code[k] > (rw[k] & 0xFFFFu));
+#define UGVC_ROOT_STEP(K) if constexpr (NT > K) I[K] = base_plus_const_plus_carry<2 * K>(vb2, m[K]);
+        UGVC_ROOT_STEP(0) UGVC_ROOT_STEP(1) UGVC_ROOT_STEP(2) UGVC_ROOT_STEP(3) UGVC_ROOT_STEP(4) UGVC_ROOT_STEP(5) UGVC_ROOT_STEP(6) UGVC_ROOT_STEP(7)
+        UGVC_ROOT_STEP(8) UGVC_ROOT_STEP(9) UGVC_ROOT_STEP(10) UGVC_ROOT_STEP(11) UGVC_ROOT_STEP(12) UGVC_ROOT_STEP(13) UGVC_ROOT_STEP(14) UGVC_ROOT_STEP(15)
+#undef UGVC_ROOT_STEP
+    }
+    for (int d = 1; d < D - 1; ++d) {
+        uint32_t w[NT], code[NT];
+#pragma unroll
+        for (int k = 0; k < NT; ++k) w[k] = lds_u32(hi_b + 4u * I[k]);
+#pragma unroll
+        for (int k = 0; k < NT; ++k) code[k] = lds_u16(planes_lane_b + (w[k] >> 16));
+#pragma unroll
+        for (int k = 0; k < NT; ++k)
+            I[k] = twice_plus_carry(I[k], __builtin_amdgcn_ballot_w64(code[k] > (w[k] & 0xFFFFu)));
+    }
+    uint2 wl[NT];
+    uint32_t code[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) wl[k] = lds_u32x2(last_base + 8u * I[k]);
+#pragma unroll
+    for (int k = 0; k < NT; ++k) code[k] = lds_u16(planes_lane_b + (wl[k].x >> 16));
+#pragma unroll
+    for (int k = 0; k < NT; ++k) pay[k] = pick_half(code[k], wl[k].x, wl[k].y);
+}
+
+// a forest of depth 1: the root is the last level (entry t of the `last` table)
+__device__ __forceinline__ uint32_t stump_payload(uint32_t last_b, uint32_t planes_lane_b, int t) {
+    const uint2 wl = lds_u32x2(last_b + 8u * (uint32_t)t);
+    const uint32_t code = lds_u16(planes_lane_b + (wl.x >> 16));
+    return pick_half(code, wl.x, wl.y);
+}
+
 }  // namespace ugvc
