@@ -1,5 +1,5 @@
 cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
 rm -rf /tmp/clk && mkdir -p /tmp/clk && cp -r variantcalling_amd oracle include profiles tests bench.py /tmp/clk/ 2>/dev/null
 ( cd /tmp/clk/variantcalling_amd/csrc && touch kernels_v5.hip && make EXTRA=-DUGVC_PHASE_CLOCK -j8 > /tmp/clk/build.log 2>&1; tail -2 /tmp/clk/build.log )
-( cd /tmp/clk && python bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-e2e $CLK_ARGS 2>&1 | grep -E "^clk|^iclk|^fclk|issue" | sort | head -16 ) > gpurun_out/r02_phase_clocks.txt
-cat gpurun_out/r02_phase_clocks.txt
+( cd /tmp/clk && python bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-e2e $CLK_ARGS 2>&1 | grep -E "^clk|^iclk|^fclk|issue" | sort | head -60 ) > gpurun_out/${CLK_OUT:-r04_phase_clocks.txt}
+cat gpurun_out/${CLK_OUT:-r04_phase_clocks.txt}

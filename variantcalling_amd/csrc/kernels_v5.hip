@@ -36,6 +36,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <vector>
 
 #include "ugvc_walk.hpp"
 
@@ -1202,25 +1203,43 @@ __device__ __forceinline__ void walk_forest(const PackedGroupView& pg, uint32_t 
 // A forest's three tables (hi | last | p1, each padded to 16 bytes) -> one contiguous LDS image, 16 bytes per thread and
 // trip.  The first KB trips' loads are ALL issued before the first store: written as a plain loop with a three-way source
 // select the copy ran one dependent round trip per trip (six for the 91 KB SNP forest: ~9 us of every launch at any size).
+// The first KB trips' loads are ALL issued before the first store, UNPREDICATED (indices clamped into the tables, sources
+// chosen by selects): a load under `if (q < total)` compiles to a branch with `s_waitcnt vmcnt(0)` behind it - one dependent
+// round trip per trip, six for the 91 KB SNP forest, ~9 us of every launch at any size (round 3, and the first version of
+// this function).  ForestLoads keeps the pieces between issue() and store() so that other loads can be issued in between.
+template <int KB>
+struct ForestLoads {
+    uint4 r[KB];
+    __device__ __forceinline__ void issue(const uint4* s0, size_t n0, const uint4* s1, size_t n1, const uint4* s2, size_t n2, int tid, int nthreads) {
+        const size_t total = n0 + n1 + n2;
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+            size_t q = (size_t)tid + (size_t)k * nthreads;
+            q = q < total ? q : (total ? total - 1 : 0);
+            const uint4* p = q < n0 ? s0 + q : (q < n0 + n1 ? s1 + (q - n0) : s2 + (q - n0 - n1));
+            r[k] = total ? *p : make_uint4(0, 0, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void store(unsigned char* dst, const uint4* s0, size_t n0, const uint4* s1, size_t n1, const uint4* s2, size_t n2, int tid,
+                                          int nthreads) const {
+        const size_t total = n0 + n1 + n2;
+        uint4* d = reinterpret_cast<uint4*>(dst);
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+            const size_t q = (size_t)tid + (size_t)k * nthreads;
+            if (q < total) d[q] = r[k];
+        }
+        for (size_t q = (size_t)tid + (size_t)KB * nthreads; q < total; q += nthreads)
+            d[q] = q < n0 ? s0[q] : (q < n0 + n1 ? s1[q - n0] : s2[q - n0 - n1]);
+    }
+};
+
 template <int KB>
 __device__ __forceinline__ void fill_forest_lds(unsigned char* dst, const uint4* s0, size_t n0, const uint4* s1, size_t n1, const uint4* s2,
                                                 size_t n2, int tid, int nthreads) {
-    const size_t total = n0 + n1 + n2;
-    uint4* d = reinterpret_cast<uint4*>(dst);
-    auto src = [&](size_t q) -> const uint4* { return q < n0 ? s0 + q : (q < n0 + n1 ? s1 + (q - n0) : s2 + (q - n0 - n1)); };
-    uint4 r[KB];
-#pragma unroll
-    for (int k = 0; k < KB; ++k) {
-        const size_t q = (size_t)tid + (size_t)k * nthreads;
-        r[k] = make_uint4(0, 0, 0, 0);
-        if (q < total) r[k] = *src(q);
-    }
-#pragma unroll
-    for (int k = 0; k < KB; ++k) {
-        const size_t q = (size_t)tid + (size_t)k * nthreads;
-        if (q < total) d[q] = r[k];
-    }
-    for (size_t q = (size_t)tid + (size_t)KB * nthreads; q < total; q += nthreads) d[q] = *src(q);
+    ForestLoads<KB> f;
+    f.issue(s0, n0, s1, n1, s2, n2, tid, nthreads);
+    f.store(dst, s0, n0, s1, n1, s2, n2, tid, nthreads);
 }
 
 // LDS of a workgroup: group forest (hi | last | p1, 16-byte padded) | group 0's level-order threshold trees | the
@@ -1241,26 +1260,51 @@ __device__ __forceinline__ Lds5 lds5_fill(unsigned char* smem, const V5Args& v, 
     L.p1_b = lds_addr(smem);
     L.hi_b = lds_addr(smem + b_p1);
     L.last_b = lds_addr(smem + b_p1 + b_hi);
+    // ---- every global load of the fill is issued here, unpredicated, before the first LDS store (round 4: each table used to
+    // be its own load -> wait -> store loop, ~8 dependent round trips in front of the first tile)
+    ForestLoads<6> fl;
+    fl.issue(reinterpret_cast<const uint4*>(pg.p1), b_p1 / 16, reinterpret_cast<const uint4*>(pg.hi4), b_hi / 16,
+             reinterpret_cast<const uint4*>(pg.last4), b_last / 16, tid, nthreads);
+    const int n_eyt4 = v.eyt_len / 4;
+    const float4 r_eyt = n_eyt4 > 0 ? reinterpret_cast<const float4*>(v.eyt)[min(tid, n_eyt4 - 1)] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int n_thr = v.thr_lds_len - v.thr0_len;                                          // groups 1 and 2
+    constexpr int KT = 4;                                                                  // (kThr3 = 3584 floats at most: four per thread)
+    float r_thr[KT];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) r_thr[k] = n_thr > 0 ? v.thr[v.thr0_len + min(tid + k * nthreads, n_thr - 1)] : 0.f;
+    const uint32_t r_gcr = model_tables ? reinterpret_cast<const uint32_t*>(v.gcr)[min(tid, kGcRankBytes / 4 - 1)] : 0u;
+    const uint8_t r_css = v.css_lut[min(tid, 255)];
+    uint2 r_desc = make_uint2(0u, 0u);
+    {
+        const int q = min(max(tid - 64, 0), 5), g = 1 + q / 3, sfeat = q % 3;
+        const int fj = sfeat == 0 ? 0 : (sfeat == 1 ? 1 : 5);
+        if (model_tables) r_desc = v.desc3[g * kMaxFeatures + fj];      // (wave-uniform condition: no per-lane branch, no wait behind it)
+    }
+    // ---- the stores
     off = b_hi + b_last + b_p1;
     if (with_forest)
-        fill_forest_lds<6>(smem, reinterpret_cast<const uint4*>(pg.p1), b_p1 / 16, reinterpret_cast<const uint4*>(pg.hi4), b_hi / 16,
-                           reinterpret_cast<const uint4*>(pg.last4), b_last / 16, tid, nthreads);
+        fl.store(smem, reinterpret_cast<const uint4*>(pg.p1), b_p1 / 16, reinterpret_cast<const uint4*>(pg.hi4), b_hi / 16,
+                 reinterpret_cast<const uint4*>(pg.last4), b_last / 16, tid, nthreads);
     float* eyt_l = reinterpret_cast<float*>(smem + off);
-    for (int q = tid; q < v.eyt_len / 4; q += nthreads) reinterpret_cast<float4*>(eyt_l)[q] = reinterpret_cast<const float4*>(v.eyt)[q];
+    if (tid < n_eyt4) reinterpret_cast<float4*>(eyt_l)[tid] = r_eyt;
+    for (int q = tid + nthreads; q < n_eyt4; q += nthreads) reinterpret_cast<float4*>(eyt_l)[q] = reinterpret_cast<const float4*>(v.eyt)[q];
     L.eyt_b = lds_addr(eyt_l);
     off += (size_t)v.eyt_len * 4;
     float* thr_l = reinterpret_cast<float*>(smem + off);
-    const int n_thr = v.thr_lds_len - v.thr0_len;                                          // groups 1 and 2
-    for (int q = tid; q < n_thr; q += nthreads) thr_l[q + (q >> 5)] = v.thr[v.thr0_len + q];   // skewed: element j at j + (j >> 5)
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+        const int q = tid + k * nthreads;
+        if (q < n_thr) thr_l[q + (q >> 5)] = r_thr[k];                                     // skewed: element j at j + (j >> 5)
+    }
+    for (int q = tid + KT * nthreads; q < n_thr; q += nthreads) thr_l[q + (q >> 5)] = v.thr[v.thr0_len + q];
     L.thr_b = lds_addr(thr_l);
     off += ((size_t)(n_thr + (n_thr >> 5) + 1) * 4 + 15) & ~(size_t)15;
     uint16_t* gcr = reinterpret_cast<uint16_t*>(smem + off);
-    if (model_tables)
-        for (int q = tid; q < kGcRankBytes / 4; q += nthreads) reinterpret_cast<uint32_t*>(gcr)[q] = reinterpret_cast<const uint32_t*>(v.gcr)[q];   // (built on the host: model_pack.hip)
+    if (model_tables && tid < kGcRankBytes / 4) reinterpret_cast<uint32_t*>(gcr)[tid] = r_gcr;   // (built on the host: model_pack.hip)
     L.gcr_b = lds_addr(gcr);
     off += kGcRankBytes;
     uint8_t* css = smem + off;
-    for (int q = tid; q < 256; q += nthreads) css[q] = v.css_lut[q];
+    if (tid < 256) css[tid] = r_css;
     L.css_b = lds_addr(css);
     off += 256;
     // per indel group: the clamps of the integer features (u16 [2][16]) and the (offset, length) of the three float
@@ -1268,11 +1312,9 @@ __device__ __forceinline__ Lds5 lds5_fill(unsigned char* smem, const V5Args& v, 
     unsigned char* gtab = smem + off;
     if (tid < 32) reinterpret_cast<uint16_t*>(gtab)[tid] = (uint16_t)v.cap5[1 + (tid >> 4)][tid & 15];
     if (model_tables && tid >= 64 && tid < 70) {
-        const int q = tid - 64, g = 1 + q / 3, sfeat = q % 3;
-        const int fj = sfeat == 0 ? 0 : (sfeat == 1 ? 1 : 5);
-        const uint2 d = v.desc3[g * kMaxFeatures + fj];
-        reinterpret_cast<uint32_t*>(gtab + 64)[2 * q] = (d.x & 0xFFFFFu) - (uint32_t)v.thr0_len;      // the staged table starts at group 1
-        reinterpret_cast<uint32_t*>(gtab + 64)[2 * q + 1] = d.y & 0xFFFFu;
+        const int q = tid - 64;
+        reinterpret_cast<uint32_t*>(gtab + 64)[2 * q] = (r_desc.x & 0xFFFFFu) - (uint32_t)v.thr0_len;      // the staged table starts at group 1
+        reinterpret_cast<uint32_t*>(gtab + 64)[2 * q + 1] = r_desc.y & 0xFFFFu;
     }
     L.gtab_b = lds_addr(gtab);
     off += kGtabBytes;
@@ -1313,6 +1355,7 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
     const uint64_t k_begin = __builtin_readcyclecounter();
 #endif
     if (lds_addr(smem) != 0u) __builtin_trap();                  // (walk_forest: payloads are absolute LDS addresses)
+    const uint64_t wclk_entry = v.wave_clk ? __builtin_readcyclecounter() : 0;
     const int64_t r0 = (int64_t)blockIdx.x * v.rows_wg;
     if (r0 >= a.n) return;                                       // (uniform: before the first barrier)
     const int64_t r1 = min(r0 + (int64_t)v.rows_wg, a.n);
@@ -1431,6 +1474,7 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
         const int64_t q = (nit + n_iw - 1) / n_iw;
         const int64_t t0 = (int64_t)(wave - n_sw) * q, t1 = min(t0 + q, nit);
         if (t0 >= t1) return;
+        const uint64_t wclk_first = v.wave_clk ? __builtin_readcyclecounter() : 0;
         PhaseClk pc{};
 #ifdef UGVC_PHASE_CLOCK
         pc.last = __builtin_readcyclecounter();
@@ -1476,8 +1520,12 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
             ++n_done;
 #endif
         }
+        if (v.wave_clk && lane == 0) {
+            unsigned long long* w = v.wave_clk + ((size_t)blockIdx.x * 16 + wave) * 4;
+            w[0] = wclk_entry; w[1] = wclk_first; w[2] = __builtin_readcyclecounter(); w[3] = (unsigned long long)(t1 - t0) | ((unsigned long long)(t1 - t0) << 32);
+        }
 #ifdef UGVC_PHASE_CLOCK
-        if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 133) && wave == n_waves - 1)
+        if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 133))
             printf("iclk b%d w%d tiles %d total %llu | load+window %llu hmer+motif %llu joins %llu codes+record %llu (ranks %llu)\n", (int)blockIdx.x, wave, n_done,
                    (unsigned long long)(pc.last - t_begin), (unsigned long long)pc.acc[0], (unsigned long long)pc.acc[1], (unsigned long long)pc.acc[2],
                    (unsigned long long)pc.acc[3], (unsigned long long)pc.acc[6]);
@@ -1487,6 +1535,7 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
     const int64_t q = (nst + n_sw - 1) / n_sw;
     const int64_t t0 = (int64_t)wave * q, t1 = min(t0 + q, nst);
     if (t0 >= t1) return;
+    const uint64_t wclk_first = v.wave_clk ? __builtin_readcyclecounter() : 0;
     auto ids_of = [&](int64_t t, uint32_t& i, bool& live) {
         const uint32_t id = ls[t * 64 + lane];
         live = id != ~0u;
@@ -1553,8 +1602,12 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
         ++n_done;
 #endif
     }
+    if (v.wave_clk && lane == 0) {
+        unsigned long long* w = v.wave_clk + ((size_t)blockIdx.x * 16 + wave) * 4;
+        w[0] = wclk_entry; w[1] = wclk_first; w[2] = __builtin_readcyclecounter(); w[3] = (unsigned long long)(t1 - t0);
+    }
 #ifdef UGVC_PHASE_CLOCK
-    if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 133) && (wave == 0 || wave == 7))
+    if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 133))
         printf("clk b%d w%d tiles %d total %llu | stage %llu window %llu joins %llu codes %llu cols_n %llu walk %llu\n", (int)blockIdx.x, wave, n_done,
                (unsigned long long)(pc.last - t_begin), (unsigned long long)pc.acc[0], (unsigned long long)pc.acc[1], (unsigned long long)pc.acc[2],
                (unsigned long long)pc.acc[3], (unsigned long long)pc.acc[4], (unsigned long long)pc.acc[5]);
@@ -1786,11 +1839,27 @@ int launch_filter_v5(ugvc_ctx* ctx, const FilterArgs& a) {
         fprintf(stderr, "ok\n");
         return 0;
     };
+    // UGVC_WAVE_CLK=<file>: every wave of the fused kernel leaves its entry / first-tile / end clocks and its tile counts; the
+    // buffer of the LAST pass is written to the file (tools/wave_clk.py reads it).  Waits for every pass: profiling only.
+    static const char* wclk_path = getenv("UGVC_WAVE_CLK");
+    static DeviceBuf wclk_buf;
+    const size_t wclk_bytes = (size_t)((a.n + v.rows_wg - 1) / v.rows_wg) * 16 * 4 * 8;
+    if (wclk_path) {
+        if (ensure(wclk_buf, wclk_bytes)) return -1;
+        UGVC_HIP(hipMemsetAsync(wclk_buf.p, 0, wclk_bytes, ctx->stream));
+        v.wave_clk = wclk_buf.as<unsigned long long>();
+    }
     const size_t lds_f = lds5_bytes(v, v.n_waves);
     if (dbg) fprintf(stderr, "[ugvc v5] fused5: %d waves (%d indel), %zu B of LDS\n", v.n_waves, v.n_indel_waves, lds_f);
     const unsigned n_wg = (unsigned)((a.n + v.rows_wg - 1) / v.rows_wg);
     hipLaunchKernelGGL(fused5_for(a.n_tracks, (a.ablate & (1 << 28)) != 0), dim3(n_wg), dim3(v.n_waves * 64), lds_f, ctx->stream, v);
     if (step("fused5")) return -1;
+    if (wclk_path) {
+        std::vector<unsigned long long> h(wclk_bytes / 8);
+        UGVC_HIP(hipMemcpyAsync(h.data(), wclk_buf.p, wclk_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        UGVC_HIP(hipStreamSynchronize(ctx->stream));
+        if (FILE* f = fopen(wclk_path, "wb")) { fwrite(h.data(), 1, wclk_bytes, f); fclose(f); }
+    }
     if (v.run_forest) {
         int n_waves = 0;
         size_t lds = 0;
