@@ -512,16 +512,17 @@ def test_c5_leaf_matrix_gemm(engine, small_callset, frozen_models):
     for g in range(S.N_GROUPS):
         rows = np.flatnonzero(group == g).astype(np.int32)
         exp_margin, exp_score = O.forest_predict(forests[g], X[rows])
-        for mfma in (True, False):
+        for mfma in (1, 2, 0):                                   # round-4 kernel (lane = row predicates), round-1 kernel, traversal
             got, ms = engine.forest_gemm(g, rows, use_mfma=mfma)
             assert np.array_equal(got, exp_margin), (g, mfma, np.flatnonzero(got != exp_margin)[:5])
             assert ms > 0
     # all rows with one group's model, ragged tail (n not a multiple of 16), tiny inputs
     got, _ = engine.forest_gemm(0, None, use_mfma=True)
     assert np.array_equal(got, O.forest_predict(forests[0], X)[0])
-    for k in (1, 15, 17):
-        got, _ = engine.forest_gemm(2, np.arange(k, dtype=np.int32), use_mfma=True)
-        assert np.array_equal(got, O.forest_predict(forests[2], X[:k])[0])
+    for k in (1, 15, 17, 63, 64, 65, 129):                       # (tiles of 64 rows in the round-4 kernel, of 16 in the round-1 one)
+        for mfma in (1, 2):
+            got, _ = engine.forest_gemm(2, np.arange(k, dtype=np.int32), use_mfma=mfma)
+            assert np.array_equal(got, O.forest_predict(forests[2], X[:k])[0]), (k, mfma)
     # RF / deep trees are refused, not approximated
     _configure(engine, cs.ref, cs.runs, cs.tracks, cs.blacklist, frozen_models[RF])
     engine.feature_matrix(cs.variants)

@@ -115,6 +115,153 @@ __global__ __launch_bounds__(kGemmThreads) void forest_gemm_kernel(const GemmArg
     }
 }
 
+// ---- round 4: the same GEMM, predicates without LDS gathers ---------------------------------------------------------
+// forest_gemm_kernel above builds a row's 64 predicates in four lanes, sixteen each, every one with an LDS read of the node
+// and an LDS GATHER of the feature value (the node's feature differs between the four lane groups): ~34 LDS + ~90 vector
+// instructions per tree and 16-row tile feed four MFMAs - 203 int8-TOP/s, 0.04 of the matrix cores' rate.
+// Here a lane owns ONE ROW of a 64-row tile for the predicates: its F feature values sit in a register vector, a tree's 63
+// (threshold, feature) pairs are wave-uniform - scalar loads - so a predicate is: feature value by REGISTER INDEX (the index is
+// in a scalar register: s_set_gpr_idx / v_movrels, no LDS), one compare against the scalar threshold, one byte-select write
+// into the lane's 64-byte predicate vector.  The vector goes through the wave's LDS scratch once per tree (row-major, 80-byte
+// rows) and comes back in the MFMA operand layout for the four 16-row tiles.  The product is formed TRANSPOSED - leaves x rows,
+// D = C^T t^T + (-popcount(leaf)) - so that a lane holds sixteen leaves of ONE row per leaf block, the exit leaf (D == 0) is
+// picked by a compare + select per element and reduced over the four lanes of its row; the margin is added by the row's own
+// lane, in tree order: bit-identical to the traversal and the oracle (same compares, same f32 adds).
+typedef float f32x32_t __attribute__((ext_vector_type(32)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+constexpr int kGemm2Threads = 512;
+constexpr int kGemm2RowB = 80;          // bytes per staged predicate row (64 + 16: conflict-free 16-byte accesses)
+
+// byte K of `a` := (the lane goes RIGHT at the node) ? 1 : 0 - right = !(x <= thr) for scikit-learn forests, !(x < thr) for
+// XGBoost-style ensembles (a NaN feature goes right in both, as in the traversal kernel's compares).  x = xv[fidx]: the compare
+// reads the feature vector by REGISTER INDEX (VGPR index mode on its first source: xv's first register + fidx) - no move, no LDS.
+// `xv` is passed as an operand of its own so that the 32 registers stay live and contiguous; `x0` is its element 0 - the
+// listing is checked for `x0` being the tuple's first register (tests/ would fail bit-exactness otherwise).
+// (s_set_gpr_idx_on writes M0, which clang reserves and warns about when it is clobbered; nothing else in this kernel uses M0)
+#pragma clang diagnostic ignored "-Winline-asm"
+#define UGVC_PRED_ASM(CMP, BYTE)                                                                                          \
+    asm("s_set_gpr_idx_on %5, gpr_idx(SRC0)\n\t" CMP " vcc, %4, %3\n\ts_set_gpr_idx_off\n\t"                              \
+        "v_cndmask_b32_sdwa %0, %1, %2, vcc dst_sel:" BYTE " dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"   \
+        : "+v"(a) : "v"(zero), "v"(one), "s"(thr), "v"(x0), "s"(fidx), "v"(xv) : "vcc", "m0")
+template <int K, bool RF>
+__device__ __forceinline__ void pred_byte(uint32_t& a, const f32x32_t& xv, int fidx, float thr, uint32_t zero, uint32_t one) {
+    const float x0 = xv[0];
+    if constexpr (RF) {
+        if constexpr (K == 0) UGVC_PRED_ASM("v_cmp_nle_f32_e64", "BYTE_0");
+        if constexpr (K == 1) UGVC_PRED_ASM("v_cmp_nle_f32_e64", "BYTE_1");
+        if constexpr (K == 2) UGVC_PRED_ASM("v_cmp_nle_f32_e64", "BYTE_2");
+        if constexpr (K == 3) UGVC_PRED_ASM("v_cmp_nle_f32_e64", "BYTE_3");
+    } else {
+        if constexpr (K == 0) UGVC_PRED_ASM("v_cmp_nlt_f32_e64", "BYTE_0");
+        if constexpr (K == 1) UGVC_PRED_ASM("v_cmp_nlt_f32_e64", "BYTE_1");
+        if constexpr (K == 2) UGVC_PRED_ASM("v_cmp_nlt_f32_e64", "BYTE_2");
+        if constexpr (K == 3) UGVC_PRED_ASM("v_cmp_nlt_f32_e64", "BYTE_3");
+    }
+}
+
+#define UGVC_GEMM_CONST __attribute__((address_space(4)))
+
+template <bool RF>
+__global__ __launch_bounds__(kGemm2Threads) void forest_gemm2_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* leaves = reinterpret_cast<float*>(smem);                                        // [T][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int k = tid; k < g.T * 16; k += kGemm2Threads) reinterpret_cast<float4*>(leaves)[k] = reinterpret_cast<const float4*>(g.leaves)[k];
+    __syncthreads();
+    unsigned char* stage = smem + (size_t)g.T * 64 * 4 + (size_t)wave * 64 * kGemm2RowB;  // the wave's 64 x 80-byte predicate rows
+    const uint32_t stage_b = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)stage;
+    const uint32_t leaves_b = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)leaves;
+
+    // A operand of the transposed product: lane holds C^T[leaf = 16 j + (lane & 15)][k = (lane >> 4) * 16 .. + 16]
+    i32x4_t CT[4], bias[4];
+    const int col = lane & 15, kb = (lane >> 4) * 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 16; ++q) w[q >> 2] |= (path_entry(kb + q, 16 * j + col) & 0xff) << (8 * (q & 3));
+        CT[j] = i32x4_t{w[0], w[1], w[2], w[3]};
+        // D[leaf = 16 j + 4 (lane >> 4) + q][row = lane & 15]: zero for the exit leaf, negative elsewhere
+        const int l0 = 16 * j + 4 * (lane >> 4);
+        bias[j] = i32x4_t{-(int)__popc(l0), -(int)__popc(l0 + 1), -(int)__popc(l0 + 2), -(int)__popc(l0 + 3)};
+    }
+    const uint32_t zero = 0u, one = 1u;
+    const f32x2_t UGVC_GEMM_CONST* const nodes = (const f32x2_t UGVC_GEMM_CONST*)(uintptr_t)g.nodes;   // wave-uniform: scalar loads
+    const int64_t n_tiles = (g.n + 63) / 64;
+    const int F = g.F;
+    for (int64_t tile = (int64_t)blockIdx.x * (kGemm2Threads / 64) + wave; tile < n_tiles; tile += (int64_t)gridDim.x * (kGemm2Threads / 64)) {
+        int64_t gr = tile * 64 + lane;
+        const bool live = gr < g.n;
+        if (!live) gr = g.n - 1;
+        const int64_t src = g.rows ? (int64_t)g.rows[gr] : gr;
+        const float* xr = g.X + src * F;
+        f32x32_t xv;
+#pragma unroll
+        for (int f = 0; f < 32; ++f) xv[f] = 0.f;
+        if ((F & 3) == 0) {
+#pragma unroll
+            for (int q = 0; q < kMaxFeatures / 4 + 1; ++q)
+                if (4 * q < F) {
+                    const float4 x4 = reinterpret_cast<const float4*>(xr)[q];
+                    xv[4 * q] = x4.x; xv[4 * q + 1] = x4.y; xv[4 * q + 2] = x4.z; xv[4 * q + 3] = x4.w;
+                }
+        } else {
+#pragma unroll
+            for (int f = 0; f < kMaxFeatures; ++f)
+                if (f < F) xv[f] = xr[f];
+        }
+        float margin = g.base;
+        for (int t = 0; t < g.T; ++t) {
+            uint32_t a[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) a[q] = 0u;
+            const f32x2_t UGVC_GEMM_CONST* tn = nodes + (size_t)t * 64;
+#pragma unroll
+            for (int i = 0; i < 63; ++i) {                           // (slot 63 is padding: its path-matrix row is zero)
+                const f32x2_t nd = tn[i];
+                const float thr = nd[0];
+                const int fidx = __float_as_int(nd[1]);              // (< kMaxFeatures: gemm_model; the padding slots name feature 0)
+                if ((i & 3) == 0) pred_byte<0, RF>(a[i >> 2], xv, fidx, thr, zero, one);
+                else if ((i & 3) == 1) pred_byte<1, RF>(a[i >> 2], xv, fidx, thr, zero, one);
+                else if ((i & 3) == 2) pred_byte<2, RF>(a[i >> 2], xv, fidx, thr, zero, one);
+                else pred_byte<3, RF>(a[i >> 2], xv, fidx, thr, zero, one);
+            }
+            // the lane's 64 predicate bytes -> its row of the staging area; back in the operand layout of the four row tiles
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t wr = stage_b + (uint32_t)lane * kGemm2RowB;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                *(__attribute__((address_space(3))) i32x4_t*)(uintptr_t)(wr + 16u * c) = i32x4_t{(int)a[4 * c], (int)a[4 * c + 1], (int)a[4 * c + 2], (int)a[4 * c + 3]};
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            f32x4_t lv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                lv[j] = *(const __attribute__((address_space(3))) f32x4_t*)(uintptr_t)(leaves_b + (uint32_t)(t * 256 + 64 * j + 16 * (lane >> 4)));
+            float mine = 0.f;                                        // the exit leaf's value of THIS lane's row (tile lane >> 4)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const i32x4_t P = *(const __attribute__((address_space(3))) i32x4_t*)(uintptr_t)(stage_b + (uint32_t)((16 * r + col) * kGemm2RowB + kb));
+                uint32_t hit = 0u;                                   // bits of the exit leaf's f32 value if one of this lane's 16 leaves is it
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const i32x4_t D = __builtin_amdgcn_mfma_i32_16x16x64_i8(CT[j], P, bias[j], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) hit = D[q] == 0 ? __float_as_uint(lv[j][q]) : hit;
+                }
+                // the four lanes of a row (same lane & 15) hold three zeros and the value
+                hit |= (uint32_t)__shfl_xor((int)hit, 16);
+                hit |= (uint32_t)__shfl_xor((int)hit, 32);
+                mine = (lane >> 4) == r ? __uint_as_float(hit) : mine;
+            }
+            margin += mine;                                          // tree order, f32: as the traversal
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (live) g.out[tile * 64 + lane] = margin;
+    }
+}
+
 // Traversal over the same matrix and the same dense node table: one lane per row, fixed 6-level walk.
 __global__ __launch_bounds__(256) void forest_rows_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -184,10 +331,16 @@ extern "C" int ugvc_forest_gemm(ugvc_ctx* ctx, int group, const int32_t* rows, i
         GemmArgs g{ctx->x_mat.as<float>(), F, rows ? dr.as<int32_t>() : nullptr, n, dn.as<float2>(), dl.as<float>(),
                    T, kind, base, dout.as<float>()};
         const size_t lds_tables = (size_t)T * 64 * 12;
-        const size_t lds = use_mfma ? lds_tables + (size_t)(kGemmThreads / 64) * 16 * kGemmXStride * 4 : lds_tables;
+        // use_mfma: 1 = the round-4 kernel (register-indexed predicates, transposed product), 2 = the round-1 kernel (LDS gathers)
+        const bool v2 = use_mfma == 1 && !(ctx->kernel_variant & 512);
+        const size_t lds = !use_mfma ? lds_tables
+                         : v2 ? (size_t)T * 64 * 4 + (size_t)(kGemm2Threads / 64) * 64 * kGemm2RowB
+                              : lds_tables + (size_t)(kGemmThreads / 64) * 16 * kGemmXStride * 4;
         if (lds > 156 * 1024) rc = fail("ensemble too large for the LDS-resident GEMM formulation (T * 768 bytes)");
+        const void* fn = !use_mfma ? reinterpret_cast<const void*>(forest_rows_kernel)
+                       : !v2 ? reinterpret_cast<const void*>(forest_gemm_kernel)
+                       : kind == UGVC_MODEL_RF ? reinterpret_cast<const void*>(forest_gemm2_kernel<true>) : reinterpret_cast<const void*>(forest_gemm2_kernel<false>);
         if (!rc) {
-            const void* fn = use_mfma ? reinterpret_cast<const void*>(forest_gemm_kernel) : reinterpret_cast<const void*>(forest_rows_kernel);
             if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess)
                 rc = fail("cannot raise the dynamic LDS limit");
         }
@@ -195,8 +348,11 @@ extern "C" int ugvc_forest_gemm(ugvc_ctx* ctx, int group, const int32_t* rows, i
             const unsigned grid = (unsigned)ctx->n_cus;
             if (hipEventRecord(ctx->ev0, ctx->stream) != hipSuccess) rc = fail("event record failed");
             for (int it = 0; it < iters && !rc; ++it) {
-                if (use_mfma) hipLaunchKernelGGL(forest_gemm_kernel, dim3(grid), dim3(kGemmThreads), lds, ctx->stream, g);
-                else hipLaunchKernelGGL(forest_rows_kernel, dim3(grid * 4), dim3(256), lds, ctx->stream, g);
+                if (!use_mfma) hipLaunchKernelGGL(forest_rows_kernel, dim3(grid * 4), dim3(256), lds, ctx->stream, g);
+                else if (!v2) hipLaunchKernelGGL(forest_gemm_kernel, dim3(grid), dim3(kGemmThreads), lds, ctx->stream, g);
+                // (two workgroups of eight waves per CU: 110 registers and 66 KB of LDS each)
+                else if (kind == UGVC_MODEL_RF) hipLaunchKernelGGL(forest_gemm2_kernel<true>, dim3(grid * 2), dim3(kGemm2Threads), lds, ctx->stream, g);
+                else hipLaunchKernelGGL(forest_gemm2_kernel<false>, dim3(grid * 2), dim3(kGemm2Threads), lds, ctx->stream, g);
             }
             if (!rc && (hipEventRecord(ctx->ev1, ctx->stream) != hipSuccess || hipEventSynchronize(ctx->ev1) != hipSuccess ||
                         hipGetLastError() != hipSuccess))
