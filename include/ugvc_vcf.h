@@ -85,6 +85,12 @@ int ugvc_vcf_write_filtered(const ugvc_vcf* h, const char* out_path, const float
 void ugvc_vcf_free(ugvc_vcf* h);
 const char* ugvc_vcf_last_error(void);
 int ugvc_vcf_abi_version(void);
+/* Which deflate implementation the BGZF reader / writer use: 0 = automatic (libdeflate.so.0 when the host has it - 2-3 x
+ * zlib's speed on 64 KB blocks - else zlib; the environment variable UGVC_DEFLATE=zlib means 1), 1 = zlib level 6 (the
+ * compressed BYTES are then those of the pure-Python reference codec io/vcf.py), 2 = libdeflate level 6 (fails if absent).
+ * Returns the implementation now in use (1 or 2), or -1 with ugvc_vcf_last_error() set.  Inflated text, CRCs, block structure
+ * and the meaning of the tabix index are the same either way. */
+int ugvc_vcf_set_deflate(int backend);
 
 /* ---- side tables of the same tools: FASTA -> base codes, BED / interval_list -> interval arrays ----------------
  * `--reference_file` is opened with pyfaidx and fetched per row in the reference

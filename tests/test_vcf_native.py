@@ -25,6 +25,25 @@ def _built():
         subprocess.run(["make", "-C", os.path.join(ROOT, "variantcalling_amd", "csrc_host")], check=True)
 
 
+@pytest.fixture(autouse=True)
+def _zlib_bytes():
+    """The byte-for-byte comparisons of this file are against io/vcf.py, which drives zlib: the native codec is switched to
+    zlib for them (its default since round 4 is libdeflate when the host has it: same text, same blocks, other bytes - the
+    `deflate`-parametrised tests below cover that path by inflate-equality and by index queries)."""
+    nv.set_deflate("zlib")
+    yield
+    nv.set_deflate("auto")
+
+
+def _has_libdeflate():
+    try:
+        return nv.set_deflate("libdeflate") == "libdeflate"
+    except RuntimeError:
+        return False
+    finally:
+        nv.set_deflate("zlib")
+
+
 def _same_file(a, b, mutect=False):
     for c in COLS:
         x, y = getattr(a.table, c), getattr(b.table, c)
@@ -40,7 +59,7 @@ def _same_file(a, b, mutect=False):
 def test_header_symbols_are_exported():
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "ugvc_vcf.h")).read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(ugvc_(?:vcf|fasta|intervals)_[a-z0-9_]+)\s*\(", text)))
-    assert len(names) == 13
+    assert len(names) == 14
     lib = nv.load_library()
     for n in names:
         assert hasattr(lib, n), n
@@ -52,8 +71,12 @@ def test_header_symbols_are_exported():
     assert "amdhip" not in deps and "libz" in deps
 
 
+@pytest.mark.parametrize("deflate", ["zlib", "libdeflate"])
 @pytest.mark.parametrize("threads", [1, 3, 0])
-def test_synthetic_callset_read_and_write_back(tmp_path, threads):
+def test_synthetic_callset_read_and_write_back(tmp_path, threads, deflate):
+    if deflate == "libdeflate" and not _has_libdeflate():
+        pytest.skip("libdeflate.so.0 is not on this host")
+    nv.set_deflate(deflate)
     cs = synth.make_callset(30_000, genome_len=20_000_000, n_contigs=3, seed=5)
     vt = cs.variants
     ids = np.arange(vt.n) % 3 == 0
@@ -78,7 +101,25 @@ def test_synthetic_callset_read_and_write_back(tmp_path, threads):
             if out_name.endswith(".gz"):
                 assert gzip.decompress(A) == gzip.decompress(B)
                 assert B.endswith(pv._BGZF_EOF) and B[12:14] == b"BC"
-            assert A == B, "output streams differ"
+            if deflate == "zlib" or not out_name.endswith(".gz"):
+                assert A == B, "output streams differ"
+            else:
+                # libdeflate: other compressed bytes, the same 65280-byte blocks; the file reads back (both readers, libdeflate
+                # and zlib inflate) to the table and to the verdicts that were written
+                off, sizes = 0, []
+                while off < len(B):
+                    bsize = int.from_bytes(B[off + 16: off + 18], "little") + 1
+                    sizes.append(len(zlib.decompress(B[off + 18: off + bsize - 8], -15)))
+                    off += bsize
+                assert all(x == 65280 for x in sizes[:-2]) and sizes[-1] == 0
+                for reader_deflate in ("libdeflate", "zlib"):
+                    nv.set_deflate(reader_deflate)
+                    c = nv.read_vcf(ob, cs.ref.names, n_threads=threads)
+                    d = pv.read_vcf(oa, cs.ref.names)
+                    _same_file(d, c)
+                    c.close()
+                nv.set_deflate(deflate)
+                assert os.path.exists(ob + ".tbi")
         b.close()
 
 

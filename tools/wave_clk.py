@@ -51,3 +51,25 @@ print(f"correlation of a workgroup's end with its tiles {c:.2f}, with its indel 
 # quarter by quarter of the grid
 q = a.shape[0] // 4
 print("mean relative end by quarter of the grid (genome order):", [int(wg_end[k * q:(k + 1) * q].mean()) for k in range(4)])
+
+# ---- the pass before, if it was kept: do the same workgroups finish late again?
+import os
+if os.path.exists(sys.argv[1] + ".prev"):
+    b = np.fromfile(sys.argv[1] + ".prev", dtype=np.uint64).reshape(-1, 16, 4).astype(np.int64)
+    if b.shape == a.shape:
+        lb = b[..., 2] > 0
+        tb = np.where(lb, b[..., 0], np.iinfo(np.int64).max).min(axis=1, keepdims=True)
+        eb = np.where(lb, b[..., 2] - tb, 0).max(axis=1)
+        print(f"correlation of a workgroup's end with its end in the previous pass: {np.corrcoef(wg_end, eb)[0, 1]:.2f}")
+        slow_a, slow_b = set(np.argsort(-wg_end)[:26].tolist()), set(np.argsort(-eb)[:26].tolist())
+        print(f"of the 26 slowest workgroups, {len(slow_a & slow_b)} are among the 26 slowest of the previous pass")
+        # per-wave correlation inside a workgroup: is it one wave that is late, or the whole workgroup?
+        ea = np.where(live, end - t0, 0)
+        print("mean over workgroups of (workgroup end - median wave end):", int((wg_end - np.median(np.where(live, ea, np.nan), axis=1)).mean()))
+# ---- the slowest workgroups wave by wave, beside a median one
+med = int(np.argsort(wg_end)[len(wg_end) // 2])
+for b in list(order[:3]) + [med]:
+    ea = np.where(live[b], end[b] - t0[b, 0], 0)
+    fa = np.where(live[b], first[b] - t0[b, 0], 0)
+    print(f"workgroup {b} (end {wg_end[b]}): wave: first-tile / end / tiles(indel)")
+    print("   " + "  ".join(f"{w}:{fa[w] // 1000}k/{ea[w] // 1000}k/{tiles[b, w]}({(info[b, w] >> 32)})" for w in range(16)))

@@ -36,6 +36,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <string>
 #include <vector>
 
 #include "ugvc_walk.hpp"
@@ -217,6 +218,35 @@ __device__ __forceinline__ int join_one_global(const FilterArgs* ap, int t, int 
     }
     *op = o;
     return rank;
+}
+
+// A further contig segment of a tile that spans a contig boundary (lanes lo .. hi, contig `bk.c` after the caller's wave
+// search at the segment's first variant): every lane finds its ranks by a galloping search FROM the segment's ranks - a
+// handful of probes on the cache lines next to them - instead of a binary search over the contig's whole row range (~100
+// dependent round trips to HBM for the five tables).  Rare (a tile per contig boundary and class), so the code is kept small:
+// no staging.  Leaves the ranks at lane `hi` in bk.
+template <int NT>
+__device__ __forceinline__ void cold_segment_joins(const FilterArgs& a, Brk<NT>& bk, int pos, uint64_t key, int hi, JoinOut& jo) {
+    auto gallop = [&](auto&& below, int lo, int end) {              // first index in [lo, end] that is not `below`, bracketed by doubling
+        int step = 1;
+        while (lo + step < end && below(lo + step)) step <<= 1;
+        return min(lo + step + 1, end);
+    };
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if ((t == 0 && !a.has_runs) || bk.phi[t] <= bk.plo[t]) continue;
+        const TrackView& tv = table_view(a, t);
+        const int lo = max(bk.L[t], bk.plo[t]);
+        const int end = gallop([&](int r) { return tv.starts[r] < pos; }, lo, bk.phi[t]);
+        const int sg = join_one_global(&a, t, lo, end, bk.plo[t], bk.phi[t], pos, key, &jo);
+        bk.L[t] = __builtin_amdgcn_readlane(sg, hi);
+    }
+    if (a.n_bl > 0) {
+        const int lo = bk.Lb;
+        const int end = gallop([&](int r) { return a.bl[r] < key; }, lo, (int)a.n_bl);
+        const int rb = join_one_global(&a, kJoin5 - 1, lo, end, 0, 0, pos, key, &jo);
+        bk.Lb = __builtin_amdgcn_readlane(rb, hi);
+    }
 }
 
 // Indel tiles cover ~5x the span of an SNP tile, so their slices are staged per table, from two rows before the
@@ -484,6 +514,105 @@ __device__ __forceinline__ void store_feature_rows_tile(const FilterArgs& a, uin
     __builtin_amdgcn_wave_barrier();                             // (before the next tile stages its slices here)
 }
 
+// ---- the joins of one contig SEGMENT of an SNP tile (lanes 0 .. last share contig c_seg; almost always the whole tile) --------
+// The slices fetched from the carried ranks (`pre`) go to the wave's LDS scratch, sentinel padded; seven lock-step descent
+// steps rank every table at once; verdicts from a few reads around the rank; a table whose staged slice does not reach the
+// segment's last variant is searched in HBM from the carried rank.  Leaves the ranks at lane `last` in `bk` (where the next
+// tile - or the next segment's search - starts).  Lanes beyond `last` compute values nobody reads.
+template <int NT>
+__device__ __forceinline__ void snp_join_segment(const V5Args& v, const Scratch& sc, Brk<NT>& bk, const SlicePre<NT>& pre, int lane, int pos,
+                                                 uint64_t key, int c_seg, int last, JoinOut& jo) {
+    const FilterArgs& a = v.f;
+    const int pos_max = __builtin_amdgcn_readlane(pos, last);
+    int L[NT], plo[NT], phi[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        L[t] = bk.L[t] - 2;
+        plo[t] = bk.plo[t];
+        phi[t] = bk.phi[t];
+    }
+    const int Lb0 = bk.Lb;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (t == 0 && !a.has_runs) continue;
+        const int cap = v.jcap[t];
+        const uint32_t dS = sc.base + 4u * (uint32_t)v.joff[t], dE = dS + 4u * (uint32_t)cap;
+        {
+            const int gi = L[t] + lane;
+            lds_st32(dS + 4u * lane, gi < plo[t] ? INT32_MIN : (gi >= phi[t] ? INT32_MAX : pre.sv[t][0]));
+            lds_st32(dE + 4u * lane, pre.ev[t][0]);
+        }
+        if (cap > 64) {
+            const int gi = L[t] + 64 + lane;
+            lds_st32(dS + 256u + 4u * lane, gi < plo[t] ? INT32_MIN : (gi >= phi[t] ? INT32_MAX : pre.sv[t][1]));
+            lds_st32(dE + 256u + 4u * lane, pre.ev[t][1]);
+        }
+    }
+    if (a.n_bl > 0) lds_st64(sc.base + 4u * (uint32_t)v.joff[kJoin5 - 1] + 8u * lane, pre.bl);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // rank among the staged starts of every table: seven descent steps in lock-step, no bounds test (sentinels)
+    // and no branch (a table staged with 64 entries makes a step of zero at 64)
+    uint32_t p[NT], A[NT], maskB[NT];
+    const uint32_t Ab = sc.base + 4u * (uint32_t)v.joff[kJoin5 - 1];
+    uint32_t pb = Ab - 8u;
+    const uint64_t key_max = ((uint64_t)(uint32_t)c_seg << 32) | (uint32_t)pos_max;
+    bool miss = false;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        A[t] = sc.base + 4u * (uint32_t)v.joff[t];
+        p[t] = A[t] - 4u;
+        maskB[t] = 4u * (uint32_t)(v.jcap[t] - 1);
+        // a staged slice that does not reach the segment's last variant: that table is searched in HBM (dense stretches)
+        if (t > 0 || a.has_runs) miss |= lds_i32(A[t] + maskB[t]) < pos_max;
+    }
+    if (a.n_bl > 0) miss |= lds_u64(Ab + 8u * (kBlCap5 - 1)) < key_max;
+#pragma unroll
+    for (int sb = 256; sb >= 4; sb >>= 1) {
+        uint32_t cand[NT];
+        int x[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            cand[t] = p[t] + ((uint32_t)sb & maskB[t]);
+            x[t] = lds_i32(cand[t]);
+        }
+        const uint32_t cb = pb + (uint32_t)((2 * sb) & (8 * (kBlCap5 - 1)));
+        const uint64_t xk = lds_u64(cb);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) p[t] = x[t] < pos ? cand[t] : p[t];
+        pb = xk < key ? cb : pb;
+    }
+    int sg_l[NT];
+    int rb_l = Lb0 + (int)((pb + 8u - Ab) >> 3);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        sg_l[t] = bk.L[t];
+        if (t == 0 && !a.has_runs) continue;
+        const uint32_t dE = 4u * (uint32_t)v.jcap[t];
+        const int sg = L[t] + (int)((p[t] + 4u - A[t]) >> 2);   // staged starts below pos
+        sg_l[t] = sg;
+        const uint32_t ps = p[t];                               // LDS address of starts[sg - 1]
+        auto S = [&](int gi) { return lds_i32(ps + 4u * (uint32_t)(gi - sg + 1)); };
+        auto E = [&](int gi) { return lds_i32(ps + dE + 4u * (uint32_t)(gi - sg + 1)); };
+        interval_verdict(t, sg, plo[t], phi[t], pos, a.hpol_dist, S, E, jo);
+    }
+    if (a.n_bl > 0 && lds_u64(pb + 8u) == key) jo.cohort = true;   // the staged key at the rank (sentinel beyond the table)
+    if (__ballot(miss) != 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (t == 0 && !a.has_runs) continue;
+            if (__ballot(lds_i32(A[t] + maskB[t]) < pos_max) != 0)
+                sg_l[t] = join_one_global(&a, t, max(L[t] + 2, plo[t]), phi[t], plo[t], phi[t], pos, key, &jo);
+        }
+        if (a.n_bl > 0 && __ballot(lds_u64(Ab + 8u * (kBlCap5 - 1)) < key_max) != 0)
+            rb_l = join_one_global(&a, kJoin5 - 1, Lb0, (int)a.n_bl, 0, 0, pos, key, &jo);
+    }
+    // the next tile of this wave (or the next contig segment of this one) starts where this segment's last variant ended
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bk.L[t] = __builtin_amdgcn_readlane(sg_l[t], last);
+    bk.Lb = __builtin_amdgcn_readlane(rb_l, last);
+}
+
 // ---- SNP / MNP tile: features of 64 substitutions (ref_len == alt_len) ---------------------------------
 // Writes the flags column, leaves the 16-bit codes of the group-0 forest in the wave's code planes.
 template <int NTRK, bool WX>
@@ -494,12 +623,18 @@ __device__ __forceinline__ void featurize_snp_tile(const V5Args& v, const Scratc
     const int c = k.c, pos = k.pos, rl = k.rl;
     const uint32_t ro = k.ro, ao = k.ao;
     const int c0 = rfl(c);
+    // A tile's rows are sorted by (contig, pos) and its padding lanes repeat lane 0's row: the live lanes of the FIRST contig
+    // are a prefix.  All but a handful of tiles have one contig; one that spans a contig boundary is joined segment by
+    // segment (round 4: it used to send every lane through its own 20-step binary searches in HBM - ~100 dependent round
+    // trips, 60-85 k ticks - and the 23 workgroups that hold such a boundary were the slowest of every launch, which then
+    // waited for them: profiles/r04_wave_clk_static.txt).
+    const int n_live = (int)__popcll(__ballot(live));
+    const int n_seg0 = (int)__popcll(__ballot(live && c == c0));
     const bool uni = __ballot(c != c0) == 0;                    // one contig (all but a handful of tiles)
     const bool joins_on = !(a.ablate & 524288);
-    const bool stage = uni && joins_on;
     if (c0 != bk.c) {                                           // the wave's first tile, or a new contig: search afresh
         brk_refresh<NT>(a, bk, c0, rfl(pos), lane);
-        if (stage) issue_slices<NT>(v, bk, lane, pre);
+        if (joins_on) issue_slices<NT>(v, bk, lane, pre);
     }
     const int64_t clo = uni ? bk.clo : a.contig_off[c], chi = uni ? bk.chi : a.contig_off[c + 1];
     const uint32_t clen = (uint32_t)(chi - clo);
@@ -512,18 +647,7 @@ __device__ __forceinline__ void featurize_snp_tile(const V5Args& v, const Scratc
     const uint4 xw = *reinterpret_cast<const uint4*>(a.ref + wa);
     const uint32_t rbase = a.alleles[ro], abase = a.alleles[ao];
 
-    // ---- side-table slices of this tile -> wave-private LDS (sentinel padded)
-    const int n_live = (int)__popcll(__ballot(live));
-    const int pos_max = __builtin_amdgcn_readlane(pos, n_live - 1);
     const uint64_t key = ((uint64_t)(uint32_t)c << 32) | (uint32_t)pos;
-    int L[NT], plo[NT], phi[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        L[t] = bk.L[t] - 2;
-        plo[t] = bk.plo[t];
-        phi[t] = bk.phi[t];
-    }
-    const int Lb0 = bk.Lb;
     CLK(pc, 6);
     const float qual = k.qual, sor = k.sor;
     const int dp = k.dp, adr = k.adr, ada = k.ada, gq = k.gq;
@@ -543,104 +667,29 @@ __device__ __forceinline__ void featurize_snp_tile(const V5Args& v, const Scratc
         rank3_eyt(fx, base, bits, len, cd);
     }
     CLK(pc, 7);
-    if (stage) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (t == 0 && !a.has_runs) continue;
-            const int cap = v.jcap[t];
-            const uint32_t dS = sc.base + 4u * (uint32_t)v.joff[t], dE = dS + 4u * (uint32_t)cap;
-            {
-                const int gi = L[t] + lane;
-                lds_st32(dS + 4u * lane, gi < plo[t] ? INT32_MIN : (gi >= phi[t] ? INT32_MAX : pre.sv[t][0]));
-                lds_st32(dE + 4u * lane, pre.ev[t][0]);
-            }
-            if (cap > 64) {
-                const int gi = L[t] + 64 + lane;
-                lds_st32(dS + 256u + 4u * lane, gi < plo[t] ? INT32_MIN : (gi >= phi[t] ? INT32_MAX : pre.sv[t][1]));
-                lds_st32(dE + 256u + 4u * lane, pre.ev[t][1]);
-            }
-        }
-        if (a.n_bl > 0) lds_st64(sc.base + 4u * (uint32_t)v.joff[kJoin5 - 1] + 8u * lane, pre.bl);
-    }
     CLK(pc, 0);
 
     // ---- joins
     JoinOut jo{false, false, false, 0u};
-    if (!joins_on) {
-    } else if (uni) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // rank among the staged starts of every table: seven descent steps in lock-step, no bounds test (sentinels)
-        // and no branch (a table staged with 64 entries makes a step of zero at 64)
-        uint32_t p[NT], A[NT], maskB[NT];
-        const uint32_t Ab = sc.base + 4u * (uint32_t)v.joff[kJoin5 - 1];
-        uint32_t pb = Ab - 8u;
-        const uint64_t key_max = ((uint64_t)(uint32_t)c0 << 32) | (uint32_t)pos_max;
-        bool miss = false;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            A[t] = sc.base + 4u * (uint32_t)v.joff[t];
-            p[t] = A[t] - 4u;
-            maskB[t] = 4u * (uint32_t)(v.jcap[t] - 1);
-            // a staged slice that does not reach the tile's last variant: that table is searched in HBM (dense stretches)
-            if (t > 0 || a.has_runs) miss |= lds_i32(A[t] + maskB[t]) < pos_max;
-        }
-        if (a.n_bl > 0) miss |= lds_u64(Ab + 8u * (kBlCap5 - 1)) < key_max;
-#pragma unroll
-        for (int sb = 256; sb >= 4; sb >>= 1) {
-            uint32_t cand[NT];
-            int x[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                cand[t] = p[t] + ((uint32_t)sb & maskB[t]);
-                x[t] = lds_i32(cand[t]);
+    if (joins_on) {
+        snp_join_segment<NT>(v, sc, bk, pre, lane, pos, key, c0, max(n_seg0, 1) - 1, jo);
+        if (!uni) {
+            // the further contigs of the tile: a fresh wave search at each segment's first variant, then short per-lane searches
+            int lo = n_seg0;
+            while (lo < n_live) {
+                const int cs = __builtin_amdgcn_readlane(c, lo);
+                const int hi = lo + (int)__popcll(__ballot(live && c == cs)) - 1;
+                brk_refresh<NT>(a, bk, cs, __builtin_amdgcn_readlane(pos, lo), lane);
+                JoinOut js{false, false, false, 0u};
+                // (lanes of the tile's other contigs search for the segment's FIRST variant: their own positions would send the
+                // galloping search across the whole contig)
+                const bool mine = lane >= lo && lane <= hi;
+                const int pos_s = mine ? pos : __builtin_amdgcn_readlane(pos, lo);
+                cold_segment_joins<NT>(a, bk, pos_s, ((uint64_t)(uint32_t)cs << 32) | (uint32_t)pos_s, hi, js);
+                if (mine) jo = js;
+                lo = hi + 1;
             }
-            const uint32_t cb = pb + (uint32_t)((2 * sb) & (8 * (kBlCap5 - 1)));
-            const uint64_t xk = lds_u64(cb);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) p[t] = x[t] < pos ? cand[t] : p[t];
-            pb = xk < key ? cb : pb;
         }
-        int sg_l[NT];
-        int rb_l = Lb0 + (int)((pb + 8u - Ab) >> 3);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            sg_l[t] = bk.L[t];
-            if (t == 0 && !a.has_runs) continue;
-            const uint32_t dE = 4u * (uint32_t)v.jcap[t];
-            const int sg = L[t] + (int)((p[t] + 4u - A[t]) >> 2);   // staged starts below pos
-            sg_l[t] = sg;
-            const uint32_t ps = p[t];                               // LDS address of starts[sg - 1]
-            auto S = [&](int gi) { return lds_i32(ps + 4u * (uint32_t)(gi - sg + 1)); };
-            auto E = [&](int gi) { return lds_i32(ps + dE + 4u * (uint32_t)(gi - sg + 1)); };
-            interval_verdict(t, sg, plo[t], phi[t], pos, a.hpol_dist, S, E, jo);
-        }
-        if (a.n_bl > 0 && lds_u64(pb + 8u) == key) jo.cohort = true;   // the staged key at the rank (sentinel beyond the table)
-        if (__ballot(miss) != 0) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                if (t == 0 && !a.has_runs) continue;
-                if (__ballot(lds_i32(A[t] + maskB[t]) < pos_max) != 0)
-                    sg_l[t] = join_one_global(&a, t, max(L[t] + 2, plo[t]), phi[t], plo[t], phi[t], pos, key, &jo);
-            }
-            if (a.n_bl > 0 && __ballot(lds_u64(Ab + 8u * (kBlCap5 - 1)) < key_max) != 0)
-                rb_l = join_one_global(&a, kJoin5 - 1, Lb0, (int)a.n_bl, 0, 0, pos, key, &jo);
-        }
-        // the next tile of this wave starts where this tile's last variant ended
-#pragma unroll
-        for (int t = 0; t < NT; ++t) bk.L[t] = __builtin_amdgcn_readlane(sg_l[t], n_live - 1);
-        bk.Lb = __builtin_amdgcn_readlane(rb_l, n_live - 1);
-    } else {
-        // a tile that spans contigs: every lane searches its own contig's rows
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (t == 0 && !a.has_runs) continue;
-            const TrackView& tv = table_view(a, t);
-            const int pl = tv.ptr[c], ph = tv.ptr[c + 1];
-            join_one_global(&a, t, pl, ph, pl, ph, pos, key, &jo);
-        }
-        if (a.n_bl > 0) join_one_global(&a, kJoin5 - 1, 0, (int)a.n_bl, 0, 0, pos, key, &jo);
-        bk.c = -1;                                              // the next tile searches afresh
     }
     uint8_t flags = (uint8_t)(jo.trk << UGVC_FLAG_TRACK0_SHIFT);
     if (jo.cohort) flags |= UGVC_FLAG_COHORT_FP;
@@ -800,10 +849,9 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
     const bool uni = __ballot(c != c0) == 0;
     if (c0 != bk.c) {                                           // the wave's first tile, or a new contig: search afresh
         brk_refresh<NT>(a, bk, c0, rfl(pos), lane);
-        if (uni && joins_on) issue_indel_slices<NTRK>(v, bk, lane, pre);
+        if (joins_on) issue_indel_slices<NTRK>(v, bk, lane, pre);
     }
     const int n_live = (int)__popcll(__ballot(live));
-    const int pos_max = __builtin_amdgcn_readlane(pos, n_live - 1);
     const bool ins = rl < al;
     const int classify = ins ? 1 : 2;
     const int indel_length = ins ? al - rl : rl - al;
@@ -935,8 +983,9 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
     // ---- joins: the staged slices, two tables at a time in the scratch the window rows have left
     const uint64_t key = ((uint64_t)(uint32_t)c << 32) | (uint32_t)pos;
     JoinOut jo{false, false, false, 0u};
-    if (!joins_on) {
-    } else if (uni) {
+    // the joins of one contig segment of the tile (lanes .. last share contig c_seg; almost always the whole tile)
+    auto join_seg = [&](int c_seg, int last, JoinOut& jo) {
+        const int pos_max = __builtin_amdgcn_readlane(pos, last);
         const uint32_t s0 = sc.base, s1 = sc.base + kIndelSlotB;
         auto on = [&](int t) { return t > 0 || a.has_runs; };
         auto is_wide = [&](int t) { return ((v.iwide >> t) & 1) != 0; };
@@ -1006,7 +1055,7 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
                 else sg_l[t] = join_one_global(&a, t, max(bk.L[t], bk.plo[t]), bk.phi[t], bk.plo[t], bk.phi[t], pos, key, &jo);
             }
             if (bl_on) {
-                const uint64_t key_max = ((uint64_t)(uint32_t)c0 << 32) | (uint32_t)pos_max;
+                const uint64_t key_max = ((uint64_t)(uint32_t)c_seg << 32) | (uint32_t)pos_max;
                 if (__ballot(lds_u64(sb_b + 8u * (kIndelRows - 1)) < key_max) == 0) {
                     if (lds_u64(pb + 8u) == key) jo.cohort = true;
                     rb_l = bk.Lb + (int)((pb + 8u - sb_b) >> 3);
@@ -1024,7 +1073,7 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
         __builtin_amdgcn_wave_barrier();
         if (on(0) && !is_wide(0)) narrow(s0, 0);
         if (bl_on) {
-            const uint64_t key_max = ((uint64_t)(uint32_t)c0 << 32) | (uint32_t)pos_max;
+            const uint64_t key_max = ((uint64_t)(uint32_t)c_seg << 32) | (uint32_t)pos_max;
             const uint64_t last_key = lds_u64(s1 + 8u * (kIndelRows - 1));
             if (__ballot(last_key < key_max) == 0) {
                 uint32_t pb = s1 - 8u;
@@ -1061,18 +1110,29 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
         }
         // the next tile of this wave starts where this tile's last variant ended
 #pragma unroll
-        for (int t = 0; t < NT; ++t) bk.L[t] = __builtin_amdgcn_readlane(sg_l[t], n_live - 1);
-        bk.Lb = __builtin_amdgcn_readlane(rb_l, n_live - 1);
-    } else {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (t == 0 && !a.has_runs) continue;
-            const TrackView& tv = table_view(a, t);
-            const int pl_ = tv.ptr[c], ph_ = tv.ptr[c + 1];
-            join_one_global(&a, t, pl_, ph_, pl_, ph_, pos, key, &jo);
+        for (int t = 0; t < NT; ++t) bk.L[t] = __builtin_amdgcn_readlane(sg_l[t], last);
+        bk.Lb = __builtin_amdgcn_readlane(rb_l, last);
+    };
+    if (joins_on) {
+        // (a tile that spans a contig boundary is joined segment by segment - see featurize_snp_tile)
+        const int n_seg0 = (int)__popcll(__ballot(live && c == c0));
+        join_seg(c0, max(n_seg0, 1) - 1, jo);
+        if (!uni) {
+            int lo = n_seg0;
+            while (lo < n_live) {
+                const int cs = __builtin_amdgcn_readlane(c, lo);
+                const int hi = lo + (int)__popcll(__ballot(live && c == cs)) - 1;
+                brk_refresh<NT>(a, bk, cs, __builtin_amdgcn_readlane(pos, lo), lane);
+                JoinOut js{false, false, false, 0u};
+                // (lanes of the tile's other contigs search for the segment's FIRST variant: their own positions would send the
+                // galloping search across the whole contig)
+                const bool mine = lane >= lo && lane <= hi;
+                const int pos_s = mine ? pos : __builtin_amdgcn_readlane(pos, lo);
+                cold_segment_joins<NT>(a, bk, pos_s, ((uint64_t)(uint32_t)cs << 32) | (uint32_t)pos_s, hi, js);
+                if (mine) jo = js;
+                lo = hi + 1;
+            }
         }
-        if (a.n_bl > 0) join_one_global(&a, kJoin5 - 1, 0, (int)a.n_bl, 0, 0, pos, key, &jo);
-        bk.c = -1;                                              // the next tile searches afresh
     }
     uint8_t flags = (uint8_t)(jo.trk << UGVC_FLAG_TRACK0_SHIFT);
     if (jo.cohort) flags |= UGVC_FLAG_COHORT_FP;
@@ -1532,6 +1592,9 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
 #endif
         return;
     }
+    // (equal shares, the last wave takes what is left.  Shares that differ by at most one tile - the larger ones to the oldest
+    // waves - were measured: no faster, profiles/r04_even_shares_ab.txt; the waves of a SIMD share its issue slots, so a wave
+    // that finishes early leaves them to the others: what counts is the workgroup's total work, not the spread of its waves' ends)
     const int64_t q = (nst + n_sw - 1) / n_sw;
     const int64_t t0 = (int64_t)wave * q, t1 = min(t0 + q, nst);
     if (t0 >= t1) return;
@@ -1858,6 +1921,8 @@ int launch_filter_v5(ugvc_ctx* ctx, const FilterArgs& a) {
         std::vector<unsigned long long> h(wclk_bytes / 8);
         UGVC_HIP(hipMemcpyAsync(h.data(), wclk_buf.p, wclk_bytes, hipMemcpyDeviceToHost, ctx->stream));
         UGVC_HIP(hipStreamSynchronize(ctx->stream));
+        static int wclk_pass = 0;                                  // (the previous pass stays beside it as <file>.prev: are the slow workgroups the same ones?)
+        if (wclk_pass++ > 0) (void)rename(wclk_path, (std::string(wclk_path) + ".prev").c_str());
         if (FILE* f = fopen(wclk_path, "wb")) { fwrite(h.data(), 1, wclk_bytes, f); fclose(f); }
     }
     if (v.run_forest) {

@@ -59,6 +59,8 @@ def load_library():
         lib.ugvc_vcf_format_f32.restype = C.c_int
         lib.ugvc_vcf_format_f32.argtypes = [C.c_float, C.c_char_p, C.c_int]
         lib.ugvc_vcf_abi_version.restype = C.c_int
+        lib.ugvc_vcf_set_deflate.restype = C.c_int
+        lib.ugvc_vcf_set_deflate.argtypes = [C.c_int]
         lib.ugvc_fasta_read.restype = C.c_int
         lib.ugvc_fasta_read.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
         lib.ugvc_fasta_get_view.restype = C.c_int
@@ -255,3 +257,13 @@ def read_intervals(path: str, contig_names: list, merge: bool = True, n_threads:
         if stem.endswith(suf):
             stem = stem[: -len(suf)]
     return bed.track_from_arrays(c, s, e, len(contig_names), stem, merge)
+
+
+def set_deflate(backend: str = "auto") -> str:
+    """Which deflate implementation the BGZF reader / writer use: "auto" (libdeflate when the host has it, else zlib), "zlib"
+    (level 6: the compressed bytes are then those of the pure-Python reference codec) or "libdeflate".  Returns the one in use."""
+    lib = load_library()
+    rc = lib.ugvc_vcf_set_deflate({"auto": 0, "zlib": 1, "libdeflate": 2}[backend])
+    if rc < 0:
+        raise RuntimeError(lib.ugvc_vcf_last_error().decode())
+    return "libdeflate" if rc == 2 else "zlib"
