@@ -69,6 +69,15 @@ typedef struct ugvc_vcf_view {
  * n_threads <= 0: one per hardware thread (capped at 64). */
 int ugvc_vcf_read(const char* path, const char* const* contig_names, int n_contigs, int is_mutect, int sample,
                   int n_threads, ugvc_vcf** out);
+/* One PART of the callset, for one rank of a multi-process run (docs/run_comparison_pipeline.md:81 is the reference's own
+ * multi-process idiom): the file is inflated and cut into lines as above, then only records [R part / n_parts, R (part + 1) /
+ * n_parts) IN FILE ORDER are tokenised, ordered and turned into columns - the equal-count shard of that rank when the file is
+ * sorted by (contig, pos), which the caller has to establish across ranks (first / last key and sortedness of every part).
+ * The handle cannot be written back (ugvc_vcf_write_filtered needs the whole file).  ugvc_vcf_part_info: records in the
+ * file and the file-order index of this part's first record. */
+int ugvc_vcf_read_part(const char* path, const char* const* contig_names, int n_contigs, int is_mutect, int sample,
+                       int n_threads, int part, int n_parts, ugvc_vcf** out);
+int ugvc_vcf_part_info(const ugvc_vcf* h, int64_t* n_total, int64_t* part_lo);
 int ugvc_vcf_get_view(const ugvc_vcf* h, ugvc_vcf_view* view);
 
 /* Write the input records in their original order with FILTER := PASS | [HPOL_RUN;][COHORT_FP;][LOW_SCORE],

@@ -57,3 +57,46 @@ def test_tool_shards_and_reassembles_across_ranks(tmp_path, world):
     assert sum(sizes) == cs.variants.n and max(sizes) - min(sizes) <= 1               # equal-count (+-1) shards
     assert filecmp.cmp(one, many, shallow=False)
     assert filecmp.cmp(one + ".tbi", many + ".tbi", shallow=False)
+
+
+def test_unsorted_multiallelic_input_across_ranks(tmp_path):
+    """Round 4: ranks > 0 tokenise only their slice of the records.  That slice is a shard of the SORTED callset only for a
+    sorted file: an unsorted one sends every rank back to the whole file; multi-allelic records stay with one rank (shards are
+    cut between records, not between allele rows).  Either way the N-rank file equals the single-process one."""
+    import gzip
+    cs = synth.make_callset(4_000, genome_len=3_000_000, n_contigs=2, seed=5)
+    argv = _inputs(tmp_path, cs)
+    calls = argv[argv.index("--input_file") + 1]
+    lines = gzip.open(calls, "rt").read().split("\n")
+    hdr = [l for l in lines if l.startswith("#")]
+    rec = [l.split("\t") for l in lines if l and not l.startswith("#")]
+    for k in range(0, len(rec), 37):                                  # multi-allelic records, some straddling the shard seams
+        f = rec[k]
+        if len(f[3]) == 1 and len(f[4]) == 1:
+            other = [x for x in "ACGT" if x not in (f[3], f[4])][0]
+            f[4] += "," + other
+            keys = f[8].split(":")
+            vals = f[9].split(":")
+            if "AD" in keys:
+                vals[keys.index("AD")] += ",3"
+            f[9] = ":".join(vals)
+    for variant, name in ((rec, "sorted_ma.vcf"), (rec[:100][::-1] + rec[100:], "unsorted_ma.vcf")):
+        path = str(tmp_path / name)
+        open(path, "w").write("\n".join(hdr + ["\t".join(f) for f in variant]) + "\n")
+        a2 = list(argv)
+        a2[a2.index("--input_file") + 1] = path
+        env0 = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        one = str(tmp_path / (name + ".one.vcf.gz"))
+        ex1 = tmp_path / (name + ".ex1"); ex1.mkdir()
+        subprocess.run([sys.executable, DRIVER, str(ex1)] + a2 + ["--output_file", one], check=True, env=env0, timeout=600)
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        many = str(tmp_path / (name + ".many.vcf.gz"))
+        exn = tmp_path / (name + ".exn"); exn.mkdir()
+        procs = []
+        for r in range(3):
+            env = dict(env0, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="3", LOCAL_WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            procs.append(subprocess.Popen([sys.executable, DRIVER, str(exn)] + a2 + ["--output_file", many], env=env))
+        assert [p.wait(timeout=600) for p in procs] == [0, 0, 0]
+        assert filecmp.cmp(one, many, shallow=False), name

@@ -59,7 +59,7 @@ def _same_file(a, b, mutect=False):
 def test_header_symbols_are_exported():
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "ugvc_vcf.h")).read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(ugvc_(?:vcf|fasta|intervals)_[a-z0-9_]+)\s*\(", text)))
-    assert len(names) == 14
+    assert len(names) == 16
     lib = nv.load_library()
     for n in names:
         assert hasattr(lib, n), n
@@ -605,3 +605,45 @@ def test_real_fixtures_of_the_reference_tree(tmp_path):
     native_index = open(out_n + ".tbi", "rb").read()
     os.remove(out_n + ".tbi")
     assert pv.tabix_index(out_n) and open(out_n + ".tbi", "rb").read() == native_index
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 7])
+def test_part_reads_are_the_equal_count_slices_of_the_callset(tmp_path, world):
+    """read_vcf(part=(r, world)) - what rank r of the multi-process tool tokenises - returns records [b[r], b[r + 1]) of the
+    file with b = shard.shard_bounds(n, world); a sorted file's parts concatenate to the whole table; an unsorted slice says so;
+    a part cannot be written back."""
+    from variantcalling_amd import shard
+    cs = synth.make_callset(5_003, genome_len=4_000_000, n_contigs=3, seed=17)
+    p = str(tmp_path / "in.vcf.gz")
+    pv.write_vcf_from_table(p, cs.variants, cs.ref.names)
+    full = nv.read_vcf(p, cs.ref.names)
+    b = shard.shard_bounds(full.n, world)
+    assert full.n_total == full.n and full.part_lo == 0 and full.sorted_in_file
+    for r in range(world):
+        part = nv.read_vcf(p, cs.ref.names, part=(r, world))
+        lo, hi = int(b[r]), int(b[r + 1])
+        assert (part.n_total, part.part_lo, part.n) == (full.n, lo, hi - lo) and part.sorted_in_file
+        want = full.table.slice(lo, hi)
+        for c in COLS:
+            assert np.array_equal(getattr(part.table, c), getattr(want, c), equal_nan=getattr(want, c).dtype.kind == "f"), c
+        assert part.header == full.header
+        if hi > lo:
+            assert part.record_line(0) == full.record_line(lo)
+        if world > 1:
+            res = S.FilterResult(np.zeros(part.n, np.float32), np.zeros(part.n, np.uint8), np.zeros(part.n, np.uint8))
+            with pytest.raises(RuntimeError, match="whole file"):
+                nv.write_filtered_vcf(str(tmp_path / "no.vcf"), part, res)
+        part.close()
+    full.close()
+    # an unsorted file: the slice is sorted on its own, and says that it was not in file order
+    lines = gzip.open(p, "rt").read().split("\n")
+    hdr = [l for l in lines if l.startswith("#")]
+    rec = [l for l in lines if l and not l.startswith("#")]
+    rec[10], rec[20] = rec[20], rec[10]
+    q = str(tmp_path / "unsorted.vcf")
+    open(q, "w").write("\n".join(hdr + rec) + "\n")
+    part = nv.read_vcf(q, cs.ref.names, part=(0, 2))
+    assert not part.sorted_in_file
+    part.close()
+    with pytest.raises(ValueError, match="part"):
+        nv.read_vcf(p, cs.ref.names, part=(2, 2))

@@ -427,6 +427,7 @@ struct ugvc_vcf {
     std::vector<Span> rec_lines;            // file order, without trailing \r / \n
     std::string header_joined;
     int64_t n = 0;
+    int64_t n_total = 0, part_lo = 0;        // ugvc_vcf_read_part: records in the file, first record (file order) of this part
     // table order
     std::vector<uint16_t> contig;
     std::vector<uint8_t> gq, gt, has_id, alleles, n_alt;
@@ -761,7 +762,13 @@ void ugvc_vcf_free(ugvc_vcf* h) { delete h; }
 
 int ugvc_vcf_read(const char* path, const char* const* contig_names, int n_contigs, int is_mutect, int sample,
                   int n_threads, ugvc_vcf** out) {
+    return ugvc_vcf_read_part(path, contig_names, n_contigs, is_mutect, sample, n_threads, 0, 1, out);
+}
+
+int ugvc_vcf_read_part(const char* path, const char* const* contig_names, int n_contigs, int is_mutect, int sample,
+                       int n_threads, int part, int n_parts, ugvc_vcf** out) {
     if (!path || !out || (n_contigs > 0 && !contig_names)) return fail("NULL argument");
+    if (n_parts < 1 || part < 0 || part >= n_parts) return fail("ugvc_vcf_read_part: need 0 <= part < n_parts");
     if (n_contigs < 0 || n_contigs > 65535) return fail("the contig column is u16: at most 65535 contigs");
     if (sample < 0 || sample > 1000000) return fail("bad sample index");
     *out = nullptr;
@@ -812,6 +819,17 @@ int ugvc_vcf_read(const char* path, const char* const* contig_names, int n_conti
     for (size_t i = 0; i < h->hdr_lines.size(); ++i) {
         if (i) h->header_joined.push_back('\n');
         h->header_joined.append(base + h->hdr_lines[i].off, (size_t)h->hdr_lines[i].len);
+    }
+    // a PART of the callset (one rank of a multi-process run): equal-count slices of the record lines in FILE order - the
+    // ranks' parts are the equal-count shards of the sorted callset when the file is sorted, which the caller verifies across
+    // ranks; everything below (tokeniser, order, columns) then works on 1 / n_parts of the records
+    h->n_total = (int64_t)h->rec_lines.size();
+    if (n_parts > 1) {
+        const int64_t R = h->n_total, qb = R / n_parts, qr = R % n_parts;
+        const int64_t lo = (int64_t)part * qb + std::min<int64_t>(part, qr), hi = lo + qb + (part < qr ? 1 : 0);
+        std::vector<Span> mine(h->rec_lines.begin() + lo, h->rec_lines.begin() + hi);
+        h->rec_lines.swap(mine);
+        h->part_lo = lo;
     }
     const int64_t n = (int64_t)h->rec_lines.size();
     h->n = n;
@@ -895,6 +913,13 @@ int ugvc_vcf_read(const char* path, const char* const* contig_names, int n_conti
     return 0;
 }
 
+int ugvc_vcf_part_info(const ugvc_vcf* h, int64_t* n_total, int64_t* part_lo) {
+    if (!h) return fail("NULL argument");
+    if (n_total) *n_total = h->n_total;
+    if (part_lo) *part_lo = h->part_lo;
+    return 0;
+}
+
 int ugvc_vcf_get_view(const ugvc_vcf* h, ugvc_vcf_view* v) {
     if (!h || !v) return fail("NULL argument");
     v->n = h->n;
@@ -917,6 +942,7 @@ int ugvc_vcf_write_filtered(const ugvc_vcf* h, const char* out_path, const float
                             const uint8_t* flags, const uint8_t* cohort_extra, int64_t n, int n_threads, int write_index) {
     if (!h || !out_path || !tree_score || !filter || !flags) return fail("NULL argument");
     if (n != h->n) return fail("result columns do not match the record count of the input");
+    if (h->n != h->n_total) return fail("this handle holds one part of the file (ugvc_vcf_read_part): the write-back needs the whole file");
     const int threads = pick_threads(n_threads);
     const char* base = h->text.data();
     const size_t plen = strlen(out_path);

@@ -46,6 +46,11 @@ def load_library():
                                "(make -C variantcalling_amd/csrc_host)")
         lib = C.CDLL(LIB_PATH)
         lib.ugvc_vcf_last_error.restype = C.c_char_p
+        lib.ugvc_vcf_read_part.restype = C.c_int
+        lib.ugvc_vcf_read_part.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.POINTER(C.c_void_p)]
+        lib.ugvc_vcf_part_info.restype = C.c_int
+        lib.ugvc_vcf_part_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         lib.ugvc_vcf_read.restype = C.c_int
         lib.ugvc_vcf_read.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.POINTER(C.c_void_p)]
@@ -170,14 +175,25 @@ class NativeVcfFile:
             pass
 
 
-def read_vcf(path: str, contig_names: list, is_mutect: bool = False, sample: int = 0, n_threads: int = 0) -> NativeVcfFile:
+def read_vcf(path: str, contig_names: list, is_mutect: bool = False, sample: int = 0, n_threads: int = 0,
+             part: tuple | None = None) -> NativeVcfFile:
+    """The whole callset, or - `part = (rank, world)` - the equal-count slice of its records (file order) that one rank of a
+    multi-process run scores: `.n_total` records are in the file, `.part_lo` is the file-order index of the slice's first
+    record, `.sorted_in_file` says whether the slice was sorted by (contig, pos) as it stood (the caller checks the seams
+    between ranks: pipelines/filter_variants_pipeline.py).  A part cannot be written back."""
     lib = load_library()
     names = (C.c_char_p * len(contig_names))(*[n.encode() for n in contig_names])
     h = C.c_void_p()
-    if lib.ugvc_vcf_read(os.fsencode(path), names, len(contig_names), int(is_mutect), int(sample), int(n_threads),
-                         C.byref(h)):
+    rank, world = part if part is not None else (0, 1)
+    if lib.ugvc_vcf_read_part(os.fsencode(path), names, len(contig_names), int(is_mutect), int(sample), int(n_threads),
+                              int(rank), int(world), C.byref(h)):
         raise ValueError(_err(lib))
-    return NativeVcfFile(h, lib, is_mutect)
+    f = NativeVcfFile(h, lib, is_mutect)
+    nt, lo = C.c_int64(), C.c_int64()
+    lib.ugvc_vcf_part_info(h, C.byref(nt), C.byref(lo))
+    f.n_total, f.part_lo = int(nt.value), int(lo.value)
+    f.sorted_in_file = bool(f.n == 0 or np.array_equal(f.order, np.arange(f.n, dtype=np.int64)))
+    return f
 
 
 def write_filtered_vcf(path: str, vcf: NativeVcfFile, res: S.FilterResult, blacklist_cg: np.ndarray | None = None,

@@ -71,11 +71,31 @@ def run(argv: list[str]):
     ctx_pool = ThreadPoolExecutor(max_workers=1)
     f_eng = ctx_pool.submit(Engine, device)
     logger.info("reading side tables and %s", args.input_file)
+    # Rank 0 reads the whole callset (it writes the output: it needs every record's text); every OTHER rank tokenises only its
+    # equal-count slice of the records (vcf_native.read_vcf(part=...): the file is still inflated and cut into lines, the
+    # tokeniser / ordering / column stages - two thirds of the reader's time - run on 1 / world of them).  That slice is the
+    # rank's shard of the SORTED callset only if the file is sorted: established below across ranks, else every rank reads all.
+    part = (grp.rank, grp.world) if grp.world > 1 and grp.rank > 0 else None
     try:
         ref, runs, tracks, bl, extra = common.load_side_tables(
             args.reference_file, args.runs_file, args.annotate_intervals, args.blacklist,
-            also={"vcf": lambda names: vcfio.read_vcf(args.input_file, names, is_mutect=args.is_mutect, n_threads=n_threads)})
+            also={"vcf": lambda names: vcfio.read_vcf(args.input_file, names, is_mutect=args.is_mutect, n_threads=n_threads, part=part)})
         vcf = extra["vcf"]
+        if grp.world > 1:
+            import json
+            t = vcf.table
+            mine_ok = bool(getattr(vcf, "sorted_in_file", True))
+            first = [int(t.contig[0]), int(t.pos[0])] if t.n else None
+            last = [int(t.contig[-1]), int(t.pos[-1])] if t.n else None
+            infos = [json.loads(b.decode()) for b in grp.allgather_bytes(json.dumps(
+                dict(ok=mine_ok, n_total=int(getattr(vcf, "n_total", t.n)), first=first, last=last)).encode())]
+            seams = all(infos[r]["last"] is None or infos[r + 1]["first"] is None or infos[r]["last"] <= infos[r + 1]["first"]
+                        for r in range(1, grp.world - 1))
+            parts_ok = all(i["ok"] for i in infos) and len({i["n_total"] for i in infos}) == 1 and seams
+            if not parts_ok and part is not None:           # an unsorted file: the shards are slices of the SORTED callset - read all
+                vcf.close()
+                vcf = vcfio.read_vcf(args.input_file, ref.names, is_mutect=args.is_mutect, n_threads=n_threads)
+            part = part if parts_ok else None
         # an estimator fitted on a named frame finds its interval columns by BED stem (`LCR-hs38`, `exome.twist`, ...)
         forests = model_io.load_model_file(args.model_file, args.model_name, track_names=[t.name for t in tracks])
         common.check_model_tracks(forests, len(tracks), "filter_variants_pipeline")
@@ -90,6 +110,21 @@ def run(argv: list[str]):
     hp_len, hp_dist = args.hpol_filter_length_dist
     # one row per ALT allele (multi-allelic records, spanning deletions: io/multiallelic.py), one verdict per record
     table, base_row = multiallelic.expand(vcf)
+    if grp.world > 1:
+        # shards = equal-count slices of the RECORDS (a record's allele rows stay together): rows [rb[r], rb[r + 1]) of the
+        # expanded table on a rank that holds all of it, the whole expanded part on a rank that read its slice only
+        import json
+        import numpy as np
+        n_rec = int(getattr(vcf, "n_total", vcf.table.n))
+        b = shard.shard_bounds(n_rec, grp.world)
+        if part is None:
+            rb = np.searchsorted(base_row, b, side="left")
+            mine = table.slice(int(rb[grp.rank]), int(rb[grp.rank + 1]))
+        else:
+            if int(vcf.part_lo) != int(b[grp.rank]) or vcf.table.n != int(b[grp.rank + 1] - b[grp.rank]):
+                raise RuntimeError("internal: the codec's part bounds differ from shard.shard_bounds")
+            mine = table
+        counts = [int(x.decode()) for x in grp.allgather_bytes(str(mine.n).encode())]
     with f_eng.result() as eng:
         ctx_pool.shutdown()
         if grp.world == 1:
@@ -98,8 +133,6 @@ def run(argv: list[str]):
             res_rows = eng.filter_variants(table)
             lap("upload variants + scoring pass + download")
         else:
-            b = shard.shard_bounds(table.n, grp.world)
-            mine = table.slice(int(b[grp.rank]), int(b[grp.rank + 1]))
             ref_r, runs_r, tracks_r, bl_r, mine_r = shard.slice_context(ref, runs, tracks, bl, mine, hpol_dist=hp_dist)
             configure(eng, ref_r, runs_r, tracks_r, bl_r, forests, args.flow_order, hp_len, hp_dist, True)
             uid = grp.broadcast_bytes(eng.comm_unique_id() if grp.rank == 0 else None, 0)
@@ -108,13 +141,14 @@ def run(argv: list[str]):
             if info["nranks"] != grp.world or info["rank"] != grp.rank:
                 raise RuntimeError(f"RCCL communicator reports {info}, launcher says rank {grp.rank} of {grp.world}")
             lap("context + uploads (reference slice, table slices, model) + RCCL communicator")
-            cap = shard.shard_cap(table.n, grp.world)
+            cap = max(counts)
             eng.upload_variants(mine_r)
             eng.filter_resident()
             eng.allgather_resident(cap)
-            res_rows = eng.gathered_download(cap, grp.world, [int(b[r + 1] - b[r]) for r in range(grp.world)])
+            res_rows = eng.gathered_download(cap, grp.world, counts)
             lap(f"upload shard + scoring pass + RCCL all-gather x{info['nranks']} + download")
-        res = multiallelic.collapse(res_rows, base_row, vcf.table.n)
+        # (only a rank that holds the whole callset folds the allele rows back: rank 0 - the others are done)
+        res = multiallelic.collapse(res_rows, base_row, vcf.table.n) if (grp.world == 1 or part is None) else None
     grp.barrier()
     if grp.rank != 0:
         grp.close()
