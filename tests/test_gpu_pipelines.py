@@ -258,6 +258,22 @@ def test_sec_training_then_correct_systematic_errors(tmp_path):
     assert np.array_equal(got_hit[~sliver], hit[~sliver]) and 0 < hit.sum() < on_db.sum()
     assert np.allclose(got_lr[on_db], ratio[on_db].astype(np.float32), rtol=1e-6, atol=1e-30)
     assert os.path.exists(out + ".tbi")
+    # ---- sec_validation (round 4): the database against the callset as a held-out sample - the consumer of the ratios
+    import csv
+    from variantcalling_amd.pipelines import sec_validation
+    prefix = str(tmp_path / "val")
+    assert sec_validation.run(["sec_validation", "--inputs", calls, "--inputs", str(tmp_path / "sample0.vcf.gz"), "--sec_db", db,
+                               "--reference_file", fa, "--output_prefix", prefix, "--min_ratio", "0.05"]) == 0
+    rows = list(csv.DictReader(open(prefix + ".sec_validation.csv")))
+    assert [r["sample"] for r in rows] == [calls, str(tmp_path / "sample0.vcf.gz"), "ALL"]
+    r0 = rows[0]
+    assert int(r0["n_calls"]) == vt.n and int(r0["n_on_database"]) == int(on_db.sum())
+    assert abs(int(r0["n_sec"]) - int(hit.sum())) <= int(sliver.sum())
+    assert abs(float(r0["ratio_q50"]) - float(np.quantile(ratio[on_db], 0.5))) <= 1e-9 * max(1.0, float(np.quantile(ratio[on_db], 0.5)))
+    assert int(rows[2]["n_calls"]) == int(rows[0]["n_calls"]) + int(rows[1]["n_calls"])
+    thr = list(csv.DictReader(open(prefix + ".sec_validation.thresholds.csv")))
+    ks = [int(t["n_sec"]) for t in thr]
+    assert ks == sorted(ks, reverse=True) and len(thr) == len(sec_validation.THRESHOLDS)       # a higher threshold tags fewer calls
 
 
 def _hip_device_count() -> int:

@@ -37,6 +37,8 @@ with tempfile.TemporaryDirectory() as d:
           f"{os.cpu_count()} host threads: total {total:.2f} s")
     for k, v in st.items():
         print(f"   {k:48s} {v:8.3f} s")
+    from variantcalling_amd.pipelines import common
+    print("   readers of the first stage (concurrent; seconds each): " + ", ".join(f"{k} {v:.3f}" for k, v in getattr(common.load_side_tables, "last_seconds", {}).items()))
     if n > 2_000_000 and len(sys.argv) < 3:
         sys.exit(0)                      # (the pure-Python comparison takes minutes at this size: pass any second argument to run it)
     t0 = time.perf_counter(); a = pyvcf.read_vcf(vcf, cs.ref.names); t_r = time.perf_counter() - t0

@@ -1,12 +1,13 @@
 """`python -m variantcalling_amd <tool> [args]`: the tools of this package under the names the reference registers
 (/root/reference/ugvc/__main__.py:42-56).  Each tool's `run` keeps its reference signature: the two filtering
 pipelines take argv with the tool name first (as simppl hands it over), evaluate_concordance takes the bare flags
-(/root/reference/ugvc/pipelines/evaluate_concordance.py:71,112-113); sec_training / correct_systematic_errors are the two SEC
-tools of /root/reference/ugvc/__main__.py:19,56 (flags BUILDER-DEFINED: the reference leaves them undocumented)."""
+(/root/reference/ugvc/pipelines/evaluate_concordance.py:71,112-113); sec_training / correct_systematic_errors / sec_validation /
+assess_sec_concordance are the four SEC tools of /root/reference/ugvc/__main__.py:19,44,56 (flags BUILDER-DEFINED: the reference
+leaves them undocumented)."""
 import sys
 
 TOOLS = ("filter_variants_pipeline", "train_models_pipeline", "training_prep_pipeline", "evaluate_concordance", "calibrate_bridging_snvs",
-         "sec_training", "correct_systematic_errors")
+         "sec_training", "correct_systematic_errors", "sec_validation", "assess_sec_concordance")
 
 
 def main(argv):

@@ -24,16 +24,28 @@ def load_side_tables(reference_file, runs_file, annotate_intervals, blacklist_fi
     if len(annotate_intervals or []) > S.MAX_TRACKS:
         raise ValueError(f"at most {S.MAX_TRACKS} --annotate_intervals files are supported")
     also = also or {}
+    import time
+    seconds = {}
+
+    def timed(name, f):
+        def g(*a):
+            t0 = time.perf_counter()
+            try:
+                return f(*a)
+            finally:
+                seconds[name] = time.perf_counter() - t0
+        return g
+    load_side_tables.last_seconds = seconds                  # (read by tools/bench_pipeline.py: which reader the stage waits for)
     with ThreadPoolExecutor(max_workers=8) as pool:
-        f_ref = pool.submit(vcf_native.read_fasta, reference_file)
+        f_ref = pool.submit(timed("reference", vcf_native.read_fasta), reference_file)
         names = vcf_native.read_fasta_names(reference_file) if os.path.exists(reference_file + ".fai") else None
         if names is None:
             names = f_ref.result().names
         # homopolymer runs are disjoint by nature; book-ended runs of different bases must stay separate
-        f_runs = pool.submit(vcf_native.read_intervals, runs_file, names, False) if runs_file else None
-        f_tracks = [pool.submit(vcf_native.read_intervals, p, names, True) for p in (annotate_intervals or [])]
-        f_bl = pool.submit(bed.read_blacklist, blacklist_file, names) if blacklist_file else None
-        f_also = {k: pool.submit(f, names) for k, f in also.items()}
+        f_runs = pool.submit(timed("runs", vcf_native.read_intervals), runs_file, names, False) if runs_file else None
+        f_tracks = [pool.submit(timed(f"track {os.path.basename(p)}", vcf_native.read_intervals), p, names, True) for p in (annotate_intervals or [])]
+        f_bl = pool.submit(timed("blacklist", bed.read_blacklist), blacklist_file, names) if blacklist_file else None
+        f_also = {k: pool.submit(timed(k, f), names) for k, f in also.items()}
         ref = f_ref.result()
         if list(ref.names) != list(names):
             raise ValueError(f"{reference_file}.fai does not list the contigs of {reference_file}")
