@@ -269,3 +269,21 @@ def test_threshold_model_is_monotone_and_scores_like_its_cells():
         assert np.all(np.diff(O.forest_predict(f, g)[1]) >= 0)
         g[:, 0], g[:, 1] = 30.0, np.linspace(0, 4, 200)
         assert np.all(np.diff(O.forest_predict(f, g)[1]) <= 0)
+
+
+def test_fai_index_points_at_every_contigs_first_base(tmp_path):
+    """io.fasta.write_fai (round 4): the samtools index of a FASTA written by write_fasta - with it beside the reference the
+    tools know the contig names at once and start every side-table reader together with the FASTA reader."""
+    from variantcalling_amd import synth
+    from variantcalling_amd.io import fasta, vcf_native as nv
+    cs = synth.make_callset(500, genome_len=1_000_003, n_contigs=3, seed=1)
+    p = str(tmp_path / "r.fa")
+    fasta.write_fasta(p, cs.ref)
+    fasta.write_fai(p, cs.ref)
+    raw = open(p, "rb").read()
+    for c, line in enumerate(open(p + ".fai")):
+        name, n, off, lb, lw = line.rstrip("\n").split("\t")
+        assert name == cs.ref.names[c] and int(n) == cs.ref.contig_len(c) and (int(lb), int(lw)) == (60, 61)
+        assert raw[int(off) - 1:int(off)] == b"\n"
+        assert raw[int(off):int(off) + 1] == fasta.CODE_TO_CHAR[cs.ref.codes[cs.ref.contig_off[c]]].encode()
+    assert nv.read_fasta_names(p) == list(cs.ref.names)

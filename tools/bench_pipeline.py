@@ -19,6 +19,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 cs = synth.make_callset(n, genome_len=400_000_000, n_contigs=4, seed=9)
 with tempfile.TemporaryDirectory() as d:
     fa = os.path.join(d, "ref.fa"); fasta.write_fasta(fa, cs.ref)
+    if not os.environ.get("UGVC_BENCH_NO_FAI"):
+        fasta.write_fai(fa, cs.ref)          # ("Indexed reference FASTA file": the readers start together)
     vcf = os.path.join(d, "calls.vcf.gz"); pyvcf.write_vcf_from_table(vcf, cs.variants, cs.ref.names)
     runs = os.path.join(d, "runs.bed"); bed.write_bed(runs, cs.runs, cs.ref.names)
     ann = []

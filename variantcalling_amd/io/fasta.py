@@ -63,3 +63,19 @@ def write_fasta(path: str, ref: Reference, width: int = 60) -> None:
                 fh.write(block.tobytes())
             if n > full:
                 fh.write(seq[full:].tobytes() + b"\n")
+
+
+def write_fai(path: str, ref: Reference, width: int = 60) -> None:
+    """The samtools `.fai` index beside a FASTA written by write_fasta(path, ref, width) (plain text only): name, length,
+    byte offset of the first base, bases per line, bytes per line.  The tools take "--reference_file: Indexed reference
+    FASTA file" (docs/filter_variants_pipeline.md:38-39): with the index beside it the contig names are known at once and
+    every side-table reader starts together with the FASTA reader instead of after it."""
+    if path.endswith(".gz"):
+        raise ValueError("write_fai: a gzip FASTA is indexed with a .gzi as well; write a plain FASTA")
+    off = 0
+    with open(path + ".fai", "w") as fh:
+        for c, name in enumerate(ref.names):
+            n = int(ref.contig_off[c + 1] - ref.contig_off[c])
+            off += len(name) + 2                                   # ">name\n"
+            fh.write(f"{name}\t{n}\t{off}\t{width}\t{width + 1}\n")
+            off += n + (n + width - 1) // width                   # the bases and one newline per line
