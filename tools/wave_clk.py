@@ -65,7 +65,7 @@ if os.path.exists(sys.argv[1] + ".prev"):
         print(f"of the 26 slowest workgroups, {len(slow_a & slow_b)} are among the 26 slowest of the previous pass")
         # per-wave correlation inside a workgroup: is it one wave that is late, or the whole workgroup?
         ea = np.where(live, end - t0, 0)
-        print("mean over workgroups of (workgroup end - median wave end):", int((wg_end - np.median(np.where(live, ea, np.nan), axis=1)).mean()))
+        print("mean over workgroups of (workgroup end - median wave end):", int(np.nanmean(wg_end - np.nanmedian(np.where(live, ea, np.nan), axis=1))))
 # ---- the slowest workgroups wave by wave, beside a median one
 med = int(np.argsort(wg_end)[len(wg_end) // 2])
 for b in list(order[:3]) + [med]:
