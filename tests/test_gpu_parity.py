@@ -76,6 +76,57 @@ def test_feature_matrix_bit_exact(engine, small_callset, frozen_models):
     assert np.array_equal(g, ft["group"].astype(np.uint8))
 
 
+def test_feature_matrix_with_a_model_too_large_for_the_fused_kernel(engine, small_callset, frozen_models):
+    """a group-0 forest that fits the v3 kernels' LDS budget but not the fused kernel's (64 complete trees of depth
+    8 with few distinct payloads) sends the SCORING pass to v3 - and must not make the feature matrix, which needs no model,
+    fail: the feature-matrix launch leaves the forest out of its LDS budget."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_fuzz import _random_forest
+    from variantcalling_amd import model_io, schema as S
+    cs = small_callset
+    O = _oracle()
+    rng = np.random.default_rng(77)
+    # (coarse fractions: a handful of distinct payloads; the dense tables are sized by trees x 2^depth whatever the trees' shape)
+    big = _random_forest(rng, S.MODEL_RF, 17 + len(cs.tracks), 64, 8, normalised="coarse")
+    big.max_depth = max(model_io._depth(big.left, big.right, big.feature, int(r)) for r in big.tree_root)
+    assert big.max_depth == 8 and big.n_trees == 64
+    forests = [big, frozen_models[RF][1], frozen_models[RF][2]]
+    _configure(engine, cs.ref, cs.runs, cs.tracks, cs.blacklist, forests)
+    X, g = engine.feature_matrix(cs.variants)                      # used to return -1: "the SNP forest does not fit the fused kernel's LDS"
+    ft = O.featurize(cs.variants, cs.ref, cs.runs, cs.tracks)
+    assert np.array_equal(X, ft["X"]) and np.array_equal(g, ft["group"].astype(np.uint8))
+    res = engine.filter_variants(cs.variants)                      # whatever path takes it (v3 when the fused kernel cannot hold the forest)
+    _assert_same(res, O.filter_variants(cs.variants, cs.ref, cs.runs, cs.tracks, cs.blacklist, forests), "large group-0 forest")
+
+
+def _hip_device_count() -> int:
+    import ctypes
+    n = ctypes.c_int(0)
+    try:
+        ctypes.CDLL("libamdhip64.so").hipGetDeviceCount(ctypes.byref(n))
+    except OSError:
+        return 0
+    return n.value
+
+
+def test_v3_path_on_the_second_device(small_callset, frozen_models):
+    """the v3 kernels' dynamic-LDS attribute is set per DEVICE (kernels_v3.hip) - a process that scores on device 1
+    after device 0 used to launch with the default limit there.  Needs two GPUs."""
+    if _hip_device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from variantcalling_amd.engine import Engine
+    cs = small_callset
+    O = _oracle()
+    exp = O.filter_variants(cs.variants, cs.ref, cs.runs, cs.tracks, cs.blacklist, frozen_models[RF])
+    for dev in (0, 1):
+        with Engine(dev) as eng:
+            _configure(eng, cs.ref, cs.runs, cs.tracks, cs.blacklist, frozen_models[RF])
+            for path in (65536, 0):
+                eng.set_kernel_variant(path)
+                _assert_same(eng.filter_variants(cs.variants), exp, f"device {dev} path {path}")
+
+
 @PATHS
 def test_filter_edge_cases_real_hg38(engine, frozen_models, path):
     """Contig ends, N runs, 50 kb 'N homopolymers', MNPs, 60 bp indels, dp = 0, empty track contig."""
