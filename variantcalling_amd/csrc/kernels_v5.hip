@@ -220,35 +220,6 @@ __device__ __forceinline__ int join_one_global(const FilterArgs* ap, int t, int 
     return rank;
 }
 
-// A further contig segment of a tile that spans a contig boundary (lanes lo .. hi, contig `bk.c` after the caller's wave
-// search at the segment's first variant): every lane finds its ranks by a galloping search FROM the segment's ranks - a
-// handful of probes on the cache lines next to them - instead of a binary search over the contig's whole row range (~100
-// dependent round trips to HBM for the five tables).  Rare (a tile per contig boundary and class), so the code is kept small:
-// no staging.  Leaves the ranks at lane `hi` in bk.
-template <int NT>
-__device__ __forceinline__ void cold_segment_joins(const FilterArgs& a, Brk<NT>& bk, int pos, uint64_t key, int hi, JoinOut& jo) {
-    auto gallop = [&](auto&& below, int lo, int end) {              // first index in [lo, end] that is not `below`, bracketed by doubling
-        int step = 1;
-        while (lo + step < end && below(lo + step)) step <<= 1;
-        return min(lo + step + 1, end);
-    };
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        if ((t == 0 && !a.has_runs) || bk.phi[t] <= bk.plo[t]) continue;
-        const TrackView& tv = table_view(a, t);
-        const int lo = max(bk.L[t], bk.plo[t]);
-        const int end = gallop([&](int r) { return tv.starts[r] < pos; }, lo, bk.phi[t]);
-        const int sg = join_one_global(&a, t, lo, end, bk.plo[t], bk.phi[t], pos, key, &jo);
-        bk.L[t] = __builtin_amdgcn_readlane(sg, hi);
-    }
-    if (a.n_bl > 0) {
-        const int lo = bk.Lb;
-        const int end = gallop([&](int r) { return a.bl[r] < key; }, lo, (int)a.n_bl);
-        const int rb = join_one_global(&a, kJoin5 - 1, lo, end, 0, 0, pos, key, &jo);
-        bk.Lb = __builtin_amdgcn_readlane(rb, hi);
-    }
-}
-
 // Indel tiles cover ~5x the span of an SNP tile, so their slices are staged per table, from two rows before the
 // carried rank: two rows per lane (kIndelRows), fetched into registers one tile ahead and written to the wave's
 // scratch two tables at a time once the window rows are dead; six rows per lane for a table the host marks dense
@@ -623,20 +594,17 @@ __device__ __forceinline__ void featurize_snp_tile(const V5Args& v, const Scratc
     const int c = k.c, pos = k.pos, rl = k.rl;
     const uint32_t ro = k.ro, ao = k.ao;
     const int c0 = rfl(c);
-    // A tile's rows are sorted by (contig, pos) and its padding lanes repeat lane 0's row: the live lanes of the FIRST contig
-    // are a prefix.  All but a handful of tiles have one contig; one that spans a contig boundary is joined segment by
-    // segment (round 4: it used to send every lane through its own 20-step binary searches in HBM - ~100 dependent round
-    // trips, 60-85 k ticks - and the 23 workgroups that hold such a boundary were the slowest of every launch, which then
-    // waited for them: profiles/r04_wave_clk_static.txt).
+    // Every lane of a tile belongs to ONE contig: the tile loop ends a tile where the contig changes (fused5_kernel: tile_cut)
+    // and the padding lanes repeat lane 0's row.  (Round 3 sent a tile that spanned two contigs through per-lane 20-step binary
+    // searches in HBM, ~100 dependent round trips: the 23 workgroups that hold a contig boundary were the slowest of every
+    // launch, which waited for them - profiles/r04_wave_clk_static.txt.)
     const int n_live = (int)__popcll(__ballot(live));
-    const int n_seg0 = (int)__popcll(__ballot(live && c == c0));
-    const bool uni = __ballot(c != c0) == 0;                    // one contig (all but a handful of tiles)
     const bool joins_on = !(a.ablate & 524288);
     if (c0 != bk.c) {                                           // the wave's first tile, or a new contig: search afresh
         brk_refresh<NT>(a, bk, c0, rfl(pos), lane);
         if (joins_on) issue_slices<NT>(v, bk, lane, pre);
     }
-    const int64_t clo = uni ? bk.clo : a.contig_off[c], chi = uni ? bk.chi : a.contig_off[c + 1];
+    const int64_t clo = bk.clo, chi = bk.chi;
     const uint32_t clen = (uint32_t)(chi - clo);
     const uint32_t p0 = (uint32_t)(pos - 1);
     const int64_t g0 = clo + p0;
@@ -671,26 +639,7 @@ __device__ __forceinline__ void featurize_snp_tile(const V5Args& v, const Scratc
 
     // ---- joins
     JoinOut jo{false, false, false, 0u};
-    if (joins_on) {
-        snp_join_segment<NT>(v, sc, bk, pre, lane, pos, key, c0, max(n_seg0, 1) - 1, jo);
-        if (!uni) {
-            // the further contigs of the tile: a fresh wave search at each segment's first variant, then short per-lane searches
-            int lo = n_seg0;
-            while (lo < n_live) {
-                const int cs = __builtin_amdgcn_readlane(c, lo);
-                const int hi = lo + (int)__popcll(__ballot(live && c == cs)) - 1;
-                brk_refresh<NT>(a, bk, cs, __builtin_amdgcn_readlane(pos, lo), lane);
-                JoinOut js{false, false, false, 0u};
-                // (lanes of the tile's other contigs search for the segment's FIRST variant: their own positions would send the
-                // galloping search across the whole contig)
-                const bool mine = lane >= lo && lane <= hi;
-                const int pos_s = mine ? pos : __builtin_amdgcn_readlane(pos, lo);
-                cold_segment_joins<NT>(a, bk, pos_s, ((uint64_t)(uint32_t)cs << 32) | (uint32_t)pos_s, hi, js);
-                if (mine) jo = js;
-                lo = hi + 1;
-            }
-        }
-    }
+    if (joins_on) snp_join_segment<NT>(v, sc, bk, pre, lane, pos, key, c0, n_live - 1, jo);
     uint8_t flags = (uint8_t)(jo.trk << UGVC_FLAG_TRACK0_SHIFT);
     if (jo.cohort) flags |= UGVC_FLAG_COHORT_FP;
     if (a.mark_hpol && (jo.inside_run || jo.close_run)) flags |= UGVC_FLAG_HPOL_RUN;
@@ -835,7 +784,7 @@ __device__ __forceinline__ IndelCols load_indel_cols(const FilterArgs& a, uint32
 }
 
 template <int NTRK, bool WX>
-__device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scratch& sc, uint32_t rshard, int lane, uint32_t i, bool live,
+__device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scratch& sc, uint32_t rshard, int split, int lane, uint32_t i, bool live,
                                                      const IndelCols& k, Brk<1 + NTRK>& bk, IndelPre<1 + NTRK>& pre, PhaseClk& pc) {
     constexpr int NT = 1 + NTRK;
     const FilterArgs& a = v.f;
@@ -846,7 +795,6 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
     const float qual = k.qual, sor = k.sor;
     const int dp = k.dp, adr = k.adr, ada = k.ada, gq = k.gq;
     const int c0 = rfl(c);
-    const bool uni = __ballot(c != c0) == 0;
     if (c0 != bk.c) {                                           // the wave's first tile, or a new contig: search afresh
         brk_refresh<NT>(a, bk, c0, rfl(pos), lane);
         if (joins_on) issue_indel_slices<NTRK>(v, bk, lane, pre);
@@ -855,7 +803,7 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
     const bool ins = rl < al;
     const int classify = ins ? 1 : 2;
     const int indel_length = ins ? al - rl : rl - al;
-    const int64_t clo = uni ? bk.clo : a.contig_off[c], chi = uni ? bk.chi : a.contig_off[c + 1];
+    const int64_t clo = bk.clo, chi = bk.chi;                  // (one contig per tile: fused5_kernel, tile_cut)
     const uint32_t clen = (uint32_t)(chi - clo);
     const uint32_t p0 = (uint32_t)(pos - 1);
     const int64_t g0 = clo + p0;
@@ -944,13 +892,23 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
     }
     // ---- record slots: one returning atomic per wave and group (issued here: its round trip runs under the joins)
     const bool mine = live && pg_ok;
+    // A tile is a run of <= 64 list entries from any offset (tile_cut): its first `split` lanes belong to the 64-entry block
+    // `rshard`, the others to the next one - each lane's record goes to ITS block's shard, so a (workgroup, block) pair never
+    // holds more than 64 records (what the shards are sized for); an aligned tile (split = 64: all but the few behind a contig
+    // boundary) issues the two atomics of round 3.
+    const unsigned long long lowm = split >= 64 ? ~0ull : ((1ull << split) - 1ull);
     const unsigned long long m1 = __ballot(mine && group == 1), m2 = __ballot(mine && group == 2);
-    const int shard = (int)(rshard & (kShards - 1));
+    const bool hi_blk = lane >= split;
+    const int shard0 = (int)(rshard & (kShards - 1)), shard1 = (int)((rshard + 1u) & (kShards - 1));
+    const int shard = hi_blk ? shard1 : shard0;
     unsigned got = 0;
-    if (lane == 1 && m1 != 0) got = atomicAdd(&v.counters[(1 * kShards + shard) * kCounterStride], (unsigned)__popcll(m1));
-    if (lane == 2 && m2 != 0) got = atomicAdd(&v.counters[(2 * kShards + shard) * kCounterStride], (unsigned)__popcll(m2));
+    if (lane == 1 && (m1 & lowm) != 0) got = atomicAdd(&v.counters[(1 * kShards + shard0) * kCounterStride], (unsigned)__popcll(m1 & lowm));
+    if (lane == 2 && (m2 & lowm) != 0) got = atomicAdd(&v.counters[(2 * kShards + shard0) * kCounterStride], (unsigned)__popcll(m2 & lowm));
+    if (lane == 3 && (m1 & ~lowm) != 0) got = atomicAdd(&v.counters[(1 * kShards + shard1) * kCounterStride], (unsigned)__popcll(m1 & ~lowm));
+    if (lane == 4 && (m2 & ~lowm) != 0) got = atomicAdd(&v.counters[(2 * kShards + shard1) * kCounterStride], (unsigned)__popcll(m2 & ~lowm));
     const unsigned long long below = (1ull << lane) - 1;
-    const unsigned grank = (unsigned)__popcll((group == 1 ? m1 : m2) & below);
+    const unsigned long long mine_blk = (group == 1 ? m1 : m2) & (hi_blk ? ~lowm : lowm);
+    const unsigned grank = (unsigned)__popcll(mine_blk & below);
 
     // ---- get_motif_around (5), gc_content (10)
     int W[11];
@@ -983,7 +941,7 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
     // ---- joins: the staged slices, two tables at a time in the scratch the window rows have left
     const uint64_t key = ((uint64_t)(uint32_t)c << 32) | (uint32_t)pos;
     JoinOut jo{false, false, false, 0u};
-    // the joins of one contig segment of the tile (lanes .. last share contig c_seg; almost always the whole tile)
+    // the joins of the tile (lanes 0 .. last are live, contig c_seg)
     auto join_seg = [&](int c_seg, int last, JoinOut& jo) {
         const int pos_max = __builtin_amdgcn_readlane(pos, last);
         const uint32_t s0 = sc.base, s1 = sc.base + kIndelSlotB;
@@ -1113,27 +1071,7 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
         for (int t = 0; t < NT; ++t) bk.L[t] = __builtin_amdgcn_readlane(sg_l[t], last);
         bk.Lb = __builtin_amdgcn_readlane(rb_l, last);
     };
-    if (joins_on) {
-        // (a tile that spans a contig boundary is joined segment by segment - see featurize_snp_tile)
-        const int n_seg0 = (int)__popcll(__ballot(live && c == c0));
-        join_seg(c0, max(n_seg0, 1) - 1, jo);
-        if (!uni) {
-            int lo = n_seg0;
-            while (lo < n_live) {
-                const int cs = __builtin_amdgcn_readlane(c, lo);
-                const int hi = lo + (int)__popcll(__ballot(live && c == cs)) - 1;
-                brk_refresh<NT>(a, bk, cs, __builtin_amdgcn_readlane(pos, lo), lane);
-                JoinOut js{false, false, false, 0u};
-                // (lanes of the tile's other contigs search for the segment's FIRST variant: their own positions would send the
-                // galloping search across the whole contig)
-                const bool mine = lane >= lo && lane <= hi;
-                const int pos_s = mine ? pos : __builtin_amdgcn_readlane(pos, lo);
-                cold_segment_joins<NT>(a, bk, pos_s, ((uint64_t)(uint32_t)cs << 32) | (uint32_t)pos_s, hi, js);
-                if (mine) jo = js;
-                lo = hi + 1;
-            }
-        }
-    }
+    if (joins_on) join_seg(c0, n_live - 1, jo);
     uint8_t flags = (uint8_t)(jo.trk << UGVC_FLAG_TRACK0_SHIFT);
     if (jo.cohort) flags |= UGVC_FLAG_COHORT_FP;
     if (a.mark_hpol && (jo.inside_run || jo.close_run)) flags |= UGVC_FLAG_HPOL_RUN;
@@ -1189,9 +1127,10 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
     r[9] = ((jo.trk >> 1) & 1u ? 2u : 1u) | (((jo.trk >> 2) & 1u ? 2u : 1u) << 16);
     r[10] = ((jo.trk >> 3) & 1u ? 2u : 1u) | (((jo.trk >> 4) & 1u ? 2u : 1u) << 16);
     r[11] = i;
-    const unsigned b1 = __shfl(got, 1), b2 = __shfl(got, 2);
+    const unsigned b1 = __shfl(got, 1), b2 = __shfl(got, 2), b3 = __shfl(got, 3), b4 = __shfl(got, 4);
     if (mine) {
-        uint4* dst = v.rec5[group] + ((size_t)shard * v.shard_cap5 + (group == 1 ? b1 : b2) + grank) * 3;
+        const unsigned slot0 = group == 1 ? (hi_blk ? b3 : b1) : (hi_blk ? b4 : b2);
+        uint4* dst = v.rec5[group] + ((size_t)shard * v.shard_cap5 + slot0 + grank) * 3;
         dst[0] = make_uint4(r[0], r[1], r[2], r[3]);
         dst[1] = make_uint4(r[4], r[5], r[6], r[7]);
         dst[2] = make_uint4(r[8], r[9], r[10], r[11]);
@@ -1396,6 +1335,39 @@ static size_t lds5_bytes(const V5Args& v, int n_waves) {
     return b + (size_t)(n_waves - n_iw) * v.scratch_bytes + (size_t)n_iw * v.scratch_indel;
 }
 
+// ---- a tile ends where the contig changes (round 4) ----------------------------------------------------------
+// A wave's tiles are runs of <= 64 consecutive entries of its workgroup's list, taken from a list OFFSET: when the live lanes of
+// a tile hold two contigs (one tile per contig boundary and class) the tile is cut after the first contig's rows - the others
+// wait for the next tile, which starts at the boundary - so that featurize_*_tile only ever sees one contig.  The lanes cut off
+// repeat lane 0's row, like the padding lanes of a list's last tile.  Returns the number of entries the tile consumes.
+__device__ __forceinline__ float rfl_f(float x) { return __int_as_float(rfl(__float_as_int(x))); }
+__device__ __forceinline__ int tile_cut(bool& live, uint32_t& i, SnpCols& k) {
+    const int c0 = rfl(k.c);
+    const unsigned long long lv = __ballot(live), same = __ballot(live && k.c == c0);
+    if (same == lv) return 64;
+    const int n0 = (int)__popcll(same);
+    live = live && k.c == c0;                                       // (rows are sorted by contig: a prefix of the live lanes)
+    if (!live) {
+        i = (uint32_t)rfl((int)i);
+        k.c = c0; k.pos = rfl(k.pos); k.rl = rfl(k.rl); k.ro = (uint32_t)rfl((int)k.ro); k.ao = (uint32_t)rfl((int)k.ao);
+        k.qual = rfl_f(k.qual); k.sor = rfl_f(k.sor); k.dp = rfl(k.dp); k.adr = rfl(k.adr); k.ada = rfl(k.ada); k.gq = rfl(k.gq);
+    }
+    return n0;
+}
+__device__ __forceinline__ int tile_cut(bool& live, uint32_t& i, IndelCols& k) {
+    const int c0 = rfl(k.c);
+    const unsigned long long lv = __ballot(live), same = __ballot(live && k.c == c0);
+    if (same == lv) return 64;
+    const int n0 = (int)__popcll(same);
+    live = live && k.c == c0;
+    if (!live) {
+        i = (uint32_t)rfl((int)i);
+        k.c = c0; k.pos = rfl(k.pos); k.rl = rfl(k.rl); k.al = rfl(k.al); k.ro = (uint32_t)rfl((int)k.ro); k.ao = (uint32_t)rfl((int)k.ao);
+        k.qual = rfl_f(k.qual); k.sor = rfl_f(k.sor); k.dp = rfl(k.dp); k.adr = rfl(k.adr); k.ada = rfl(k.ada); k.gq = rfl(k.gq);
+    }
+    return n0;
+}
+
 // ---- Kf: persistent, one workgroup per CU; every wave works through tiles on its own --------------------
 // A workgroup owns `rows_wg` consecutive rows of the callset.  Prologue (the only workgroup barriers): the forest
 // and the threshold tables go to LDS while every wave counts the variant classes of its sixteenth of the rows; the
@@ -1539,54 +1511,62 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
 #ifdef UGVC_PHASE_CLOCK
         pc.last = __builtin_readcyclecounter();
         const uint64_t t_begin = pc.last;
-        int n_done = 0;
 #endif
         Brk<NT> bk{};
         bk.c = -1;
         IndelPre<NT> pre{};
-        auto ids_of = [&](int64_t t, uint32_t& i, bool& live) {
-            const uint32_t id = li[t * 64 + lane];
-            live = id != ~0u;
+        // this wave's entries of the workgroup's indel list; a tile = up to 64 of them from an offset (tile_cut)
+        const int64_t e0 = t0 * 64, e1 = min(t1 * 64, (int64_t)ni_l);
+        auto ids_at = [&](int64_t off, uint32_t& i, bool& live) {
+            const uint32_t id = li[off + lane];                // (the list is padded by 64 entries: off < e1 <= ni_l)
+            live = id != ~0u && off + lane < e1;
             const uint32_t id0 = (uint32_t)rfl((int)id);       // (outside the select: a ternary would read the first PADDING lane)
             i = live ? id : id0;
         };
         uint32_t i, i_n = 0;
         bool live, live_n = false;
-        ids_of(t0, i, live);
+        int64_t off = e0;
+        ids_at(off, i, live);
         IndelCols cols = load_indel_cols(a, i);
-        if (t0 + 1 < t1) ids_of(t0 + 1, i_n, live_n);
+        if (off + 64 < e1) ids_at(off + 64, i_n, live_n);
+        unsigned n_done = 0;
         const UGVC_CONST V5Args* const vk = (const UGVC_CONST V5Args*)__builtin_amdgcn_kernarg_segment_ptr();
-        for (int64_t t = t0; t < t1; ++t) {
+        for (;;) {
             const UGVC_CONST V5Args* vq = vk;                   // (launch arguments re-read per tile, as in the SNP loop below)
             asm volatile("" : "+s"(vq));
             const V5Args& vt = *(const V5Args*)vq;
+            const int take = tile_cut(live, i, cols);
+            const int64_t off_n = off + take;
+            if (take != 64 && off_n < e1) ids_at(off_n, i_n, live_n);   // (the ids fetched ahead were those of off + 64)
+            const bool more = off_n < e1;
             // two tiles ahead: row indices; one tile ahead: columns (both in flight during this tile)
             uint32_t i_n2 = 0;
             bool live_n2 = false;
             IndelCols cols_n = cols;
-            if (t + 1 < t1) cols_n = load_indel_cols(vt.f, i_n);
+            if (more) cols_n = load_indel_cols(vt.f, i_n);
+            const int64_t off_n2 = off_n + 64;
             uint32_t id_n2 = ~0u;
-            if (t + 2 < t1) id_n2 = li[(t + 2) * 64 + lane];
-            featurize_indel_tile<NTRK, WX>(vt, sc, (uint32_t)(blockIdx.x * 7 + t), lane, i, live, cols, bk, pre, pc);
-            if (t + 1 < t1 && joins_on && bk.c >= 0) issue_indel_slices<NTRK>(vt, bk, lane, pre);
-            if (t + 2 < t1) {
-                live_n2 = id_n2 != ~0u;
+            if (more && off_n2 < e1) id_n2 = li[off_n2 + lane];
+            featurize_indel_tile<NTRK, WX>(vt, sc, (uint32_t)(blockIdx.x * 7 + (off >> 6)), 64 - (int)(off & 63), lane, i, live, cols, bk, pre, pc);
+            ++n_done;
+            if (!more) break;
+            if (joins_on && bk.c >= 0) issue_indel_slices<NTRK>(vt, bk, lane, pre);
+            {
+                live_n2 = id_n2 != ~0u && off_n2 + lane < e1;
                 const uint32_t id0 = (uint32_t)rfl((int)id_n2);
                 i_n2 = live_n2 ? id_n2 : id0;
             }
+            off = off_n;
             cols = cols_n; i = i_n; live = live_n; i_n = i_n2; live_n = live_n2;
             __builtin_amdgcn_wave_barrier();
-#ifdef UGVC_PHASE_CLOCK
-            ++n_done;
-#endif
         }
         if (v.wave_clk && lane == 0) {
             unsigned long long* w = v.wave_clk + ((size_t)blockIdx.x * 16 + wave) * 4;
-            w[0] = wclk_entry; w[1] = wclk_first; w[2] = __builtin_readcyclecounter(); w[3] = (unsigned long long)(t1 - t0) | ((unsigned long long)(t1 - t0) << 32);
+            w[0] = wclk_entry; w[1] = wclk_first; w[2] = __builtin_readcyclecounter(); w[3] = (unsigned long long)n_done | ((unsigned long long)n_done << 32);
         }
 #ifdef UGVC_PHASE_CLOCK
         if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 133))
-            printf("iclk b%d w%d tiles %d total %llu | load+window %llu hmer+motif %llu joins %llu codes+record %llu (ranks %llu)\n", (int)blockIdx.x, wave, n_done,
+            printf("iclk b%d w%d tiles %d total %llu | load+window %llu hmer+motif %llu joins %llu codes+record %llu (ranks %llu)\n", (int)blockIdx.x, wave, (int)n_done,
                    (unsigned long long)(pc.last - t_begin), (unsigned long long)pc.acc[0], (unsigned long long)pc.acc[1], (unsigned long long)pc.acc[2],
                    (unsigned long long)pc.acc[3], (unsigned long long)pc.acc[6]);
 #endif
@@ -1599,30 +1579,33 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
     const int64_t t0 = (int64_t)wave * q, t1 = min(t0 + q, nst);
     if (t0 >= t1) return;
     const uint64_t wclk_first = v.wave_clk ? __builtin_readcyclecounter() : 0;
-    auto ids_of = [&](int64_t t, uint32_t& i, bool& live) {
-        const uint32_t id = ls[t * 64 + lane];
-        live = id != ~0u;
+    // this wave's entries of the workgroup's SNP list; a tile = up to 64 of them from an offset (tile_cut)
+    const int64_t e0 = t0 * 64, e1 = min(t1 * 64, (int64_t)ns_l);
+    auto ids_at = [&](int64_t off, uint32_t& i, bool& live) {
+        const uint32_t id = ls[off + lane];                    // (the list is padded by 64 entries: off < e1 <= ns_l)
+        live = id != ~0u && off + lane < e1;
         const uint32_t id0 = (uint32_t)rfl((int)id);
         i = live ? id : id0;
     };
     uint32_t i;
     bool live;
-    ids_of(t0, i, live);
+    int64_t off = e0;
+    ids_at(off, i, live);
     SnpCols cols = load_snp_cols(a, i);
     Brk<NT> bk{};
     bk.c = -1;
     SlicePre<NT> pre{};
     PhaseClk pc{};
+    unsigned n_done = 0;
 #ifdef UGVC_PHASE_CLOCK
     pc.last = __builtin_readcyclecounter();
     const uint64_t t_begin = pc.last;
-    int n_done = 0;
 #endif
     // A featurize phase is a short instruction stream between long memory waits; the walk is a long stream that waits
     // on LDS.  (Raised priority for the featurize phase - s_setprio - made no measurable difference: variant bit 29.)
     const bool prio = !(a.ablate & (1 << 29));
     const UGVC_CONST V5Args* const vk = (const UGVC_CONST V5Args*)__builtin_amdgcn_kernarg_segment_ptr();
-    for (int64_t t = t0; t < t1; ++t) {
+    for (;;) {
         // The launch arguments are read afresh in every tile (the pointer passes through an empty asm): hoisted out of
         // the loop they would sit in ~100 SGPRs, spill to VGPR lanes and come back as v_readlane - vector-ALU work, which
         // is what this kernel is short of; scalar loads from the constant cache are not.
@@ -1630,15 +1613,16 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
         asm volatile("" : "+s"(vq));
         const V5Args& vt = *(const V5Args*)vq;
         const FilterArgs& at = vt.f;
-        const bool more = t + 1 < t1;
+        const int64_t off_n = off + tile_cut(live, i, cols);    // (the tile ends where the contig changes)
+        const bool more = off_n < e1;
         uint32_t id_n = 0, i_n = 0;
         bool live_n = false;
         if (prio) __builtin_amdgcn_s_setprio(2);
-        if (more) id_n = ls[(t + 1) * 64 + lane];                // consumed after the joins
+        if (more) id_n = ls[off_n + lane];                       // consumed after the joins
         featurize_snp_tile<NTRK, WX>(vt, sc, lane, i, live, has0, cols, bk, pre, pc);
         SnpCols cols_n = cols;
         if (more) {
-            live_n = id_n != ~0u;
+            live_n = id_n != ~0u && off_n + lane < e1;
             const uint32_t id0 = (uint32_t)rfl((int)id_n);
             i_n = live_n ? id_n : id0;
             cols_n = load_snp_cols(at, i_n);                    // in flight during the walk
@@ -1658,20 +1642,20 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
             stg32(at.score, i, 0.f);
             stg32(at.filter, i, (uint8_t)UGVC_FILTER_PASS);
         }
+        ++n_done;
+        if (!more) break;
+        off = off_n;
         cols = cols_n; i = i_n; live = live_n;
         __builtin_amdgcn_wave_barrier();
         CLK(pc, 5);
-#ifdef UGVC_PHASE_CLOCK
-        ++n_done;
-#endif
     }
     if (v.wave_clk && lane == 0) {
         unsigned long long* w = v.wave_clk + ((size_t)blockIdx.x * 16 + wave) * 4;
-        w[0] = wclk_entry; w[1] = wclk_first; w[2] = __builtin_readcyclecounter(); w[3] = (unsigned long long)(t1 - t0);
+        w[0] = wclk_entry; w[1] = wclk_first; w[2] = __builtin_readcyclecounter(); w[3] = (unsigned long long)n_done;
     }
 #ifdef UGVC_PHASE_CLOCK
     if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 133))
-        printf("clk b%d w%d tiles %d total %llu | stage %llu window %llu joins %llu codes %llu cols_n %llu walk %llu\n", (int)blockIdx.x, wave, n_done,
+        printf("clk b%d w%d tiles %d total %llu | stage %llu window %llu joins %llu codes %llu cols_n %llu walk %llu\n", (int)blockIdx.x, wave, (int)n_done,
                (unsigned long long)(pc.last - t_begin), (unsigned long long)pc.acc[0], (unsigned long long)pc.acc[1], (unsigned long long)pc.acc[2],
                (unsigned long long)pc.acc[3], (unsigned long long)pc.acc[4], (unsigned long long)pc.acc[5]);
     if (lane == 0 && blockIdx.x == 0 && wave == 0)

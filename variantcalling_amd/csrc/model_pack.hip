@@ -703,6 +703,8 @@ int v5_fill_args(ugvc_ctx* ctx, V5Args& v, const FilterArgs& a, bool scoring) {
     v.list_stride = (v.rows_wg + kTile5 - 1) / kTile5 * kTile5 + kTile5;
     // record lists: a workgroup's indel tiles go round-robin over the kShards lists of their group
     const int64_t tiles_wg = v.list_stride / kTile5;
+    // (a tile is a run of <= 64 list entries from any offset - kernels_v5.hip: tile_cut - and every lane's record goes to the
+    // shard of the 64-entry block its entry lies in: at most 64 records per workgroup and block)
     v.shard_cap5 = (int)(n_wg * ((tiles_wg + kShards - 1) / kShards) * kTile5);
     if (ensure(s->snp_idx, (size_t)n_wg * v.list_stride * 4) || ensure(s->indel_idx, (size_t)n_wg * v.list_stride * 4)) return -1;
     const size_t c5_bytes = (size_t)UGVC_N_GROUPS * kShards * kCounterStride * 4;
