@@ -1,5 +1,6 @@
-cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
+# the library rebuilt with -DUGVC_PHASE_CLOCK in a scratch copy, one bench invocation; the LAST pass's lines per (kind, workgroup, wave)
+cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp UGVC_SYNTH_CACHE=/tmp/ugvc_synth
 rm -rf /tmp/clk && mkdir -p /tmp/clk && cp -r variantcalling_amd oracle include profiles tests bench.py /tmp/clk/ 2>/dev/null
 ( cd /tmp/clk/variantcalling_amd/csrc && touch kernels_v5.hip && make EXTRA=-DUGVC_PHASE_CLOCK -j8 > /tmp/clk/build.log 2>&1; tail -2 /tmp/clk/build.log )
-( cd /tmp/clk && python bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-e2e $CLK_ARGS 2>&1 | grep -E "^clk|^iclk|^fclk|issue" | sort | head -60 ) > gpurun_out/${CLK_OUT:-r04_phase_clocks.txt}
+( cd /tmp/clk && python bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-e2e $CLK_ARGS 2>&1 | grep -E "^clk|^iclk|^fclk|^  issue" | awk '{k=$1" "$2" "$3; last[k]=$0} END{for (k in last) print last[k]}' | sort ) > gpurun_out/${CLK_OUT:-r04_phase_clocks.txt}
 cat gpurun_out/${CLK_OUT:-r04_phase_clocks.txt}

@@ -155,7 +155,7 @@ __device__ __forceinline__ void brk_refresh(const FilterArgs& a, Brk<NT>& bk, in
 }
 
 #ifdef UGVC_PHASE_CLOCK
-struct PhaseClk { uint64_t last; uint64_t acc[8]; };
+struct PhaseClk { uint64_t last; uint64_t acc[16]; };
 #define CLK(pc, k) do { const uint64_t now_ = __builtin_readcyclecounter(); (pc).acc[k] += now_ - (pc).last; (pc).last = now_; } while (0)
 #else
 struct PhaseClk {};
@@ -163,6 +163,8 @@ struct PhaseClk {};
 #endif
 
 // ---- joins ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_max_i32(int x);
+struct __attribute__((packed, aligned(1))) U2u { uint32_t x, y; };     // an 8-byte load from any byte address
 struct JoinOut {
     bool inside_run, close_run, cohort;
     uint32_t trk;                    // bit t: inside an interval of annotation track t
@@ -358,21 +360,26 @@ __device__ __forceinline__ void rank3_sorted(const float (&fx)[3], uint32_t thr_
 // leaf index is the rank; three VALU per level and feature, reads of one level on consecutive LDS words.
 __device__ __forceinline__ void rank3_eyt(const float (&fx)[3], const uint32_t (&base)[3], const int (&bits)[3], const uint32_t (&len)[3],
                                           uint32_t (&cd)[3]) {
+    // (round 4: the level step is the walk's - v_lshl_add for the address off a SCALAR base, the compare into an SGPR pair,
+    // v_addc for i = 2 i + carry; written with a select and a shift-or the compiler spent 5.7 instructions per level and feature)
     uint32_t i[3] = {1u, 1u, 1u};
+    uint32_t b[3];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) b[e] = (uint32_t)rfl((int)base[e]);
     const int bmin = min(bits[0], min(bits[1], bits[2])), bmax = max(bits[0], max(bits[1], bits[2]));
     for (int s = 0; s < bmin; ++s) {
         float t[3];
 #pragma unroll
-        for (int e = 0; e < 3; ++e) t[e] = lds_f32(base[e] + 4u * i[e]);
+        for (int e = 0; e < 3; ++e) t[e] = lds_f32(b[e] + 4u * i[e]);
 #pragma unroll
-        for (int e = 0; e < 3; ++e) i[e] = 2u * i[e] + (t[e] < fx[e] ? 1u : 0u);
+        for (int e = 0; e < 3; ++e) i[e] = twice_plus_carry(i[e], __builtin_amdgcn_ballot_w64(t[e] < fx[e]));
     }
     for (int s = bmin; s < bmax; ++s) {
 #pragma unroll
         for (int e = 0; e < 3; ++e)
             if (s < bits[e]) {
-                const float t = lds_f32(base[e] + 4u * i[e]);
-                i[e] = 2u * i[e] + (t < fx[e] ? 1u : 0u);
+                const float t = lds_f32(b[e] + 4u * i[e]);
+                i[e] = twice_plus_carry(i[e], __builtin_amdgcn_ballot_w64(t < fx[e]));
             }
     }
 #pragma unroll
@@ -508,15 +515,27 @@ __device__ __forceinline__ void snp_join_segment(const V5Args& v, const Scratch&
         if (t == 0 && !a.has_runs) continue;
         const int cap = v.jcap[t];
         const uint32_t dS = sc.base + 4u * (uint32_t)v.joff[t], dE = dS + 4u * (uint32_t)cap;
-        {
-            const int gi = L[t] + lane;
-            lds_st32(dS + 4u * lane, gi < plo[t] ? INT32_MIN : (gi >= phi[t] ? INT32_MAX : pre.sv[t][0]));
+        // (the staged rows lie inside the contig's rows in all but a contig's first and last tiles: a wave-uniform test
+        // instead of two compares and two selects per lane and half)
+        const bool inner = L[t] >= plo[t] && L[t] + cap <= phi[t];
+        if (inner) {
+            lds_st32(dS + 4u * lane, pre.sv[t][0]);
             lds_st32(dE + 4u * lane, pre.ev[t][0]);
-        }
-        if (cap > 64) {
-            const int gi = L[t] + 64 + lane;
-            lds_st32(dS + 256u + 4u * lane, gi < plo[t] ? INT32_MIN : (gi >= phi[t] ? INT32_MAX : pre.sv[t][1]));
-            lds_st32(dE + 256u + 4u * lane, pre.ev[t][1]);
+            if (cap > 64) {
+                lds_st32(dS + 256u + 4u * lane, pre.sv[t][1]);
+                lds_st32(dE + 256u + 4u * lane, pre.ev[t][1]);
+            }
+        } else {
+            {
+                const int gi = L[t] + lane;
+                lds_st32(dS + 4u * lane, gi < plo[t] ? INT32_MIN : (gi >= phi[t] ? INT32_MAX : pre.sv[t][0]));
+                lds_st32(dE + 4u * lane, pre.ev[t][0]);
+            }
+            if (cap > 64) {
+                const int gi = L[t] + 64 + lane;
+                lds_st32(dS + 256u + 4u * lane, gi < plo[t] ? INT32_MIN : (gi >= phi[t] ? INT32_MAX : pre.sv[t][1]));
+                lds_st32(dE + 256u + 4u * lane, pre.ev[t][1]);
+            }
         }
     }
     if (a.n_bl > 0) lds_st64(sc.base + 4u * (uint32_t)v.joff[kJoin5 - 1] + 8u * lane, pre.bl);
@@ -811,6 +830,12 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
     if (ws < 0) ws = 0;
     const int o0 = (int)(g0 - ws);                            // byte of the variant's first base, 6..21 (less at genome start)
     const uint32_t wrow_b = sc.base + (uint32_t)(lane * kWinRowB);
+    // allele bytes: the tail of the longer allele.  Requested BEFORE the window: the window's rows go to LDS behind a wait for
+    // everything in flight, and loads written after that wait were a second dependent round trip of every tile (round 4).
+    const uint32_t lo_off = ins ? ao : ro;
+    const int ln = ins ? al : rl;
+    // (bases 1..8 of the allele as ONE unaligned 8-byte load - the pool is padded by 16 bytes, api.hip: ugvc_upload_variants)
+    const U2u abw = *reinterpret_cast<const U2u*>(apool + lo_off + 1);
     {
         const uint4* src = reinterpret_cast<const uint4*>(a.ref + ws);
         const uint4 x0 = src[0], x1 = src[1], x2 = src[2];
@@ -830,14 +855,6 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
 #pragma unroll
         for (int q = 0; q < kWinDw; ++q) lds_st32(wrow_b + 4u * q, (int32_t)w[q]);
     }
-    // allele bytes: the tail of the longer allele
-    const uint32_t lo_off = ins ? ao : ro;
-    const int ln = ins ? al : rl;
-    uint32_t ab[8];
-    ab[0] = apool[lo_off + 1];
-    ab[1] = apool[lo_off + (2 < ln ? 2 : ln - 1)];
-#pragma unroll
-    for (int q = 2; q < 8; ++q) ab[q] = apool[lo_off + (q + 1 < ln ? q + 1 : ln - 1)];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     CLK(pc, 0);
@@ -853,12 +870,24 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
     const int so = o0 + d_so;
     int hmer_len = 0, hmer_nuc = 0, run = 0;
     {
-        const int bb = (int)ab[0];
-        bool mono = true;
-#pragma unroll
-        for (int q = 1; q < 8; ++q) mono &= ab[q] == (uint32_t)bb;   // clamped reads repeat the last byte
-        if (ln > 9)
-            for (int q = 9; q < ln; ++q) mono &= apool[lo_off + q] == bb;
+        const int bb = (int)(abw.x & 0xFFu);
+        const uint32_t pat = (uint32_t)bb * 0x01010101u;
+        // bytes 0 .. n - 1 of a loaded 8-byte word against the first base, n = bases of the allele in the word
+        auto same8 = [&](uint32_t lo, uint32_t hi, int n) {
+            const uint32_t mlo = n >= 4 ? ~0u : (n <= 0 ? 0u : (1u << (8 * n)) - 1u);
+            const uint32_t mhi = n >= 8 ? ~0u : (n <= 4 ? 0u : (1u << (8 * (n - 4))) - 1u);
+            return (((lo ^ pat) & mlo) | ((hi ^ pat) & mhi)) == 0u;
+        };
+        bool mono = same8(abw.x, abw.y, ln - 1);
+        // (alleles longer than nine bases: eight bases per round trip - one dependent round trip per BYTE of the
+        // tile's longest allele until round 4)
+        if (__ballot(ln > 9) != 0) {
+            const int ln_max = wave_max_i32(ln);
+            for (int q0 = 9; q0 < ln_max; q0 += 8) {
+                const U2u x = *reinterpret_cast<const U2u*>(apool + lo_off + (uint32_t)min(q0, ln - 1));
+                mono &= same8(x.x, x.y, ln - q0);
+            }
+        }
         const uint32_t pstart = p0 + (uint32_t)d_so;
         if (mono && pstart < clen) {
             if (so + 12 <= kWinBytes) {
@@ -901,15 +930,23 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
     const bool hi_blk = lane >= split;
     const int shard0 = (int)(rshard & (kShards - 1)), shard1 = (int)((rshard + 1u) & (kShards - 1));
     const int shard = hi_blk ? shard1 : shard0;
+    // (ONE atomic instruction, executed by lanes 1..4 for the (group, block) pairs that have records: four `if (lane == k) got =
+    // atomicAdd(..)` statements compiled to four dependent round trips - each waits for the one before, `got` being one register)
     unsigned got = 0;
-    if (lane == 1 && (m1 & lowm) != 0) got = atomicAdd(&v.counters[(1 * kShards + shard0) * kCounterStride], (unsigned)__popcll(m1 & lowm));
-    if (lane == 2 && (m2 & lowm) != 0) got = atomicAdd(&v.counters[(2 * kShards + shard0) * kCounterStride], (unsigned)__popcll(m2 & lowm));
-    if (lane == 3 && (m1 & ~lowm) != 0) got = atomicAdd(&v.counters[(1 * kShards + shard1) * kCounterStride], (unsigned)__popcll(m1 & ~lowm));
-    if (lane == 4 && (m2 & ~lowm) != 0) got = atomicAdd(&v.counters[(2 * kShards + shard1) * kCounterStride], (unsigned)__popcll(m2 & ~lowm));
+    {
+        const unsigned c0 = (unsigned)__popcll(m1 & lowm), c1 = (unsigned)__popcll(m2 & lowm), c2 = (unsigned)__popcll(m1 & ~lowm),
+                       c3 = (unsigned)__popcll(m2 & ~lowm);
+        const unsigned i0 = (unsigned)((1 * kShards + shard0) * kCounterStride), i1 = (unsigned)((2 * kShards + shard0) * kCounterStride),
+                       i2 = (unsigned)((1 * kShards + shard1) * kCounterStride), i3 = (unsigned)((2 * kShards + shard1) * kCounterStride);
+        const unsigned cnt_k = lane == 1 ? c0 : (lane == 2 ? c1 : (lane == 3 ? c2 : (lane == 4 ? c3 : 0u)));
+        const unsigned idx_k = lane == 1 ? i0 : (lane == 2 ? i1 : (lane == 3 ? i2 : i3));
+        if (cnt_k != 0) got = atomicAdd(&v.counters[idx_k], cnt_k);
+    }
     const unsigned long long below = (1ull << lane) - 1;
     const unsigned long long mine_blk = (group == 1 ? m1 : m2) & (hi_blk ? ~lowm : lowm);
     const unsigned grank = (unsigned)__popcll(mine_blk & below);
 
+    CLK(pc, 8);                                                 // (hmer run, record slots requested)
     // ---- get_motif_around (5), gc_content (10)
     int W[11];
 #pragma unroll
@@ -954,15 +991,19 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
 #pragma unroll
         for (int t = 0; t < NT; ++t) sg_l[t] = bk.L[t];
         int rb_l = bk.Lb;
-        // the first dense table: its rows are requested now and arrive under the narrow rounds
+        // the first dense table: its rows are requested when the narrow slices have been staged and arrive under the narrow
+        // rounds.  (Requested BEFORE the staging, as until round 4, they were waited for there: the stores of the staged rows wait for
+        // everything in flight - the loop's back edge hides the order of the requests from the wait-count pass.)
         int tw = -1;
         int wv[kWideChunks], we[kWideChunks];
+        auto request_wide = [&]() {
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-            if (tw < 0 && on(t) && is_wide(t)) {
-                tw = t;
-                wide_load(table_view(a, t), bk.L[t] - 2, max(v.na[t] - 1, 0), lane, wv, we);
-            }
+            for (int t = 0; t < NT; ++t)
+                if (tw < 0 && on(t) && is_wide(t)) {
+                    tw = t;
+                    wide_load(table_view(a, t), bk.L[t] - 2, max(v.na[t] - 1, 0), lane, wv, we);
+                }
+        };
         auto narrow = [&](uint32_t slot, int t) {
             if (covers(slot + 4u * (kIndelRows - 1))) sg_l[t] = staged_verdict(a, slot, t, bk.L[t] - 2, bk.plo[t], bk.phi[t], pos, jo);
             else sg_l[t] = join_one_global(&a, t, max(bk.L[t], bk.plo[t]), bk.phi[t], bk.plo[t], bk.phi[t], pos, key, &jo);
@@ -987,6 +1028,8 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            request_wide();
+            CLK(pc, 9);                                         // (narrow slices staged)
             uint32_t pb = sb_b - 8u;
 #pragma unroll
             for (int t = 0; t < NT; ++t) p[t] = slot[t] - 4u;
@@ -1029,6 +1072,7 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        request_wide();
         if (on(0) && !is_wide(0)) narrow(s0, 0);
         if (bl_on) {
             const uint64_t key_max = ((uint64_t)(uint32_t)c_seg << 32) | (uint32_t)pos_max;
@@ -1057,6 +1101,7 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
             if (t + 1 < NT && !is_wide(t2)) narrow(s1, t2);
         }
         }
+        CLK(pc, 10);                                            // (narrow tables ranked, verdicts)
         // the dense tables: six rows per lane, the whole scratch, one at a time
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -1340,6 +1385,11 @@ static size_t lds5_bytes(const V5Args& v, int n_waves) {
 // a tile hold two contigs (one tile per contig boundary and class) the tile is cut after the first contig's rows - the others
 // wait for the next tile, which starts at the boundary - so that featurize_*_tile only ever sees one contig.  The lanes cut off
 // repeat lane 0's row, like the padding lanes of a list's last tile.  Returns the number of entries the tile consumes.
+__device__ __forceinline__ int wave_max_i32(int x) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x = max(x, __shfl_xor(x, d));
+    return rfl(x);
+}
 __device__ __forceinline__ float rfl_f(float x) { return __int_as_float(rfl(__float_as_int(x))); }
 __device__ __forceinline__ int tile_cut(bool& live, uint32_t& i, SnpCols& k) {
     const int c0 = rfl(k.c);
@@ -1494,7 +1544,7 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
     // it works on the current one.
     const int n_big = v.n_indel_waves, n_small = n_waves - n_big;
     sc.base = L.scratch_b + (uint32_t)(wave < n_small ? wave * v.scratch_bytes : n_small * v.scratch_bytes + (wave - n_small) * v.scratch_indel);
-    // (an indel tile's cost relative to an SNP tile's, in 1/256: V5Args::indel_w - 1 for the scoring pass, ~3 when nothing is walked)
+    // (an indel tile's cost relative to an SNP tile's, in 1/256: V5Args::indel_w - 0.85 for the scoring pass, ~3 when nothing is walked)
     const int64_t wi = nit * v.indel_w, ws = nst * 256;
     int n_iw = nit > 0 ? (int)((n_waves * wi + (ws + wi) - 1) / (ws + wi)) : 0;
     n_iw = n_iw < n_big ? n_iw : n_big;
@@ -1547,6 +1597,7 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
             const int64_t off_n2 = off_n + 64;
             uint32_t id_n2 = ~0u;
             if (more && off_n2 < e1) id_n2 = li[off_n2 + lane];
+            CLK(pc, 11);                                        // (tile bookkeeping: cut, next columns and row indices requested)
             featurize_indel_tile<NTRK, WX>(vt, sc, (uint32_t)(blockIdx.x * 7 + (off >> 6)), 64 - (int)(off & 63), lane, i, live, cols, bk, pre, pc);
             ++n_done;
             if (!more) break;
@@ -1566,9 +1617,10 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
         }
 #ifdef UGVC_PHASE_CLOCK
         if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 133))
-            printf("iclk b%d w%d tiles %d total %llu | load+window %llu hmer+motif %llu joins %llu codes+record %llu (ranks %llu)\n", (int)blockIdx.x, wave, (int)n_done,
-                   (unsigned long long)(pc.last - t_begin), (unsigned long long)pc.acc[0], (unsigned long long)pc.acc[1], (unsigned long long)pc.acc[2],
-                   (unsigned long long)pc.acc[3], (unsigned long long)pc.acc[6]);
+            printf("iclk b%d w%d tiles %d total %llu | bookkeeping %llu load+window %llu hmer %llu motif+gc %llu staging %llu narrow %llu wide %llu ranks %llu record %llu\n",
+                   (int)blockIdx.x, wave, (int)n_done, (unsigned long long)(pc.last - t_begin), (unsigned long long)pc.acc[11], (unsigned long long)pc.acc[0],
+                   (unsigned long long)pc.acc[8], (unsigned long long)pc.acc[1], (unsigned long long)pc.acc[9], (unsigned long long)pc.acc[10],
+                   (unsigned long long)pc.acc[2], (unsigned long long)pc.acc[6], (unsigned long long)pc.acc[3]);
 #endif
         return;
     }
@@ -1576,7 +1628,12 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
     // waves - were measured: no faster, profiles/r04_even_shares_ab.txt; the waves of a SIMD share its issue slots, so a wave
     // that finishes early leaves them to the others: what counts is the workgroup's total work, not the spread of its waves' ends)
     const int64_t q = (nst + n_sw - 1) / n_sw;
-    const int64_t t0 = (int64_t)wave * q, t1 = min(t0 + q, nst);
+    int64_t t0 = (int64_t)wave * q, t1 = min(t0 + q, nst);
+    if (v.snp_cum[16] != 0) {                                   // (profiling: weighted shares)
+        const int64_t tot = v.snp_cum[n_sw];
+        t0 = nst * v.snp_cum[wave] / tot;
+        t1 = nst * v.snp_cum[wave + 1] / tot;
+    }
     if (t0 >= t1) return;
     const uint64_t wclk_first = v.wave_clk ? __builtin_readcyclecounter() : 0;
     // this wave's entries of the workgroup's SNP list; a tile = up to 64 of them from an offset (tile_cut)
@@ -1614,6 +1671,7 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
         const V5Args& vt = *(const V5Args*)vq;
         const FilterArgs& at = vt.f;
         const int64_t off_n = off + tile_cut(live, i, cols);    // (the tile ends where the contig changes)
+        CLK(pc, 12);                                            // (the wait for this tile's columns, requested before the previous walk)
         const bool more = off_n < e1;
         uint32_t id_n = 0, i_n = 0;
         bool live_n = false;
@@ -1659,8 +1717,8 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
                (unsigned long long)(pc.last - t_begin), (unsigned long long)pc.acc[0], (unsigned long long)pc.acc[1], (unsigned long long)pc.acc[2],
                (unsigned long long)pc.acc[3], (unsigned long long)pc.acc[4], (unsigned long long)pc.acc[5]);
     if (lane == 0 && blockIdx.x == 0 && wave == 0)
-        printf("  issue %llu eyt %llu | prologue (fill, class lists) %llu cycles before the first tile\n", (unsigned long long)pc.acc[6],
-               (unsigned long long)pc.acc[7], (unsigned long long)(t_begin - k_begin));
+        printf("  cut %llu issue %llu eyt %llu | prologue (fill, class lists) %llu cycles before the first tile\n", (unsigned long long)pc.acc[12],
+               (unsigned long long)pc.acc[6], (unsigned long long)pc.acc[7], (unsigned long long)(t_begin - k_begin));
 #endif
 }
 

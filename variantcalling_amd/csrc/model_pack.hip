@@ -779,7 +779,21 @@ int v5_fill_args(ugvc_ctx* ctx, V5Args& v, const FilterArgs& a, bool scoring) {
             if ((double)v.na[t] / tiles > 100.0) v.iwide |= 1u << t;
         if (const char* e = getenv("UGVC_IWIDE")) v.iwide = (uint32_t)atoi(e);        // (profiling)
     }
-    v.indel_w = 256;
+    // (an indel tile relative to an SNP tile in the wave-role split: 0.85 since round 4's indel tiles - one memory round trip less
+    // per tile, one atomic instead of four; at 1.0 the workgroups with the most indel tiles went to four indel waves and were the
+    // launch's slowest, profiles/r04_indel_cost_sweep.txt)
+    v.indel_w = 218;
+    if (const char* e = getenv("UGVC_INDEL_COST")) v.indel_w = std::max(1, (int)(atof(e) * 256.0));      // (profiling)
+    for (auto& x : v.snp_cum) x = 0;
+    if (const char* e = getenv("UGVC_SNP_W")) {                           // (profiling) "w0,w1,...": tile weights of the SNP waves
+        int k = 0;
+        for (const char* p = e; *p && k < 16; ++k) {
+            v.snp_cum[k + 1] = (unsigned short)(v.snp_cum[k] + atoi(p));
+            while (*p && *p != ',') ++p;
+            if (*p == ',') ++p;
+        }
+        for (; k < 16; ++k) v.snp_cum[k + 1] = v.snp_cum[k];
+    }
     v.n_indel_waves = 0;
     v.n_waves = v5_fused_waves(v);
     if (v.n_waves == 0) return fail("internal: the SNP forest does not fit the fused kernel's LDS");

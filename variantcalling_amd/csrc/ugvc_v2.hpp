@@ -130,6 +130,7 @@ struct V5Args {
     int n_indel_waves;                   // waves of a fused workgroup that work on indel tiles
     int indel_w;                         // cost of an indel tile relative to an SNP tile, in 1/256 (the wave role split follows it)
     unsigned long long* wave_clk;        // profiling (UGVC_WAVE_CLK): per workgroup and wave {kernel entry, first tile, end, tiles | indel tiles << 32} in s_memtime ticks, or null
+    unsigned short snp_cum[17];          // profiling (UGVC_SNP_W): cumulative tile weights of the SNP waves, or all zero (equal consecutive shares)
     int forest_lds_tail;                 // forest5_kernel: byte offset of its shard-offset / total words in the dynamic LDS
 };
 
