@@ -802,9 +802,14 @@ __device__ __forceinline__ IndelCols load_indel_cols(const FilterArgs& a, uint32
     return k;
 }
 
-template <int NTRK, bool WX>
+// `touch_next`: the caller's loads for the NEXT tile (columns, row indices - requested at the top of this tile) are named in an empty
+// asm just before this tile's last stores.  The loop copies them into its registers at its latch, behind those stores and behind
+// the slice loads requested after this function: the wait-count pass cannot order them across the loop's branches, waits for
+// EVERYTHING there, and the slice loads' whole round trip was exposed at the end of every tile (round 4; ~4 k of a tile's 38 k
+// cycles).  Waited for here, they have been in flight for a whole tile and nothing younger is.
+template <int NTRK, bool WX, class TouchNext>
 __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scratch& sc, uint32_t rshard, int split, int lane, uint32_t i, bool live,
-                                                     const IndelCols& k, Brk<1 + NTRK>& bk, IndelPre<1 + NTRK>& pre, PhaseClk& pc) {
+                                                     const IndelCols& k, Brk<1 + NTRK>& bk, IndelPre<1 + NTRK>& pre, PhaseClk& pc, TouchNext touch_next) {
     constexpr int NT = 1 + NTRK;
     const FilterArgs& a = v.f;
     const uint8_t* __restrict__ apool = a.alleles;
@@ -1136,6 +1141,7 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
         x[16] = jo.close_run ? 1.f : 0.f;
 #pragma unroll
         for (int t = 0; t < UGVC_MAX_TRACKS; ++t) x[UGVC_N_BASE_FEATURES + t] = (jo.trk >> t) & 1u ? 1.f : 0.f;
+        touch_next();
         if constexpr (((UGVC_N_BASE_FEATURES + NTRK) & 3) == 0) store_feature_rows_tile<UGVC_N_BASE_FEATURES + NTRK>(a, sc.base, lane, i, live, x, group);
         else store_feature_row(a, i, live, x, group);
         return;
@@ -1173,9 +1179,12 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
     r[10] = ((jo.trk >> 3) & 1u ? 2u : 1u) | (((jo.trk >> 4) & 1u ? 2u : 1u) << 16);
     r[11] = i;
     const unsigned b1 = __shfl(got, 1), b2 = __shfl(got, 2), b3 = __shfl(got, 3), b4 = __shfl(got, 4);
+    touch_next();
     if (mine) {
         const unsigned slot0 = group == 1 ? (hi_blk ? b3 : b1) : (hi_blk ? b4 : b2);
-        uint4* dst = v.rec5[group] + ((size_t)shard * v.shard_cap5 + slot0 + grank) * 3;
+        // (a select between the two pointers: `v.rec5[group]` with the lane's group is a VECTOR load from the launch arguments and a wait)
+        uint4* const rec_g = group == 1 ? v.rec5[1] : v.rec5[2];
+        uint4* dst = rec_g + ((size_t)shard * v.shard_cap5 + slot0 + grank) * 3;
         dst[0] = make_uint4(r[0], r[1], r[2], r[3]);
         dst[1] = make_uint4(r[4], r[5], r[6], r[7]);
         dst[2] = make_uint4(r[8], r[9], r[10], r[11]);
@@ -1598,7 +1607,11 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
             uint32_t id_n2 = ~0u;
             if (more && off_n2 < e1) id_n2 = li[off_n2 + lane];
             CLK(pc, 11);                                        // (tile bookkeeping: cut, next columns and row indices requested)
-            featurize_indel_tile<NTRK, WX>(vt, sc, (uint32_t)(blockIdx.x * 7 + (off >> 6)), 64 - (int)(off & 63), lane, i, live, cols, bk, pre, pc);
+            auto touch_next = [&]() {
+                asm volatile("" ::"v"(cols_n.c), "v"(cols_n.pos), "v"(cols_n.rl), "v"(cols_n.al), "v"(cols_n.ro), "v"(cols_n.ao), "v"(cols_n.qual),
+                             "v"(cols_n.sor), "v"(cols_n.dp), "v"(cols_n.adr), "v"(cols_n.ada), "v"(cols_n.gq), "v"(id_n2));
+            };
+            featurize_indel_tile<NTRK, WX>(vt, sc, (uint32_t)(blockIdx.x * 7 + (off >> 6)), 64 - (int)(off & 63), lane, i, live, cols, bk, pre, pc, touch_next);
             ++n_done;
             if (!more) break;
             if (joins_on && bk.c >= 0) issue_indel_slices<NTRK>(vt, bk, lane, pre);
