@@ -1375,6 +1375,8 @@ __device__ __forceinline__ Lds5 lds5_fill(unsigned char* smem, const V5Args& v, 
     return L;
 }
 
+// (a workgroup may hold all 160 KiB of a CU's LDS; 158 until round 4, whose boundary words - kGtabBytes - needed 256 bytes more)
+constexpr int kLds5Limit = 159 * 1024;
 static size_t lds5_bytes(const V5Args& v, int n_waves) {
     const PackedGroupView& pg = v.pg[0];
     const bool with_forest = pg.ok != 0;
@@ -1474,6 +1476,18 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
         }
     };
     load_classes(w0, rl, al);                                    // (requested BEFORE the LDS fill: their round trip runs under it)
+    // ---- a contig boundary inside the workgroup's rows (round 4).  The tile loops cut a tile where the contig changes
+    // (tile_cut); with tiles laid on a 64-entry grid from the head of the list that costs the wave that holds the boundary one
+    // EXTRA tile - a third of a wave's work in a shard-sized launch, whose slowest workgroups were exactly those.  So the grid
+    // restarts at the boundary: entries before the first row of the second contig are tiled from the list's head, the others
+    // from that row's place in the list; the one extra tile of the workgroup falls on its last wave, which has room.  The row is
+    // found here by the whole workgroup: one probe per thread under the fill, one more round after the first barrier.  (Further
+    // boundaries in the same workgroup - small contigs - are left to tile_cut.)
+    const int rows_here = (int)(r1 - r0);
+    const int probe_step = (int)(((unsigned)rows_here + blockDim.x - 1u) / blockDim.x);
+    const int64_t probe_row = r0 + (int64_t)tid * probe_step;
+    const uint32_t c_first = a.contig[r0], c_last = a.contig[r1 - 1];
+    const uint32_t c_probe = a.contig[min(probe_row, r1 - 1)];
     const Lds5 L = lds5_fill(smem, v, has0, tid, blockDim.x, !WX);
     unsigned cs = 0, ci = 0;
     {
@@ -1500,8 +1514,25 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
     // (no static __shared__ in this kernel: the dynamic LDS then starts at address 0, the forest's p1 table with it, and the
     // walk's final read needs no base added to its payload - ugvc_walk.hpp: walk6; the per-wave counts live behind gtab)
     unsigned (*wcnt)[kK2Threads / 64] = reinterpret_cast<unsigned (*)[kK2Threads / 64]>(smem + (L.gtab_b - lds_addr(smem)) + 128);
+    unsigned (*bnd)[kK2Threads / 64] = reinterpret_cast<unsigned (*)[kK2Threads / 64]>(smem + (L.gtab_b - lds_addr(smem)) + 256);   // [3][16]
+    const bool has_b = rfl((int)c_first) != rfl((int)c_last) && probe_step <= 64 && m <= 2048;   // (m: the classes of a wave's rows are kept for 32 groups)
+    if (has_b) {
+        const unsigned long long fl = __ballot(probe_row >= r1 || c_probe != c_first);
+        if (lane == 0) bnd[0][wave] = fl ? (unsigned)(wave * 64 + __builtin_ctzll(fl)) : ~0u;
+    }
     if (lane == 0) { wcnt[0][wave] = cs; wcnt[1][wave] = ci; }
     __syncthreads();
+    // the first row of the second contig: the probe found it to one stride; one more load per lane closes it
+    int64_t b_row = r1;
+    uint32_t c_fine = 0;
+    if (has_b) {
+        unsigned F = ~0u;
+        for (int w = 0; w < n_waves; ++w) F = min(F, bnd[0][w]);
+        F = (unsigned)rfl((int)F);                                // (>= 1: thread 0 probes row r0 itself)
+        const int64_t lo_row = r0 + (int64_t)(F - 1u) * probe_step + 1;
+        c_fine = a.contig[min(lo_row + lane, r1 - 1)];           // (consumed after the list pass: in flight under it)
+        b_row = lo_row;                                          // (+ the first lane whose contig differs: below)
+    }
     unsigned ps = 0, pi = 0, ns_l = 0, ni_l = 0;
     for (int w = 0; w < n_waves; ++w) {
         const unsigned x = wcnt[0][w], y = wcnt[1][w];
@@ -1540,13 +1571,41 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
             li[ni_l + lane] = ~0u;
         }
     }
+    if (has_b) {
+        // this wave's substitutions / indels in rows before the boundary, from the kept class bits (the fine probe's round trip
+        // ran under the list pass)
+        const unsigned long long fl = __ballot(c_fine != c_first);    // (set at some lane < probe_step: the stride's last row differs)
+        b_row += fl ? (int64_t)__builtin_ctzll(fl) : 0;
+        unsigned sb_w = 0, ib_w = 0;
+        int gi = 0;
+        for (int64_t g = w0; g < w1 && g < b_row; g += 64, ++gi) {
+            const uint32_t two = (cls[gi >> 4] >> (2 * (gi & 15))) & 3u;
+            const int64_t nb = b_row - g;                        // rows of this group before the boundary (> 0)
+            const unsigned long long mb = nb >= 64 ? ~0ull : (1ull << nb) - 1ull;
+            sb_w += (unsigned)__popcll(__ballot((two & 1u) != 0) & mb);
+            ib_w += (unsigned)__popcll(__ballot((two & 2u) != 0) & mb);
+        }
+        if (lane == 0) { bnd[1][wave] = sb_w; bnd[2][wave] = ib_w; }
+    }
     __threadfence_block();
     __syncthreads();
+    // places of the boundary in the two lists (entries before it), or the list's length without one
+    unsigned b_s = ns_l, b_i = ni_l;
+    if (has_b) {
+        b_s = b_i = 0;
+        for (int w = 0; w < n_waves; ++w) { b_s += bnd[1][w]; b_i += bnd[2][w]; }
+        b_s = (unsigned)rfl((int)b_s);                           // (read from LDS: uniform, but in vector registers until named so)
+        b_i = (unsigned)rfl((int)b_i);
+    }
     Scratch sc;
     sc.eyt_b = L.eyt_b; sc.thr_b = L.thr_b; sc.gcr_b = L.gcr_b; sc.css_b = L.css_b; sc.gtab_b = L.gtab_b;
     const int hslot = ((lane & 31) << 1) | (lane >> 5);
-    const int64_t nst = (ns_l + 63) >> 6;
-    const int64_t nit = (a.ablate & 262144) ? 0 : (ni_l + 63) >> 6;
+    // tile T of a list: entries from 64 T before the boundary's tiles, from b + 64 (T - Tb) behind them
+    // (32-bit: a workgroup's lists hold fewer than 2^31 entries)
+    const int tb_s = (int)((b_s + 63u) >> 6), tb_i = (int)((b_i + 63u) >> 6);
+    const int nst = tb_s + (int)((ns_l - b_s + 63u) >> 6);
+    const int nit = (a.ablate & 262144) ? 0 : tb_i + (int)((ni_l - b_i + 63u) >> 6);
+    auto tile_off = [](int T, int tb, unsigned b) { return T < tb ? 64 * T : (int)b + 64 * (T - tb); };
     // Wave roles.  The LDS layout gives the last `n_indel_waves` waves the larger (window-row) scratch; how many of
     // them actually work on indel tiles follows the class mix of the workgroup's rows (an SNV-only callset has none:
     // every wave runs the SNP pipeline).  A wave fetches its next tile's row indices, columns and table slices while
@@ -1554,7 +1613,7 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
     const int n_big = v.n_indel_waves, n_small = n_waves - n_big;
     sc.base = L.scratch_b + (uint32_t)(wave < n_small ? wave * v.scratch_bytes : n_small * v.scratch_bytes + (wave - n_small) * v.scratch_indel);
     // (an indel tile's cost relative to an SNP tile's, in 1/256: V5Args::indel_w - 0.85 for the scoring pass, ~3 when nothing is walked)
-    const int64_t wi = nit * v.indel_w, ws = nst * 256;
+    const int64_t wi = (int64_t)nit * v.indel_w, ws = (int64_t)nst * 256;
     int n_iw = nit > 0 ? (int)((n_waves * wi + (ws + wi) - 1) / (ws + wi)) : 0;
     n_iw = n_iw < n_big ? n_iw : n_big;
     if (nst == 0) n_iw = n_big;
@@ -1562,8 +1621,8 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
     const uint32_t planes_lane_b = sc.base + 2u * (uint32_t)hslot;
     const bool joins_on = !(a.ablate & 524288);
     if (wave >= n_sw) {
-        const int64_t q = (nit + n_iw - 1) / n_iw;
-        const int64_t t0 = (int64_t)(wave - n_sw) * q, t1 = min(t0 + q, nit);
+        const int q = (nit + n_iw - 1) / n_iw;
+        const int t0 = (wave - n_sw) * q, t1 = min(t0 + q, nit);
         if (t0 >= t1) return;
         const uint64_t wclk_first = v.wave_clk ? __builtin_readcyclecounter() : 0;
         PhaseClk pc{};
@@ -1575,8 +1634,8 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
         bk.c = -1;
         IndelPre<NT> pre{};
         // this wave's entries of the workgroup's indel list; a tile = up to 64 of them from an offset (tile_cut)
-        const int64_t e0 = t0 * 64, e1 = min(t1 * 64, (int64_t)ni_l);
-        auto ids_at = [&](int64_t off, uint32_t& i, bool& live) {
+        const int e0 = rfl(tile_off(t0, tb_i, b_i)), e1 = rfl(min(tile_off(t1, tb_i, b_i), (int)ni_l));
+        auto ids_at = [&](int off, uint32_t& i, bool& live) {
             const uint32_t id = li[off + lane];                // (the list is padded by 64 entries: off < e1 <= ni_l)
             live = id != ~0u && off + lane < e1;
             const uint32_t id0 = (uint32_t)rfl((int)id);       // (outside the select: a ternary would read the first PADDING lane)
@@ -1584,7 +1643,7 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
         };
         uint32_t i, i_n = 0;
         bool live, live_n = false;
-        int64_t off = e0;
+        int off = e0;
         ids_at(off, i, live);
         IndelCols cols = load_indel_cols(a, i);
         if (off + 64 < e1) ids_at(off + 64, i_n, live_n);
@@ -1595,7 +1654,7 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
             asm volatile("" : "+s"(vq));
             const V5Args& vt = *(const V5Args*)vq;
             const int take = tile_cut(live, i, cols);
-            const int64_t off_n = off + take;
+            const int off_n = off + take;
             if (take != 64 && off_n < e1) ids_at(off_n, i_n, live_n);   // (the ids fetched ahead were those of off + 64)
             const bool more = off_n < e1;
             // two tiles ahead: row indices; one tile ahead: columns (both in flight during this tile)
@@ -1603,7 +1662,7 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
             bool live_n2 = false;
             IndelCols cols_n = cols;
             if (more) cols_n = load_indel_cols(vt.f, i_n);
-            const int64_t off_n2 = off_n + 64;
+            const int off_n2 = off_n + 64;
             uint32_t id_n2 = ~0u;
             if (more && off_n2 < e1) id_n2 = li[off_n2 + lane];
             CLK(pc, 11);                                        // (tile bookkeeping: cut, next columns and row indices requested)
@@ -1640,18 +1699,18 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
     // (equal shares, the last wave takes what is left.  Shares that differ by at most one tile - the larger ones to the oldest
     // waves - were measured: no faster, profiles/r04_even_shares_ab.txt; the waves of a SIMD share its issue slots, so a wave
     // that finishes early leaves them to the others: what counts is the workgroup's total work, not the spread of its waves' ends)
-    const int64_t q = (nst + n_sw - 1) / n_sw;
-    int64_t t0 = (int64_t)wave * q, t1 = min(t0 + q, nst);
+    const int q = (nst + n_sw - 1) / n_sw;
+    int t0 = wave * q, t1 = min(t0 + q, nst);
     if (v.snp_cum[16] != 0) {                                   // (profiling: weighted shares)
-        const int64_t tot = v.snp_cum[n_sw];
-        t0 = nst * v.snp_cum[wave] / tot;
-        t1 = nst * v.snp_cum[wave + 1] / tot;
+        const int tot = v.snp_cum[n_sw];
+        t0 = (int)((int64_t)nst * v.snp_cum[wave] / tot);
+        t1 = (int)((int64_t)nst * v.snp_cum[wave + 1] / tot);
     }
     if (t0 >= t1) return;
     const uint64_t wclk_first = v.wave_clk ? __builtin_readcyclecounter() : 0;
     // this wave's entries of the workgroup's SNP list; a tile = up to 64 of them from an offset (tile_cut)
-    const int64_t e0 = t0 * 64, e1 = min(t1 * 64, (int64_t)ns_l);
-    auto ids_at = [&](int64_t off, uint32_t& i, bool& live) {
+    const int e0 = rfl(tile_off(t0, tb_s, b_s)), e1 = rfl(min(tile_off(t1, tb_s, b_s), (int)ns_l));
+    auto ids_at = [&](int off, uint32_t& i, bool& live) {
         const uint32_t id = ls[off + lane];                    // (the list is padded by 64 entries: off < e1 <= ns_l)
         live = id != ~0u && off + lane < e1;
         const uint32_t id0 = (uint32_t)rfl((int)id);
@@ -1659,7 +1718,7 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
     };
     uint32_t i;
     bool live;
-    int64_t off = e0;
+    int off = e0;
     ids_at(off, i, live);
     SnpCols cols = load_snp_cols(a, i);
     Brk<NT> bk{};
@@ -1683,7 +1742,7 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
         asm volatile("" : "+s"(vq));
         const V5Args& vt = *(const V5Args*)vq;
         const FilterArgs& at = vt.f;
-        const int64_t off_n = off + tile_cut(live, i, cols);    // (the tile ends where the contig changes)
+        const int off_n = off + tile_cut(live, i, cols);    // (the tile ends where the contig changes)
         CLK(pc, 12);                                            // (the wait for this tile's columns, requested before the previous walk)
         const bool more = off_n < e1;
         uint32_t id_n = 0, i_n = 0;
@@ -1877,7 +1936,7 @@ static size_t k5_forest_lds(const PackedGroupView& pg, int n_waves) {
 // LDS budget of the fused kernel for this configuration: 16, 12 or 8 waves of scratch beside the SNP forest
 int v5_fused_waves(const V5Args& v) {
     for (int w : {16, 12, 8}) {
-        if (lds5_bytes(v, w) <= 158 * 1024) return w;
+        if (lds5_bytes(v, w) <= kLds5Limit) return w;
     }
     return 0;
 }
@@ -1915,7 +1974,7 @@ int launch_feature_matrix_v5(ugvc_ctx* ctx, const FilterArgs& a) {
     static bool attr_set[64] = {};
     if (!attr_set[ctx->device & 63]) {
         for (int t = 0; t <= UGVC_MAX_TRACKS; ++t)
-            UGVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused5_wx_for(t)), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+            UGVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused5_wx_for(t)), hipFuncAttributeMaxDynamicSharedMemorySize, kLds5Limit));
         attr_set[ctx->device & 63] = true;
     }
     for (int g = 0; g < UGVC_N_GROUPS; ++g) v.pg[g].ok = 0;      // (nothing is ranked or walked: the LDS holds scratch only)
@@ -1928,7 +1987,7 @@ int launch_feature_matrix_v5(ugvc_ctx* ctx, const FilterArgs& a) {
     v.scratch_bytes = std::max(v.scratch_bytes, rows_lds);
     v.scratch_indel = std::max(v.scratch_indel, rows_lds);
     if (const char* e = getenv("UGVC_FM_INDEL_W")) v.indel_w = std::max(1, (int)(atof(e) * 256.0));      // (profiling)
-    if (lds5_bytes(v, v.n_waves) > 158 * 1024) return fail("internal: feature-matrix scratch does not fit LDS");
+    if (lds5_bytes(v, v.n_waves) > (size_t)kLds5Limit) return fail("internal: feature-matrix scratch does not fit LDS");
     const unsigned n_wg = (unsigned)((a.n + v.rows_wg - 1) / v.rows_wg);
     hipLaunchKernelGGL(fused5_wx_for(a.n_tracks), dim3(n_wg), dim3(v.n_waves * 64), lds5_bytes(v, v.n_waves), ctx->stream, v);
     UGVC_HIP(hipGetLastError());
@@ -1943,7 +2002,7 @@ int launch_filter_v5(ugvc_ctx* ctx, const FilterArgs& a) {
     if (!attr_set[ctx->device & 63]) {
         for (K5 f : {fused5_for(0), fused5_for(1), fused5_for(2), fused5_for(3), fused5_for(4), fused5_for(5), fused5_for(3, true), (K5)forest5_kernel,
                      (K5)fused5_kernel<3, 16>})
-            UGVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+            UGVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, kLds5Limit));
         attr_set[ctx->device & 63] = true;
     }
     // UGVC_DEBUG_SYNC=1: name every launch on stderr and wait for it (a GPU memory fault aborts the process; the
