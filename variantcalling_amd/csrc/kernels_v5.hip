@@ -154,6 +154,48 @@ __device__ __forceinline__ void brk_refresh(const FilterArgs& a, Brk<NT>& bk, in
     coop_search<NT>(a, bk, pos0, ((uint64_t)(uint32_t)c0 << 32) | (uint32_t)pos0, lane);
 }
 
+// ---- the state for the SECOND contig of a workgroup, searched once and left in LDS (round 4) ----------------------
+// A workgroup whose rows cross a contig boundary holds two waves (one per class) that have to search afresh in the middle of
+// their work - four dependent round trips, ~19 k ticks: those workgroups were the last of every launch.  The workgroup's last
+// SNP wave (the short share: it has room, or no tiles at all in a shard-sized launch) searches for the first row of the second
+// contig before its own tiles and publishes the state at `rec_b` (gtab + 512: 24 dwords); a wave that meets that contig adopts
+// it if it is there by then, and searches itself if not.  The published ranks belong to the second contig's FIRST row of
+// either class: lower bounds for every later row of it (rows ascend by position: validated at upload).
+constexpr int kBndRecDw = 6 + 3 * kJoin5;                       // ready | Lb | clo | chi | plo[] | phi[] | L[]
+template <int NT>
+__device__ __forceinline__ void brk_publish(uint32_t rec_b, const Brk<NT>& bk, int lane) {
+    if (lane == 0) {
+        lds_st32(rec_b + 4u, bk.Lb);
+        lds_st64(rec_b + 8u, (uint64_t)bk.clo);
+        lds_st64(rec_b + 16u, (uint64_t)bk.chi);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            lds_st32(rec_b + 24u + 4u * t, bk.plo[t]);
+            lds_st32(rec_b + 24u + 4u * (kJoin5 + t), bk.phi[t]);
+            lds_st32(rec_b + 24u + 4u * (2 * kJoin5 + t), bk.L[t]);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) lds_st32(rec_b, bk.c + 1);
+}
+template <int NT>
+__device__ __forceinline__ bool brk_adopt(uint32_t rec_b, Brk<NT>& bk, int c0) {
+    if (rfl(lds_i32(rec_b)) != c0 + 1) return false;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    bk.c = c0;
+    bk.Lb = rfl(lds_i32(rec_b + 4u));
+    const uint64_t lo = lds_u64(rec_b + 8u), hi = lds_u64(rec_b + 16u);
+    bk.clo = (int64_t)(((uint64_t)(uint32_t)rfl((int)(lo >> 32)) << 32) | (uint32_t)rfl((int)lo));
+    bk.chi = (int64_t)(((uint64_t)(uint32_t)rfl((int)(hi >> 32)) << 32) | (uint32_t)rfl((int)hi));
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        bk.plo[t] = rfl(lds_i32(rec_b + 24u + 4u * t));
+        bk.phi[t] = rfl(lds_i32(rec_b + 24u + 4u * (kJoin5 + t)));
+        bk.L[t] = rfl(lds_i32(rec_b + 24u + 4u * (2 * kJoin5 + t)));
+    }
+    return true;
+}
+
 #ifdef UGVC_PHASE_CLOCK
 struct PhaseClk { uint64_t last; uint64_t acc[16]; };
 #define CLK(pc, k) do { const uint64_t now_ = __builtin_readcyclecounter(); (pc).acc[k] += now_ - (pc).last; (pc).last = now_; } while (0)
@@ -620,7 +662,7 @@ __device__ __forceinline__ void featurize_snp_tile(const V5Args& v, const Scratc
     const int n_live = (int)__popcll(__ballot(live));
     const bool joins_on = !(a.ablate & 524288);
     if (c0 != bk.c) {                                           // the wave's first tile, or a new contig: search afresh
-        brk_refresh<NT>(a, bk, c0, rfl(pos), lane);
+        if (!(bk.c >= 0 && brk_adopt<NT>(sc.gtab_b + 512u, bk, c0))) brk_refresh<NT>(a, bk, c0, rfl(pos), lane);
         if (joins_on) issue_slices<NT>(v, bk, lane, pre);
     }
     const int64_t clo = bk.clo, chi = bk.chi;
@@ -820,7 +862,7 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
     const int dp = k.dp, adr = k.adr, ada = k.ada, gq = k.gq;
     const int c0 = rfl(c);
     if (c0 != bk.c) {                                           // the wave's first tile, or a new contig: search afresh
-        brk_refresh<NT>(a, bk, c0, rfl(pos), lane);
+        if (!(bk.c >= 0 && brk_adopt<NT>(sc.gtab_b + 512u, bk, c0))) brk_refresh<NT>(a, bk, c0, rfl(pos), lane);
         if (joins_on) issue_indel_slices<NTRK>(v, bk, lane, pre);
     }
     const int n_live = (int)__popcll(__ballot(live));
@@ -1521,6 +1563,7 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
         if (lane == 0) bnd[0][wave] = fl ? (unsigned)(wave * 64 + __builtin_ctzll(fl)) : ~0u;
     }
     if (lane == 0) { wcnt[0][wave] = cs; wcnt[1][wave] = ci; }
+    if (tid == 0) lds_st32(L.gtab_b + 512u, 0);                  // (no second-contig state published yet: brk_publish)
     __syncthreads();
     // the first row of the second contig: the probe found it to one stride; one more load per lane closes it
     int64_t b_row = r1;
@@ -1705,6 +1748,11 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
         const int tot = v.snp_cum[n_sw];
         t0 = (int)((int64_t)nst * v.snp_cum[wave] / tot);
         t1 = (int)((int64_t)nst * v.snp_cum[wave + 1] / tot);
+    }
+    if (has_b && wave == n_sw - 1 && b_row < r1) {               // (brk_publish: the second contig's state, once for the workgroup)
+        Brk<NT> b2{};
+        brk_refresh<NT>(a, b2, rfl((int)a.contig[b_row]), rfl(a.pos[b_row]), lane);
+        brk_publish<NT>(L.gtab_b + 512u, b2, lane);
     }
     if (t0 >= t1) return;
     const uint64_t wclk_first = v.wave_clk ? __builtin_readcyclecounter() : 0;

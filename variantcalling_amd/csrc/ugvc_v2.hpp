@@ -93,7 +93,7 @@ constexpr int kRec5Dwords = 12;               // raw record: 20 codes (u16, by f
 constexpr int kTile5 = 64;                    // variants per tile = one wave
 constexpr int kMinRowsWg5 = 1024;             // a workgroup of the fused kernel owns at least this many rows
 constexpr int kJoin5 = UGVC_MAX_TRACKS + 2;   // runs, tracks, blacklist
-constexpr int kGtabBytes = 512;          // clamps | float-slice descriptors | per-wave class counts | contig-boundary words (fused5_kernel)
+constexpr int kGtabBytes = 640;          // clamps | float-slice descriptors | per-wave class counts | contig-boundary words | second-contig state (fused5_kernel)
 constexpr int kBlCap5 = 64;                   // staged blacklist keys per SNP tile
 
 struct V5Args {
