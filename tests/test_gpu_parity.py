@@ -251,6 +251,27 @@ def test_v5_many_small_contigs_and_row_counts(engine, frozen_models):
         assert np.array_equal(got.tree_score, exp.tree_score[5000:5000 + n]), n
 
 
+@pytest.mark.parametrize("n, n_contigs, seed", [(70_000, 2, 5), (150_001, 3, 6), (40_000, 7, 7), (300_000, 2, 8)])
+def test_v5_tile_grid_restarts_at_a_contig_boundary(engine, frozen_models, n, n_contigs, seed):
+    """Round 4: a workgroup whose rows cross a contig boundary finds the second contig's first row in its prologue, restarts
+    the tile grid of both lists there and hands the second contig's table state over in LDS (fused5_kernel: has_b, brk_publish).
+    One boundary per workgroup at most with two or three contigs, several with seven; sub-ranges move the boundary through
+    every alignment of the 64-entry grid and through every wave of the workgroup."""
+    from variantcalling_amd import synth
+    O = _oracle()
+    cs = synth.make_callset(n, genome_len=40_000_000, n_contigs=n_contigs, seed=seed)
+    _configure(engine, cs.ref, cs.runs, cs.tracks, cs.blacklist, frozen_models[RF])
+    exp = O.filter_variants(cs.variants, cs.ref, cs.runs, cs.tracks, cs.blacklist, frozen_models[RF])
+    _assert_same(engine.filter_variants(cs.variants), exp, f"{n_contigs} contigs")
+    first = int(np.flatnonzero(cs.variants.contig != cs.variants.contig[0])[0])      # first row of the second contig
+    for lo, hi in [(first - 1, first + 1), (first - 64, first + 64), (first - 1000, first + 37), (first - 37, first + 3000),
+                   (first, first + 500), (max(first - 20_000, 0), min(first + 20_000, cs.variants.n)), (0, first), (0, first + 1)]:
+        lo, hi = max(lo, 0), min(hi, cs.variants.n)
+        got = engine.filter_variants(cs.variants.slice(lo, hi))
+        assert np.array_equal(got.flags, exp.flags[lo:hi]) and np.array_equal(got.filter, exp.filter[lo:hi]), (lo, hi)
+        assert np.array_equal(got.tree_score, exp.tree_score[lo:hi]), (lo, hi)
+
+
 @pytest.mark.parametrize("n_tracks", [0, 1, 2, 4, 5])
 @PATHS
 def test_track_counts_other_than_three(engine, small_callset, path, n_tracks):

@@ -599,13 +599,25 @@ __device__ __forceinline__ void snp_join_segment(const V5Args& v, const Scratch&
         if (t > 0 || a.has_runs) miss |= lds_i32(A[t] + maskB[t]) < pos_max;
     }
     if (a.n_bl > 0) miss |= lds_u64(Ab + 8u * (kBlCap5 - 1)) < key_max;
+    // (the 64-row step exists only for a table staged with 128 rows - the densest one or two: a wave-uniform branch per table
+    // instead of a step of zero for the others)
 #pragma unroll
-    for (int sb = 256; sb >= 4; sb >>= 1) {
+    for (int t = 0; t < NT; ++t)
+        if (v.jcap[t] > 64) {
+            const uint32_t cand = p[t] + 256u;
+            p[t] = lds_i32(cand) < pos ? cand : p[t];
+        }
+    if (kBlCap5 > 64) {
+        const uint32_t cb = pb + 512u;
+        pb = lds_u64(cb) < key ? cb : pb;
+    }
+#pragma unroll
+    for (int sb = 128; sb >= 4; sb >>= 1) {
         uint32_t cand[NT];
         int x[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            cand[t] = p[t] + ((uint32_t)sb & maskB[t]);
+            cand[t] = p[t] + (uint32_t)sb;
             x[t] = lds_i32(cand[t]);
         }
         const uint32_t cb = pb + (uint32_t)((2 * sb) & (8 * (kBlCap5 - 1)));
@@ -1280,7 +1292,16 @@ __device__ __forceinline__ void walk_forest(const PackedGroupView& pg, uint32_t 
     }
     for (; t < T; ++t) a1 += lds_f64(one_tree(t));
     const double half = 0.5 * (double)T, band = pg.band;
-    score = (float)(a1 / (double)T);
+    // score = (float)(a1 / T), the reference's mean of the trees' class-1 probabilities.  The f64 division is ~20 vector
+    // instructions; a1 * (1 / T) is within two double ulps of the quotient, so the two round to the same float unless the product
+    // sits that close to the midpoint of two floats (bits 28..0 of the double's mantissa around 0x10000000): then - 2^-26 of the
+    // lanes - the whole wave divides.
+    {
+        const double xq = a1 * pg.inv_T;
+        const uint32_t low = (uint32_t)__double2loint(xq) & 0x1FFFFFFFu;
+        const bool near_mid = low - (0x10000000u - 8u) <= 16u;
+        score = __builtin_amdgcn_ballot_w64(near_mid) != 0 ? (float)(a1 / (double)T) : (float)xq;
+    }
     filt = a1 > half ? UGVC_FILTER_PASS : UGVC_FILTER_LOW_SCORE;
     // inside the band around T/2 (rounding of the two class sums, model_pack.hip) the class-0 sum decides as
     // scikit-learn's argmax does: redo the walk with both payload sums, in tree order (exact ties in practice)

@@ -585,6 +585,7 @@ int v2_fill_args(ugvc_ctx* ctx, V2Args& v, int64_t n, int n_tiles) {
         p.leaf_f32 = g.d_leaf_f32.as<float>();
         p.fast4 = g.kind == UGVC_MODEL_RF && g.fast4;
         p.band = g.band4;
+        p.inv_T = g.T > 0 ? 1.0 / (double)g.T : 0.0;
         p.hi4 = g.d_hi4.as<uint32_t>();
         p.last4 = g.d_last4.as<uint2>();
         p.p1 = g.d_p1.as<double>();
@@ -675,6 +676,7 @@ int v5_fill_args(ugvc_ctx* ctx, V5Args& v, const FilterArgs& a, bool scoring) {
         p.pairs = g.d_pairs.as<double2>();
         p.fast4 = 1;
         p.band = g.band4;
+        p.inv_T = g.T > 0 ? 1.0 / (double)g.T : 0.0;
         p.hi4 = g.d_hi5.as<uint32_t>();
         p.last4 = g.d_last5.as<uint2>();
         p.roots = g.d_roots5.as<uint32_t>();

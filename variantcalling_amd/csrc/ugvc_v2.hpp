@@ -53,6 +53,7 @@ struct PackedGroupView {
     // 1e-9 (then pr1 > pr0 is decided by the class-1 sum alone outside a narrow band around T/2).
     int fast4;
     double band;                  // |class-1 sum - T/2| <= band: both sums are recomputed (exact argmax)
+    double inv_T;                 // 1.0 / T (IEEE, from the host): the score's quotient by a multiply (walk_forest)
     const uint32_t* hi4;          // T * 2^(D-1)
     const uint2* last4;           // T * 2^(D-1)
     const double* p1;             // n_pairs
