@@ -420,6 +420,11 @@ int format_f32(float x, char* buf, int cap) {
 
 }  // namespace
 
+// Column vectors are sized once and then written in full by the worker threads: NoInitAlloc (above) leaves their elements
+// uninitialised (a `resize` of twenty 5 M-element columns was a serial zero fill of ~150 MB - and the first touch of every
+// page by ONE thread; now the pages are touched by the threads that fill them).
+template <class T> using Col = std::vector<T, NoInitAlloc<T>>;
+
 struct ugvc_vcf {
     std::string path;
     TextBuf text;
@@ -429,24 +434,24 @@ struct ugvc_vcf {
     int64_t n = 0;
     int64_t n_total = 0, part_lo = 0;        // ugvc_vcf_read_part: records in the file, first record (file order) of this part
     // table order
-    std::vector<uint16_t> contig;
-    std::vector<uint8_t> gq, gt, has_id, alleles, n_alt;
-    std::vector<int32_t> pos, dp, ad_ref, ad_alt, filter_len, rec_len;
-    std::vector<uint16_t> ref_len, alt_len;
-    std::vector<uint32_t> ref_off, alt_off;
-    std::vector<float> qual, sor, tlod;
-    std::vector<int64_t> order, filter_off, rec_off;
+    Col<uint16_t> contig;
+    Col<uint8_t> gq, gt, has_id, alleles, n_alt;
+    Col<int32_t> pos, dp, ad_ref, ad_alt, filter_len, rec_len;
+    Col<uint16_t> ref_len, alt_len;
+    Col<uint32_t> ref_off, alt_off;
+    Col<float> qual, sor, tlod;
+    Col<int64_t> order, filter_off, rec_off;
     std::vector<std::string> contig_names;  // index = contig column (for the tabix index of the output)
 };
 
 namespace {
 
 struct Parsed {                              // file order
-    std::vector<uint16_t> contig;
-    std::vector<uint8_t> gq, gt, has_id, n_alt;
-    std::vector<int32_t> pos, dp, adr, ada;
-    std::vector<float> qual, sor, tlod;
-    std::vector<Span> ref, alt, filt;
+    Col<uint16_t> contig;
+    Col<uint8_t> gq, gt, has_id, n_alt;
+    Col<int32_t> pos, dp, adr, ada;
+    Col<float> qual, sor, tlod;
+    Col<Span> ref, alt, filt;
     void resize(size_t n) {
         contig.resize(n); gq.resize(n); gt.resize(n); has_id.resize(n); n_alt.resize(n);
         pos.resize(n); dp.resize(n); adr.resize(n); ada.resize(n);
@@ -861,13 +866,31 @@ int ugvc_vcf_read_part(const char* path, const char* const* contig_names, int n_
 
     // ---- stable order by (contig, pos)
     h->order.resize((size_t)n);
-    std::iota(h->order.begin(), h->order.end(), (int64_t)0);
-    std::vector<uint64_t> key((size_t)n);
-    for (int64_t k = 0; k < n; ++k)
-        key[(size_t)k] = ((uint64_t)P.contig[(size_t)k] << 32) | (uint32_t)((uint32_t)P.pos[(size_t)k] ^ 0x80000000u);
-    if (!std::is_sorted(key.begin(), key.end()))
-        std::stable_sort(h->order.begin(), h->order.end(), [&](int64_t a, int64_t b) { return key[(size_t)a] < key[(size_t)b]; });
-    std::vector<uint64_t>().swap(key);
+    {
+        auto key_of = [&](int64_t k) {
+            return ((uint64_t)P.contig[(size_t)k] << 32) | (uint32_t)((uint32_t)P.pos[(size_t)k] ^ 0x80000000u);
+        };
+        // (a sorted file - the usual case - is recognised by the parts in parallel, seams included, without a key array)
+        std::vector<char> part_sorted((size_t)pparts, 1);
+        parallel_ranges(n, pparts, [&](int p, int64_t lo, int64_t hi) {
+            uint64_t prev = lo > 0 ? key_of(lo - 1) : 0;
+            bool ok = true;
+            for (int64_t k = lo; k < hi; ++k) {
+                h->order[(size_t)k] = k;
+                const uint64_t x = key_of(k);
+                ok &= x >= prev;
+                prev = x;
+            }
+            part_sorted[(size_t)p] = ok;
+        });
+        bool sorted = true;
+        for (char c : part_sorted) sorted &= c != 0;
+        if (!sorted) {
+            Col<uint64_t> key((size_t)n);
+            parallel_ranges(n, pparts, [&](int, int64_t lo, int64_t hi) { for (int64_t k = lo; k < hi; ++k) key[(size_t)k] = key_of(k); });
+            std::stable_sort(h->order.begin(), h->order.end(), [&](int64_t a, int64_t b) { return key[(size_t)a] < key[(size_t)b]; });
+        }
+    }
     st.lap("order");
 
     // ---- table columns
@@ -877,15 +900,30 @@ int ugvc_vcf_read_part(const char* path, const char* const* contig_names, int n_
     h->ref_len.resize((size_t)n); h->alt_len.resize((size_t)n); h->ref_off.resize((size_t)n); h->alt_off.resize((size_t)n);
     h->qual.resize((size_t)n); h->sor.resize((size_t)n); h->tlod.resize((size_t)n);
     h->filter_off.resize((size_t)n); h->filter_len.resize((size_t)n);
+    // allele-pool offsets in table order: per-part byte counts, a scan over the parts, the offsets of every part in parallel
     uint64_t tot = 0;
-    for (int64_t k = 0; k < n; ++k) {
-        const size_t j = (size_t)h->order[(size_t)k];
-        if (tot + (uint64_t)P.ref[j].len > 0xFFFFFFFFull) return fail(h->path + ": allele pool exceeds 4 GiB");
-        h->ref_off[(size_t)k] = (uint32_t)tot;
-        h->alt_off[(size_t)k] = (uint32_t)(tot + (uint64_t)P.ref[j].len);
-        tot += (uint64_t)P.ref[j].len + (uint64_t)P.alt[j].len;
+    {
+        std::vector<uint64_t> part_bytes((size_t)pparts, 0);
+        parallel_ranges(n, pparts, [&](int p, int64_t lo, int64_t hi) {
+            uint64_t b = 0;
+            for (int64_t k = lo; k < hi; ++k) {
+                const size_t j = (size_t)h->order[(size_t)k];
+                b += (uint64_t)P.ref[j].len + (uint64_t)P.alt[j].len;
+            }
+            part_bytes[(size_t)p] = b;
+        });
+        for (int p = 0; p < pparts; ++p) { const uint64_t b = part_bytes[(size_t)p]; part_bytes[(size_t)p] = tot; tot += b; }
+        if (tot > 0xFFFFFFFFull) return fail(h->path + ": allele pool exceeds 4 GiB");
+        parallel_ranges(n, pparts, [&](int p, int64_t lo, int64_t hi) {
+            uint64_t t = part_bytes[(size_t)p];
+            for (int64_t k = lo; k < hi; ++k) {
+                const size_t j = (size_t)h->order[(size_t)k];
+                h->ref_off[(size_t)k] = (uint32_t)t;
+                h->alt_off[(size_t)k] = (uint32_t)(t + (uint64_t)P.ref[j].len);
+                t += (uint64_t)P.ref[j].len + (uint64_t)P.alt[j].len;
+            }
+        });
     }
-    if (tot > 0xFFFFFFFFull) return fail(h->path + ": allele pool exceeds 4 GiB");
     h->alleles.resize((size_t)tot);
     st.lap("allocate + allele offsets");
     uint8_t code[256];
@@ -983,7 +1021,7 @@ int ugvc_vcf_write_filtered(const ugvc_vcf* h, const char* out_path, const float
     for (int64_t k = 0; k < n; ++k) row_of[(size_t)h->order[(size_t)k]] = k;
     st.lap("header + row map");
 
-    bool io_ok = true;
+    std::atomic<bool> io_ok{true};
     std::vector<uint32_t> blk_clen;                          // compressed size of every data block, file order
     std::vector<uint32_t> out_len((size_t)n);                // bytes of every output record line (with its newline)
     std::vector<int64_t> info_end(gz && write_index ? (size_t)n : 0, -1);   // INFO/END per record, for the index
@@ -992,13 +1030,14 @@ int ugvc_vcf_write_filtered(const ugvc_vcf* h, const char* out_path, const float
                                            0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     constexpr size_t kBlk = 65280;
     // emit every full 65280-byte block of data[0, size) (all of it when final); returns the bytes consumed
-    auto flush_blocks = [&](const char* data, size_t size, bool final) -> size_t {
+    std::vector<std::string> comp;                           // compressed blocks of one flush (kept: their capacity is reused)
+    auto flush_blocks = [&](const char* data, size_t size, bool final, bool timed) -> size_t {
         if (!gz) {
             if (size && fwrite(data, 1, size, fh) != size) io_ok = false;
             return size;
         }
         const size_t nb = final ? (size + kBlk - 1) / kBlk : size / kBlk;
-        std::vector<std::string> comp(nb);
+        if (comp.size() < nb) comp.resize(nb);
         std::atomic<int> bad{0};
         // one deflate state per THREAD, reset from block to block: deflateInit2 allocates ~270 KB - above glibc's mmap
         // threshold, i.e. an mmap + 66 page faults + munmap per 64 KB block, serialised on the process' address-space lock
@@ -1060,26 +1099,39 @@ int ugvc_vcf_write_filtered(const ugvc_vcf* h, const char* out_path, const float
             deflateEnd(&zs);
         });
         if (bad) { io_ok = false; return 0; }
-        st.lap("  deflate");
-        for (auto& o : comp) {
+        if (timed) st.lap("  deflate");
+        for (size_t b = 0; b < nb; ++b) {
+            const std::string& o = comp[b];
             if (fwrite(o.data(), 1, o.size(), fh) != o.size()) io_ok = false;
             blk_clen.push_back((uint32_t)o.size());
         }
-        st.lap("  file write");
+        if (timed) st.lap("  file write");
         return std::min(size, nb * kBlk);
     };
 
     // ---- records, in batches of file-order ranges
-    // (batches of 2 M records, ~360 MB of text: every batch starts its threads twice - 19 batches of 256 k records with 256
-    // threads each were ~10 000 thread starts, a third of the writer's time)
-    int64_t batch = 1 << 21;
+    // (batches of 512 k records, ~90 MB of text: every batch starts its threads twice - 19 batches of 256 k records with 256
+    // threads each were ~10 000 thread starts, a third of the writer's time in round 2; with 64 threads and the compression of
+    // a batch running beside the next batch's formatting, ten batches of a 5 M-record file overlap better than three)
+    int64_t batch = 1 << 19;
     if (const char* e = getenv("UGVC_VCF_WRITE_BATCH")) batch = std::max<int64_t>(1, atoll(e));      // (tests: batch seams on small files)
+    // A batch's blocks are compressed and written by ONE helper thread (with its own worker threads) while the next batch is
+    // formatted: what a batch leaves over for the next one - less than a block - is the tail of its text, known before a byte of
+    // it is compressed.  (Round 4: format + gather were 0.17 s of the 5 M-record write-back's 0.45 s, in front of 0.26 s of deflate.)
+    // (the per-thread text buffers and the two gather buffers live across the batches: fresh ones were ~90 MB of first-touch
+    // page faults per batch, taken under the address-space lock that the compressing threads' allocations want too)
+    std::thread flusher;
+    std::vector<std::string> part;
+    std::unique_ptr<char[]> gbuf[2];
+    size_t gcap[2] = {0, 0};
+    int gsel = 0;
     for (int64_t b0 = 0; b0 < n && io_ok; b0 += batch) {
         const int64_t b1 = std::min(n, b0 + batch);
         const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(threads, (b1 - b0) / 1024));
-        std::vector<std::string> part((size_t)parts);
+        if (part.size() < (size_t)parts) part.resize((size_t)parts);
         parallel_ranges(b1 - b0, parts, [&](int p, int64_t lo, int64_t hi) {
             std::string& o = part[(size_t)p];
+            o.clear();
             o.reserve((size_t)(hi - lo) * 160);
             char num[64];
             for (int64_t j = b0 + lo; j < b0 + hi; ++j) {
@@ -1145,18 +1197,24 @@ int ugvc_vcf_write_filtered(const ugvc_vcf* h, const char* out_path, const float
         std::vector<size_t> at((size_t)parts + 1, stream.size());
         for (int p = 0; p < parts; ++p) at[(size_t)p + 1] = at[(size_t)p] + part[(size_t)p].size();
         const size_t total = at[(size_t)parts];
-        std::unique_ptr<char[]> buf(new char[total ? total : 1]);
-        memcpy(buf.get(), stream.data(), stream.size());
-        char* dst = buf.get();
+        // (the buffer of the batch before the previous one: its flush was joined before the previous batch's was started)
+        if (gcap[gsel] < total) { gbuf[gsel].reset(new char[total + total / 8 + 1]); gcap[gsel] = total + total / 8 + 1; }
+        char* dst = gbuf[gsel].get();
+        memcpy(dst, stream.data(), stream.size());
         parallel_ranges(parts, std::min(parts, threads), [&](int, int64_t lo, int64_t hi) {
             for (int64_t p = lo; p < hi; ++p) memcpy(dst + at[(size_t)p], part[(size_t)p].data(), part[(size_t)p].size());
         });
         st.lap("gather parts");
-        const size_t used = flush_blocks(buf.get(), total, false);
-        stream.assign(buf.get() + used, total - used);
-        st.lap("deflate + write");
+        if (flusher.joinable()) flusher.join();                 // (blocks reach the file in order: one flush at a time)
+        st.lap("wait for the previous batch's deflate + write");
+        const size_t used = gz ? total / kBlk * kBlk : total;
+        stream.assign(dst + used, total - used);
+        flusher = std::thread([&flush_blocks, dst, total] { (void)flush_blocks(dst, total, false, false); });
+        gsel ^= 1;
     }
-    if (io_ok) (void)flush_blocks(stream.data(), stream.size(), true);
+    if (flusher.joinable()) flusher.join();
+    st.lap("last batch's deflate + write");
+    if (io_ok) (void)flush_blocks(stream.data(), stream.size(), true, true);
     if (io_ok && gz && fwrite(kEof, 1, 28, fh) != 28) io_ok = false;
     if (fclose(fh) != 0) io_ok = false;
     if (!io_ok) return fail(std::string(out_path) + ": write failed");
