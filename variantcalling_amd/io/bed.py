@@ -23,10 +23,19 @@ def _open_text(path: str):
 
 def track_from_arrays(contig: np.ndarray, starts: np.ndarray, ends: np.ndarray, n_contigs: int,
                       name: str = "", merge: bool = True) -> IntervalTrack:
-    order = np.lexsort((ends, starts, contig))
-    contig, starts, ends = contig[order], starts[order].astype(np.int64), ends[order].astype(np.int64)
+    contig, starts, ends = np.asarray(contig), np.asarray(starts, dtype=np.int64), np.asarray(ends, dtype=np.int64)
+    # (a BED file is sorted as a rule: one vectorised check instead of a three-key sort of 3 M rows - 0.25 s of the tool's first stage)
+    if contig.size > 1:
+        dc, ds = contig[1:] - contig[:-1], starts[1:] - starts[:-1]
+        in_order = bool(np.all((dc > 0) | ((dc == 0) & ((ds > 0) | ((ds == 0) & (ends[1:] >= ends[:-1]))))))
+    else:
+        in_order = True
+    if not in_order:
+        order = np.lexsort((ends, starts, contig))
+        contig, starts, ends = contig[order], starts[order], ends[order]
     keep = ends > starts
-    contig, starts, ends = contig[keep], starts[keep], ends[keep]
+    if not keep.all():
+        contig, starts, ends = contig[keep], starts[keep], ends[keep]
     if merge and starts.size:
         # running maximum of the ends inside each contig; a new merged interval opens where a start
         # lies beyond everything seen so far (bedtools-merge semantics, book-ended intervals stay apart)
@@ -34,11 +43,8 @@ def track_from_arrays(contig: np.ndarray, starts: np.ndarray, ends: np.ndarray, 
         cm = np.maximum.accumulate(ends + contig.astype(np.int64) * big) - contig.astype(np.int64) * big
         new = np.ones(starts.size, dtype=bool)
         new[1:] = (contig[1:] != contig[:-1]) | (starts[1:] > cm[:-1])
-        grp = np.cumsum(new) - 1
-        m_start = starts[new]
-        m_end = np.zeros(m_start.size, dtype=np.int64)
-        np.maximum.at(m_end, grp, ends)
-        contig, starts, ends = contig[new], m_start, m_end
+        first = np.flatnonzero(new)                              # (the groups are runs of rows: a segmented maximum)
+        contig, starts, ends = contig[new], starts[new], np.maximum.reduceat(ends, first)
     ptr = np.searchsorted(contig, np.arange(n_contigs + 1)).astype(np.int32)
     return IntervalTrack(starts.astype(np.int32), ends.astype(np.int32), ptr, name)
 
