@@ -146,6 +146,12 @@ int ugvc_model_clear(ugvc_ctx* ctx, int group);
  * ugvc_feature_matrix: the N x F float32 feature matrix (row-major) train_models_pipeline
  *   fits on (docs/train_models_pipeline.md:5-10); group[i] in {0,1,2} optional (may be NULL). */
 int ugvc_filter_variants(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_results* out);
+/* ugvc_reserve: everything ugvc_filter_variants allocates once per callset size (resident columns, pinned staging, streams,
+ *   events, the worker pool) and the first use of the kernels' code object, without touching a row.  Optional: a tool that
+ *   knows its callset's size early calls it from a helper thread beside its other set-up (reference / table / model uploads
+ *   on another thread are fine; a pass is not) - the first ugvc_filter_variants over 5 M rows spends 44 of its 49 ms there.
+ *   Replaces nothing in the reference (its loops allocate as they go: ugvc/pipelines/vcfbed/calibrate_bridging_snvs.py:101-130). */
+int ugvc_reserve(ugvc_ctx* ctx, int64_t n_variants, int64_t alleles_len);
 int ugvc_variants_upload(ugvc_ctx* ctx, const ugvc_variants* v);
 int ugvc_filter_resident(ugvc_ctx* ctx);
 int ugvc_results_download(ugvc_ctx* ctx, const ugvc_results* out);

@@ -78,6 +78,11 @@ int ugvc_vcf_read(const char* path, const char* const* contig_names, int n_conti
 int ugvc_vcf_read_part(const char* path, const char* const* contig_names, int n_contigs, int is_mutect, int sample,
                        int n_threads, int part, int n_parts, ugvc_vcf** out);
 int ugvc_vcf_part_info(const ugvc_vcf* h, int64_t* n_total, int64_t* part_lo);
+/* A function left here is called ONCE - on the calling thread, by the next ugvc_vcf_read / ugvc_vcf_read_part of THIS thread, as
+ * soon as the record lines are counted (a third of the way through the read) - and forgotten: a tool prepares what depends on
+ * the callset's size meanwhile (filter_variants_pipeline: ugvc_reserve of the GPU engine).  NULL clears it.  (The reference's
+ * reader has no such point: it yields records one by one, report_wo_gt.ipynb:1207-1210.) */
+void ugvc_vcf_set_count_hook(void (*fn)(int64_t n_records, int64_t text_bytes, void* user), void* user);
 int ugvc_vcf_get_view(const ugvc_vcf* h, ugvc_vcf_view* view);
 
 /* Write the input records in their original order with FILTER := PASS | [HPOL_RUN;][COHORT_FP;][LOW_SCORE],

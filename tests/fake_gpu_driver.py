@@ -31,6 +31,9 @@ class FakeEngine:
     def __exit__(self, *exc):
         return False
 
+    def reserve(self, n_variants, alleles_len):               # (Engine.reserve: allocations only)
+        assert n_variants >= 0 and alleles_len >= 0
+
     def filter_variants(self, vt):
         ref, runs, tracks, bl, forests, flow, hp_len, hp_dist, mark = self.cfg
         return O.filter_variants(vt, ref, runs, tracks, bl, forests, flow, hp_len, hp_dist, mark)

@@ -347,6 +347,41 @@ def test_error_paths(engine, small_callset, frozen_models):
         engine.set_flow_order("AAGT")
 
 
+def test_reserve_changes_nothing_but_the_first_calls_allocations(frozen_models):
+    """ugvc_reserve (round 4): the boundary call's one-time allocations from a helper thread, beside the uploads of the
+    reference / tables / model on the calling thread (how filter_variants_pipeline uses it) - smaller, exact and larger sizes
+    than the callset that follows; small callsets (plain upload path) and a second reserve are no-ops; bad sizes are errors."""
+    import threading
+    from variantcalling_amd import synth
+    from variantcalling_amd.engine import Engine
+    O = _oracle()
+    cs = synth.make_callset(300_011, genome_len=150_000_000, n_contigs=5, seed=99)
+    forests = frozen_models[RF]
+    exp = O.filter_variants(cs.variants, cs.ref, cs.runs, cs.tracks, cs.blacklist, forests)
+    for n_res in (270_000, cs.variants.n, 700_000, 1_000):
+        with Engine(0) as eng:
+            box = {}
+
+            def work():
+                try:
+                    eng.reserve(n_res, int(cs.variants.alleles.size))
+                    box["ok"] = True
+                except Exception as e:                       # noqa: BLE001 - reported by the assert below
+                    box["err"] = e
+
+            t = threading.Thread(target=work)
+            t.start()
+            _configure(eng, cs.ref, cs.runs, cs.tracks, cs.blacklist, forests)
+            t.join()
+            assert box == {"ok": True}, box
+            eng.reserve(n_res, int(cs.variants.alleles.size))          # (again: nothing left to do)
+            _assert_same(eng.filter_variants(cs.variants), exp, f"after reserve({n_res})")
+            _assert_same(eng.filter_variants(cs.variants.slice(0, 5000)), O.filter_variants(
+                cs.variants.slice(0, 5000), cs.ref, cs.runs, cs.tracks, cs.blacklist, forests), "small callset after reserve")
+            with pytest.raises(RuntimeError, match="reserve"):
+                eng.reserve(-1, 0)
+
+
 def test_chunk_pipeline_boundary(engine, frozen_models):
     """ugvc_filter_variants on a callset large enough for the chunk pipeline (csrc/pipeline.hip: >= 262144 rows; passes read
     the staging blocks, results are written packed and placed into the resident columns behind the pass): (i) equals the

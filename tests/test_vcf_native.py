@@ -59,7 +59,7 @@ def _same_file(a, b, mutect=False):
 def test_header_symbols_are_exported():
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "ugvc_vcf.h")).read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(ugvc_(?:vcf|fasta|intervals)_[a-z0-9_]+)\s*\(", text)))
-    assert len(names) == 16
+    assert len(names) == 17
     lib = nv.load_library()
     for n in names:
         assert hasattr(lib, n), n
@@ -647,3 +647,20 @@ def test_part_reads_are_the_equal_count_slices_of_the_callset(tmp_path, world):
     part.close()
     with pytest.raises(ValueError, match="part"):
         nv.read_vcf(p, cs.ref.names, part=(2, 2))
+
+
+def test_count_hook_is_called_once_with_the_record_count(tmp_path):
+    """ugvc_vcf_set_count_hook (round 4): the reader tells the tool how many records it holds as soon as the lines are counted -
+    once, on the calling thread, for the next read of that thread only (filter_variants_pipeline starts Engine.reserve there)."""
+    from variantcalling_amd import synth
+    from variantcalling_amd.io import vcf as pyvcf, vcf_native
+    cs = synth.make_callset(3000, genome_len=2_000_000, n_contigs=3, seed=5)
+    path = str(tmp_path / "calls.vcf.gz")
+    pyvcf.write_vcf_from_table(path, cs.variants, cs.ref.names)
+    seen = []
+    a = vcf_native.read_vcf(path, list(cs.ref.names), on_count=lambda n, tb: seen.append((n, tb)))
+    assert len(seen) == 1 and seen[0][0] == a.table.n and seen[0][1] > 0
+    b = vcf_native.read_vcf(path, list(cs.ref.names))                      # (the hook does not outlive its read)
+    assert len(seen) == 1 and b.table.n == a.table.n
+    part = vcf_native.read_vcf(path, list(cs.ref.names), part=(1, 2), on_count=lambda n, tb: seen.append((n, tb)))
+    assert len(seen) == 2 and seen[1][0] == part.table.n                  # (a part read reports the part's records)

@@ -127,7 +127,8 @@ int launch_score(ugvc_ctx* ctx, const FilterArgs& a) {
 int validate_rows(const ugvc_variants* v, int64_t lo, int64_t hi, int n_contigs, int64_t* n_indel, int64_t* row);   // host_rows.cpp
 const char* row_error_text(int what);
 void pipe_destroy(ugvc_ctx* ctx);                                                          // pipeline.hip
-int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_results* out, int n_chunks);
+int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_results* out, int n_chunks, bool reserve_only = false);
+int v5_warm(ugvc_ctx* ctx);
 
 }  // namespace ugvc
 
@@ -502,6 +503,26 @@ int ugvc_filter_variants(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_resul
     if (ugvc_variants_upload(ctx, v)) return -1;
     if (ugvc_filter_resident(ctx)) return -1;
     return ugvc_results_download(ctx, out);
+}
+
+int ugvc_reserve(ugvc_ctx* ctx, int64_t n_variants, int64_t alleles_len) {
+    // Everything ugvc_filter_variants allocates once per size - resident columns, pinned staging slots, streams, events, the
+    // worker pool - and the first use of the kernels' code object, without touching a row: a tool calls it from a helper
+    // thread as soon as it knows the callset's size, beside its other set-up work (the first pass over 5 M rows spent 44 of
+    // its 49 ms there).  Safe beside uploads of the reference / tables / model on another thread; not beside a pass.
+    if (!ctx) return fail("ctx is NULL");
+    if (n_variants < 0 || alleles_len < 0) return fail("bad reserve sizes");
+    UGVC_HIP(hipSetDevice(ctx->device));
+    if (v5_warm(ctx)) return -1;
+    if (n_variants < 262144) return 0;                           // (small callsets take the plain upload path: nothing to prepare)
+    const char* e = getenv("UGVC_PIPE_CHUNKS");
+    const int chunks = std::min(e ? atoi(e) : 8, 64);
+    if (chunks <= 1) return 0;
+    ugvc_variants v;
+    memset(&v, 0, sizeof v);
+    v.n = n_variants;
+    v.alleles_len = alleles_len;
+    return filter_variants_pipelined(ctx, &v, nullptr, chunks, true);
 }
 
 int ugvc_timed_filter(ugvc_ctx* ctx, int iters, float* ms_total) {

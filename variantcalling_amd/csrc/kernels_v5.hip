@@ -40,6 +40,7 @@
 #include <vector>
 
 #include "ugvc_walk.hpp"
+#include <atomic>
 
 namespace ugvc {
 
@@ -2063,17 +2064,24 @@ int launch_feature_matrix_v5(ugvc_ctx* ctx, const FilterArgs& a) {
     return 0;
 }
 
+// The scoring kernels' function attributes (per device, once).  Also the first use of the library's code object on the device:
+// ugvc_reserve calls it from a helper thread so that a tool's first pass does not pay the load (~10 ms).
+int v5_warm(ugvc_ctx* ctx) {
+    static std::atomic<bool> attr_set[64] = {};
+    if (!attr_set[ctx->device & 63].load()) {
+        for (K5 f : {fused5_for(0), fused5_for(1), fused5_for(2), fused5_for(3), fused5_for(4), fused5_for(5), fused5_for(3, true), (K5)forest5_kernel,
+                     (K5)fused5_kernel<3, 16>})
+            UGVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, kLds5Limit));
+        attr_set[ctx->device & 63].store(true);
+    }
+    return 0;
+}
+
 int launch_filter_v5(ugvc_ctx* ctx, const FilterArgs& a) {
     if (a.n == 0) return 0;
     V5Args v;
     if (v5_fill_args(ctx, v, a)) return -1;
-    static bool attr_set[64] = {};                               // (function attributes are per device)
-    if (!attr_set[ctx->device & 63]) {
-        for (K5 f : {fused5_for(0), fused5_for(1), fused5_for(2), fused5_for(3), fused5_for(4), fused5_for(5), fused5_for(3, true), (K5)forest5_kernel,
-                     (K5)fused5_kernel<3, 16>})
-            UGVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, kLds5Limit));
-        attr_set[ctx->device & 63] = true;
-    }
+    if (v5_warm(ctx)) return -1;
     // UGVC_DEBUG_SYNC=1: name every launch on stderr and wait for it (a GPU memory fault aborts the process; the
     // last name printed is the kernel that faulted)
     static const bool dbg = getenv("UGVC_DEBUG_SYNC") != nullptr;

@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(256) pipe_offsets_fill_kernel(const uint16_t* 
         }
 }
 
-int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_results* out, int n_chunks) {
+int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_results* out, int n_chunks, bool reserve_only) {
     // UGVC_PIPE_TRACE=1: host and device timeline of the call on stderr (ms since entry; tools/pipe_trace.py reads it)
     static const bool trace = getenv("UGVC_PIPE_TRACE") != nullptr;
     const auto t_entry = std::chrono::steady_clock::now();
@@ -313,6 +313,7 @@ int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_
         UGVC_HIP(hipEventCreateWithFlags(&e, ps->ev_timed ? hipEventDefault : hipEventDisableTiming));
         ps->ev.push_back(e);
     }
+    if (reserve_only) return 0;                                // (ugvc_reserve: buffers, pinned slots, streams, events, worker pool - no data touched)
     auto ev_in = [&](int c) { return ps->ev[(size_t)(4 * c)]; };          // the chunk's slot has landed in device staging
     auto ev_pass = [&](int c) { return ps->ev[(size_t)(4 * c + 1)]; };    // the pass over the chunk is done
     auto ev_out = [&](int c) { return ps->ev[(size_t)(4 * c + 2)]; };     // the chunk's results are in pinned memory

@@ -765,6 +765,19 @@ int ugvc_vcf_format_f32(float x, char* buf, int cap) { return buf ? format_f32(x
 
 void ugvc_vcf_free(ugvc_vcf* h) { delete h; }
 
+// ---- "the reader knows how many records it holds" hook (round 4) --------------------------------------------------
+// A tool that wants to prepare something of the callset's size while the reader is still tokenising (the GPU engine's
+// ugvc_reserve) leaves a function here: it is called ONCE, on the calling thread, by the next ugvc_vcf_read / _read_part of
+// THIS thread as soon as the record lines are counted - with two thirds of the reader's time still ahead - and forgotten.
+namespace {
+thread_local void (*t_count_hook)(int64_t, int64_t, void*) = nullptr;
+thread_local void* t_count_user = nullptr;
+}
+void ugvc_vcf_set_count_hook(void (*fn)(int64_t n_records, int64_t text_bytes, void* user), void* user) {
+    t_count_hook = fn;
+    t_count_user = user;
+}
+
 int ugvc_vcf_read(const char* path, const char* const* contig_names, int n_contigs, int is_mutect, int sample,
                   int n_threads, ugvc_vcf** out) {
     return ugvc_vcf_read_part(path, contig_names, n_contigs, is_mutect, sample, n_threads, 0, 1, out);
@@ -839,6 +852,11 @@ int ugvc_vcf_read_part(const char* path, const char* const* contig_names, int n_
     const int64_t n = (int64_t)h->rec_lines.size();
     h->n = n;
     st.lap("lines");
+    if (t_count_hook) {
+        void (*fn)(int64_t, int64_t, void*) = t_count_hook;
+        t_count_hook = nullptr;
+        fn(n, tn, t_count_user);
+    }
 
     // ---- tokenise (file order)
     std::unordered_map<std::string_view, int> contig_idx;

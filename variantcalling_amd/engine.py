@@ -51,6 +51,7 @@ ABI = {
     "ugvc_ctx_destroy": (C.c_int, [_ctx]),
     "ugvc_device_info": (C.c_int, [_ctx, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "ugvc_device_attr": (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_int64)]),
+    "ugvc_reserve": (C.c_int, [_ctx, C.c_int64, C.c_int64]),
     "ugvc_sync": (C.c_int, [_ctx]),
     "ugvc_ref_upload": (C.c_int, [_ctx, _u8p, C.c_int64, _i64p, C.c_int]),
     "ugvc_runs_upload": (C.c_int, [_ctx, _i32p, _i32p, _i32p, C.c_int64, C.c_int, C.c_int, C.c_int]),
@@ -241,6 +242,11 @@ class Engine:
                 self._check(self.lib.ugvc_model_clear(self._h, g))
         for g in range(len(forests), S.N_GROUPS):
             self._check(self.lib.ugvc_model_clear(self._h, g))
+
+    def reserve(self, n_variants: int, alleles_len: int):
+        """Allocate what `filter_variants` allocates once per callset size, and load the kernels, without touching data
+        (a tool calls it from a helper thread while it reads / uploads its other inputs)."""
+        self._check(self.lib.ugvc_reserve(self._h, int(n_variants), int(alleles_len)))
 
     def set_kernel_variant(self, v: int):
         self._check(self.lib.ugvc_set_kernel_variant(self._h, v))

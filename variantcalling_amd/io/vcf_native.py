@@ -38,6 +38,9 @@ class _IntervalsView(C.Structure):
     _fields_ = [("n", C.c_int64), ("contig", C.c_void_p), ("start", C.c_void_p), ("end", C.c_void_p)]
 
 
+_COUNT_HOOK = C.CFUNCTYPE(None, C.c_int64, C.c_int64, C.c_void_p)
+
+
 def load_library():
     global _lib
     if _lib is None:
@@ -49,6 +52,8 @@ def load_library():
         lib.ugvc_vcf_read_part.restype = C.c_int
         lib.ugvc_vcf_read_part.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.POINTER(C.c_void_p)]
+        lib.ugvc_vcf_set_count_hook.restype = None
+        lib.ugvc_vcf_set_count_hook.argtypes = [_COUNT_HOOK, C.c_void_p]
         lib.ugvc_vcf_part_info.restype = C.c_int
         lib.ugvc_vcf_part_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         lib.ugvc_vcf_read.restype = C.c_int
@@ -176,7 +181,7 @@ class NativeVcfFile:
 
 
 def read_vcf(path: str, contig_names: list, is_mutect: bool = False, sample: int = 0, n_threads: int = 0,
-             part: tuple | None = None) -> NativeVcfFile:
+             part: tuple | None = None, on_count=None) -> NativeVcfFile:
     """The whole callset, or - `part = (rank, world)` - the equal-count slice of its records (file order) that one rank of a
     multi-process run scores: `.n_total` records are in the file, `.part_lo` is the file-order index of the slice's first
     record, `.sorted_in_file` says whether the slice was sorted by (contig, pos) as it stood (the caller checks the seams
@@ -185,8 +190,17 @@ def read_vcf(path: str, contig_names: list, is_mutect: bool = False, sample: int
     names = (C.c_char_p * len(contig_names))(*[n.encode() for n in contig_names])
     h = C.c_void_p()
     rank, world = part if part is not None else (0, 1)
-    if lib.ugvc_vcf_read_part(os.fsencode(path), names, len(contig_names), int(is_mutect), int(sample), int(n_threads),
-                              int(rank), int(world), C.byref(h)):
+    hook = None
+    if on_count is not None:                                # on_count(n_records, text_bytes): once, when the lines are counted
+        hook = _COUNT_HOOK(lambda n, tb, _u: on_count(int(n), int(tb)))
+        lib.ugvc_vcf_set_count_hook(hook, None)
+    try:
+        rc = lib.ugvc_vcf_read_part(os.fsencode(path), names, len(contig_names), int(is_mutect), int(sample), int(n_threads),
+                                    int(rank), int(world), C.byref(h))
+    finally:
+        if hook is not None:
+            lib.ugvc_vcf_set_count_hook(_COUNT_HOOK(0), None)
+    if rc:
         raise ValueError(_err(lib))
     f = NativeVcfFile(h, lib, is_mutect)
     nt, lo = C.c_int64(), C.c_int64()

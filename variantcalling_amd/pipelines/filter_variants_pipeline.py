@@ -76,10 +76,25 @@ def run(argv: list[str]):
     # tokeniser / ordering / column stages - two thirds of the reader's time - run on 1 / world of them).  That slice is the
     # rank's shard of the SORTED callset only if the file is sorted: established below across ranks, else every rank reads all.
     part = (grp.rank, grp.world) if grp.world > 1 and grp.rank > 0 else None
+    # Single process: as soon as the reader has counted the record lines (a third of the way through the read) the context thread
+    # prepares what the boundary call allocates once per callset size - resident columns, pinned staging, worker pool - and
+    # loads the kernels (Engine.reserve: 44 of the first 5 M-row call's 49 ms); rows and allele bytes with an eighth of margin
+    # for multi-allelic records (a short reservation is topped up by the call itself).
+    reserve = {}
+
+    def on_count(n_records, _text_bytes):
+        if grp.world == 1:
+            reserve["f"] = ctx_pool.submit(lambda: f_eng.result().reserve(n_records + n_records // 8, 4 * n_records))
+
+    def wait_for_reserve():
+        f = reserve.pop("f", None)
+        return f.exception() if f is not None else None      # (waits: the context must not be used for a pass, or closed, under it)
+
     try:
         ref, runs, tracks, bl, extra = common.load_side_tables(
             args.reference_file, args.runs_file, args.annotate_intervals, args.blacklist,
-            also={"vcf": lambda names: vcfio.read_vcf(args.input_file, names, is_mutect=args.is_mutect, n_threads=n_threads, part=part)})
+            also={"vcf": lambda names: vcfio.read_vcf(args.input_file, names, is_mutect=args.is_mutect, n_threads=n_threads, part=part,
+                                                      on_count=on_count)})
         vcf = extra["vcf"]
         if grp.world > 1:
             import json
@@ -101,6 +116,7 @@ def run(argv: list[str]):
         common.check_model_tracks(forests, len(tracks), "filter_variants_pipeline")
     except BaseException:
         try:
+            wait_for_reserve()
             f_eng.result().close()
         except Exception:                                   # (no GPU / no library: the input error is the one to report)
             pass
@@ -126,13 +142,19 @@ def run(argv: list[str]):
             mine = table
         counts = [int(x.decode()) for x in grp.allgather_bytes(str(mine.n).encode())]
     with f_eng.result() as eng:
-        ctx_pool.shutdown()
         if grp.world == 1:
-            configure(eng, ref, runs, tracks, bl, forests, args.flow_order, hp_len, hp_dist, True)
+            try:
+                configure(eng, ref, runs, tracks, bl, forests, args.flow_order, hp_len, hp_dist, True)
+            finally:
+                res_err = wait_for_reserve()
+                ctx_pool.shutdown()
+            if res_err is not None:
+                raise res_err
             lap("context + uploads (reference, tables, model)")
             res_rows = eng.filter_variants(table)
             lap("upload variants + scoring pass + download")
         else:
+            ctx_pool.shutdown()
             ref_r, runs_r, tracks_r, bl_r, mine_r = shard.slice_context(ref, runs, tracks, bl, mine, hpol_dist=hp_dist)
             configure(eng, ref_r, runs_r, tracks_r, bl_r, forests, args.flow_order, hp_len, hp_dist, True)
             uid = grp.broadcast_bytes(eng.comm_unique_id() if grp.rank == 0 else None, 0)
