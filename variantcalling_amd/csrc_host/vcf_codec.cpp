@@ -554,6 +554,10 @@ bool parse_record(const char* base, Span line, int64_t k, const std::unordered_m
         for (int q = 0; q < f[4].len; ++q) na += a[q] == ',';
         P.n_alt[k] = (uint8_t)(na > 255 ? 255 : na);
     }
+    if (P.ref[k].len == 0 || P.alt[k].len == 0) {           // (schema.VariantTable.validate's rule, enforced where the row is known)
+        err = path + ": record " + std::to_string(k + 1) + ": empty alleles are not representable";
+        return false;
+    }
     if (P.ref[k].len > 65535 || P.alt[k].len > 65535) {
         err = path + ": record " + std::to_string(k + 1) + ": allele longer than 65535 bases";
         return false;
