@@ -326,7 +326,10 @@ def test_interval_reader_matches_the_python_reference(tmp_path):
 
 def _random_vcf(rng, n):
     nums = ["0", "1", "7", "42", "1e2", "1E-3", ".5", "5.", "+3", "-2", "nan", "NaN", "inf", "-Inf", "Infinity", ".", "", "abc",
-            " 12", "12 ", "1_0", "0x10", "1e400", "-1e400", "1,2", "00012", "3.99", "-0.0", "2147483648", "-2147483649", "1e-320"]
+            " 12", "12 ", "1_0", "0x10", "1e400", "-1e400", "1,2", "00012", "3.99", "-0.0", "2147483648", "-2147483649", "1e-320",
+            # (round 4: plain decimals take the integer / power-of-ten path - fifteen digits at most - everything else strtod)
+            "123456789012345", "1234567890123456", "0.000000000000001", "999999999999999.", "4.35", "0.1", "1.005", "-.5", "+.5",
+            "1..2", "1.2.3", "-", "+", "-.", "0.30000000000000004", "72057594037927.93", "9007199254740993", "1.0000000000000002"]
     gts = ["0/1", "1/1", "1|1", "0|0", "./.", "1", "0", "1/0", "1/1/1", "1|0|1", ".", "", "2/1", "1/2"]
     chroms = ["chr1", "chr2", "chr3", "chrUn"]
     lines = ["##fileformat=VCFv4.2", "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\ts1\ts2"]
