@@ -535,11 +535,11 @@ __device__ __forceinline__ void store_feature_rows_tile(const FilterArgs& a, uin
     __builtin_amdgcn_wave_barrier();                             // (before the next tile stages its slices here)
 }
 
-// ---- the joins of one contig SEGMENT of an SNP tile (lanes 0 .. last share contig c_seg; almost always the whole tile) --------
-// The slices fetched from the carried ranks (`pre`) go to the wave's LDS scratch, sentinel padded; seven lock-step descent
-// steps rank every table at once; verdicts from a few reads around the rank; a table whose staged slice does not reach the
-// segment's last variant is searched in HBM from the carried rank.  Leaves the ranks at lane `last` in `bk` (where the next
-// tile - or the next segment's search - starts).  Lanes beyond `last` compute values nobody reads.
+// ---- the joins of an SNP tile (lanes 0 .. last are its rows, all of contig c_seg: tile_cut; the lanes behind repeat lane 0) ------
+// The slices fetched from the carried ranks (`pre`) go to the wave's LDS scratch, sentinel padded; six lock-step descent
+// steps (seven for a table staged with 128 rows) rank every table at once; verdicts from a few reads around the rank; a table
+// whose staged slice does not reach the tile's last variant is searched in HBM from the carried rank.  Leaves the ranks at
+// lane `last` in `bk` (where the wave's next tile starts).  (The name is from the version that joined a tile contig by contig.)
 template <int NT>
 __device__ __forceinline__ void snp_join_segment(const V5Args& v, const Scratch& sc, Brk<NT>& bk, const SlicePre<NT>& pre, int lane, int pos,
                                                  uint64_t key, int c_seg, int last, JoinOut& jo) {
