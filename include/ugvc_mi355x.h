@@ -96,6 +96,14 @@ int ugvc_device_info(ugvc_ctx* ctx, char* name, int name_cap, int* n_cus, int64_
  * units, 2 peak memory clock in kHz, 3 LDS bytes per workgroup.  bench.py prices its instruction-issue floor with it. */
 int ugvc_device_attr(ugvc_ctx* ctx, int what, int64_t* out);
 int ugvc_sync(ugvc_ctx* ctx);
+/* Device canary (builder-defined; the reference's cheapest self-check is the CI's `-h` smoke of the two pipelines,
+ * .github/workflows/python-package-conda.yml:46-61): n 64-bit words host -> device -> host, then the library's prefix-sum
+ * kernel over them against the host's sum.  0 = this device copies and computes; the error text names the step that
+ * did not.  Debug allocation modes of every device buffer (tests only, results unchanged): UGVC_GUARD=1|2 (end | start
+ * of each buffer abuts an unmapped 2 MiB range), UGVC_POISON=1|2 (new buffers filled with 0xA5 | 0xFF),
+ * UGVC_DEBUG_SYNC=1 (every kernel launch named on stderr and waited for), UGVC_BREADCRUMB=1 (the last launches are
+ * printed if the process aborts). */
+int ugvc_selftest(ugvc_ctx* ctx, int64_t n);
 
 /* ---- resident side tables --------------------------------------------------------------
  * ugvc_ref_upload: `--reference_file` (docs/filter_variants_pipeline.md:38-39); replaces the

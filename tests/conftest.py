@@ -10,8 +10,31 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+# launch breadcrumbs of the HIP library (csrc/devmem.hip): if a GPU memory fault aborts the process, the last kernels launched
+# are printed behind the runtime's message - the record of a red run names a kernel
+os.environ.setdefault("UGVC_BREADCRUMB", "1")
+
+
+_CONFIG = None
+
+
 def pytest_configure(config):
+    global _CONFIG
+    _CONFIG = config
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
+
+
+def pytest_runtest_logstart(nodeid, location):
+    # GPU runs only (UGVC_TEST_TRACE=1, or a visible device): the name of every test goes to the REAL stderr, past pytest's
+    # capture and unbuffered - a process the runtime aborts (rc 134) still leaves the name of the test it died in
+    if os.environ.get("UGVC_TEST_TRACE", "1" if os.path.exists("/dev/kfd") else "0") == "0" or _CONFIG is None:
+        return
+    capman = _CONFIG.pluginmanager.getplugin("capturemanager")
+    if capman is None:
+        return
+    with capman.global_and_fixture_disabled():
+        sys.stderr.write(f"[test] {nodeid}\n")
+        sys.stderr.flush()
 
 
 @pytest.fixture(scope="session")

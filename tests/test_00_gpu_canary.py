@@ -1,0 +1,49 @@
+"""Collected first (file name): is this GPU usable at all?  A copy round trip and the library's smallest kernel, checked on the
+host, in front of every parity test - a dead box fails HERE with the step named, a kernel bug fails later with the kernel named
+(conftest.py turns the launch breadcrumbs on for every GPU test)."""
+import numpy as np
+import pytest
+
+
+@pytest.mark.gpu
+def test_device_canary_copies_and_computes(engine):
+    info = engine.device_info()
+    print("canary device:", info, flush=True)
+    assert "gfx950" in info["name"], f"not an MI355X: {info}"
+    assert info["n_cus"] >= 64 and info["hbm_bytes"] > (64 << 30)
+    for n in (1, 63, 64, 65, 1024, 100_003):
+        engine.selftest(n)
+
+
+@pytest.mark.gpu
+def test_second_context_canary():
+    """a fresh context beside the session's one: creation, the canary and destruction leave the first one usable"""
+    from variantcalling_amd.engine import Engine
+    with Engine(0) as e2:
+        e2.selftest(4096)
+
+
+@pytest.mark.gpu
+def test_smallest_scoring_pass_after_canary(engine, frozen_models):
+    """the smallest callsets through the production pass right behind the canary, every launch named and waited for: if
+    the first real kernel faults, the log says which"""
+    import os
+    from oracle import oracle as O
+    from variantcalling_amd import synth
+    from variantcalling_amd.engine import configure
+    forests = frozen_models["rf_model_ignore_gt_incl_hpol_runs"]
+    old = os.environ.get("UGVC_DEBUG_SYNC")
+    os.environ["UGVC_DEBUG_SYNC"] = "1"
+    try:
+        for n, contigs in ((1, 1), (65, 3), (1025, 3)):
+            cs = synth.make_callset(n, genome_len=2_000_000, n_contigs=contigs, seed=100 + n)
+            configure(engine, cs.ref, cs.runs, cs.tracks, cs.blacklist, forests)
+            got = engine.filter_variants(cs.variants)
+            exp = O.filter_variants(cs.variants, cs.ref, cs.runs, cs.tracks, cs.blacklist, forests)
+            assert np.array_equal(got.filter, exp.filter) and np.array_equal(got.flags, exp.flags)
+            assert np.array_equal(got.tree_score, exp.tree_score)
+    finally:
+        if old is None:
+            del os.environ["UGVC_DEBUG_SYNC"]
+        else:
+            os.environ["UGVC_DEBUG_SYNC"] = old

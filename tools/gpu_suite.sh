@@ -1,0 +1,43 @@
+#!/bin/bash
+# GPU-box suite runner (gpurun):  tools/gpu_suite.sh <tag> <mode> [<mode> ...]
+#   fresh    the driver's sequence on a fresh lease: smoke() as the box's FIRST GPU process, then `pytest -m gpu -x`
+#   guard1   the whole -m gpu suite, one process per test file, every device buffer's END on an unmapped 2 MiB range
+#   guard2   ... every buffer's START behind an unmapped range
+#   poison   ... every new buffer filled with 0xA5 (no guard mapping)
+#   sync     ... plain allocator, every launch named and waited for
+# Logs: gpurun_out/<tag>_<mode>.txt (+ a one-line verdict per mode in gpurun_out/<tag>_summary.txt)
+set -u
+tag=$1; shift
+out=gpurun_out; mkdir -p $out
+sum=$out/${tag}_summary.txt
+echo "== $tag $(date -u +%FT%TZ) $(git rev-parse --short HEAD 2>/dev/null) lib sha $(sha256sum variantcalling_amd/libugvc_mi355x.so | cut -c1-16)" >> $sum
+per_file() {   # per_file <log> <env...>
+    local log=$1; shift
+    local bad=0 total=0
+    for f in tests/test_*.py; do
+        grep -q "mark.gpu" $f || continue
+        echo "---- $f" >> $log
+        env "$@" timeout 900 python -m pytest $f -q -m gpu -p no:cacheprovider >> $log 2>&1
+        rc=$?
+        line=$(grep -E "passed|failed|error|no tests ran" $log | tail -1)
+        echo "rc=$rc $f :: $line" >> $sum
+        [ $rc -ne 0 ] && [ $rc -ne 5 ] && bad=$((bad+1))
+        total=$((total+1))
+    done
+    echo "$bad of $total files not green ($*)" >> $sum
+}
+for mode in "$@"; do
+    log=$out/${tag}_${mode}.txt; : > $log
+    case $mode in
+    fresh)
+        timeout 600 python -c 'import __graft_entry__ as e; e.smoke(); print("__SMOKE_OK__")' >> $log 2>&1
+        echo "fresh smoke rc=$?" >> $sum
+        timeout 1500 python -m pytest tests/ -x -q -m gpu -p no:cacheprovider >> $log 2>&1
+        echo "fresh pytest rc=$? :: $(grep -E 'passed|failed' $log | tail -1)" >> $sum ;;
+    guard1) per_file $log UGVC_GUARD=1 UGVC_POISON=1 UGVC_DEBUG_SYNC=1 ;;
+    guard2) per_file $log UGVC_GUARD=2 UGVC_POISON=2 UGVC_DEBUG_SYNC=1 ;;
+    poison) per_file $log UGVC_POISON=1 ;;
+    sync)   per_file $log UGVC_DEBUG_SYNC=1 ;;
+    esac
+done
+cat $sum | tail -60

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <limits>
 
+#include "ugvc_prims.hpp"
 #include "ugvc_v2.hpp"
 
 namespace ugvc {
@@ -19,11 +20,11 @@ int fail(const std::string& msg) {
 
 int ensure(DeviceBuf& b, size_t bytes) {
     if (bytes <= b.cap && b.p) return 0;
-    if (b.p) UGVC_HIP(hipFree(b.p));
+    dev_free(b.p);
     b.p = nullptr;
     b.cap = 0;
     size_t want = std::max<size_t>(bytes, 256);
-    UGVC_HIP(hipMalloc(&b.p, want));
+    if (dev_alloc(&b.p, want)) { b.p = nullptr; return -1; }
     b.cap = want;
     return 0;
 }
@@ -43,7 +44,7 @@ static int upload_coarse(ugvc_ctx* ctx, DeviceBuf& dst, const T* a, int64_t n) {
 }
 
 static void release(DeviceBuf& b) {
-    if (b.p) (void)hipFree(b.p);
+    if (b.p) dev_free(b.p);
     b.p = nullptr;
     b.cap = 0;
 }
@@ -222,6 +223,35 @@ int ugvc_sync(ugvc_ctx* ctx) {
     if (!ctx) return fail("ctx is NULL");
     UGVC_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
+}
+
+int ugvc_selftest(ugvc_ctx* ctx, int64_t n) {
+    // The device canary: a copy round trip and one small kernel of this library whose answer the host knows.  A box whose
+    // GPU is unusable fails HERE, with the step named, not inside the first scoring pass.
+    if (!ctx) return fail("ctx is NULL");
+    if (n < 1 || n > (1 << 24)) return fail("selftest size out of range");
+    UGVC_HIP(hipSetDevice(ctx->device));
+    std::vector<uint64_t> h((size_t)n), back((size_t)n, ~0ull);
+    for (int64_t i = 0; i < n; ++i) h[(size_t)i] = (uint64_t)((i * 2654435761ll) % 97);
+    DeviceBuf d, tmp;
+    int rc = 0;
+    do {
+        if ((rc = upload(ctx, d, h.data(), (size_t)n * 8))) break;
+        if (hipMemcpyAsync(back.data(), d.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = fail("selftest: copy round trip failed (device error)"); break; }
+        if (memcmp(h.data(), back.data(), (size_t)n * 8)) { rc = fail("selftest: copy round trip returned different bytes"); break; }
+        if ((rc = scan_u64(ctx, tmp, d.as<uint64_t>(), n, true))) break;
+        if (hipMemcpyAsync(back.data(), d.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = fail("selftest: scan kernel failed (device error)"); break; }
+        uint64_t run = 0;
+        for (int64_t i = 0; i < n && !rc; ++i) {
+            run += h[(size_t)i];
+            if (back[(size_t)i] != run) rc = fail("selftest: scan kernel wrong at element " + std::to_string(i));
+        }
+    } while (0);
+    dev_free(d.p);
+    dev_free(tmp.p);
+    return rc;
 }
 
 int ugvc_ref_upload(ugvc_ctx* ctx, const uint8_t* codes, int64_t total_len, const int64_t* contig_off,

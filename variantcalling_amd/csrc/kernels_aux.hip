@@ -229,13 +229,13 @@ int launch_pileup(ugvc_ctx* ctx) {
         for (int q = 0; q < 5; ++q) a.c16[q] = h + (size_t)q * n;
         const int cap = cap_env ? atoi(cap_env) : (ctx->pl_span <= 8192 ? 8192 : ctx->pl_span <= 10240 ? 10240 : kPlCap);
         auto kern = cap <= 8192 ? pileup_kernel<true, 8192> : cap <= 10240 ? pileup_kernel<true, 10240> : pileup_kernel<true, kPlCap>;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kPlBlock), 0, ctx->stream, a);
+        UGVC_LAUNCH(kern, dim3(grid), dim3(kPlBlock), 0, ctx->stream, a);
     } else {
         a.ref_fwd = o; a.ref_rev = o + n; a.alt_fwd = o + 2 * n; a.alt_rev = o + 3 * n;
         a.other = o + 4 * n; a.dp = o + 5 * n; a.bq_ref = o + 6 * n; a.bq_alt = o + 7 * n;
         a.vaf = reinterpret_cast<float*>(o + 8 * n);
         a.sor = reinterpret_cast<float*>(o + 9 * n);
-        hipLaunchKernelGGL((pileup_kernel<false, kPlCap>), dim3(grid), dim3(kPlBlock), 0, ctx->stream, a);
+        UGVC_LAUNCH((pileup_kernel<false, kPlCap>), dim3(grid), dim3(kPlBlock), 0, ctx->stream, a);
     }
     UGVC_HIP(hipGetLastError());
     return 0;
@@ -278,7 +278,7 @@ int launch_sec(ugvc_ctx* ctx, const int32_t* d_actual, const int32_t* d_expected
                double* d_lik, double* d_ratio) {
     if (n == 0) return 0;
     const unsigned grid = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(sec_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_actual, d_expected, n, k, d_lik, d_ratio);
+    UGVC_LAUNCH(sec_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_actual, d_expected, n, k, d_lik, d_ratio);
     UGVC_HIP(hipGetLastError());
     return 0;
 }
@@ -459,7 +459,7 @@ int ugvc_sec_likelihood_ratio(ugvc_ctx* ctx, const int32_t* actual, const int32_
     }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc) rc = fail("stream sync failed");
     for (DeviceBuf* b : {&da, &de, &dl, &dr})
-        if (b->p) (void)hipFree(b->p);
+        if (b->p) dev_free(b->p);
     return rc;
 }
 
@@ -487,7 +487,7 @@ int ugvc_bridging_snvs(ugvc_ctx* ctx, const ugvc_variants* v, const uint8_t* is_
         a.is_pass = dp_.as<uint8_t>(); a.ad_alt_sum = da.as<int32_t>(); a.bg_ad_alt_sum = db.as<int32_t>();
         a.bg_dp = dd.as<int32_t>(); a.ref = ctx->ref.as<uint8_t>() + kRefFrontPad; a.contig_off = ctx->contig_off.as<int64_t>();
         a.p = *p; a.out_hmer = oh.as<uint8_t>(); a.out_pass = op.as<uint8_t>();
-        hipLaunchKernelGGL(bridging_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a);
+        UGVC_LAUNCH(bridging_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a);
         if (hipGetLastError() != hipSuccess) rc = fail("bridging kernel launch failed");
     }
     if (!rc) {
@@ -497,7 +497,7 @@ int ugvc_bridging_snvs(ugvc_ctx* ctx, const ugvc_variants* v, const uint8_t* is_
     }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc) rc = fail("stream sync failed");
     for (DeviceBuf* b : {&dp_, &da, &db, &dd, &oh, &op})
-        if (b->p) (void)hipFree(b->p);
+        if (b->p) dev_free(b->p);
     return rc;
 }
 

@@ -109,12 +109,12 @@ int ugvc_eval_counts(ugvc_ctx* ctx, const int8_t* label, const uint16_t* cat_bit
         if ((rc = ensure(d_out, kEvalCats * 4 * 8))) break;
         if (hipMemsetAsync(d_out.p, 0, kEvalCats * 4 * 8, ctx->stream) != hipSuccess) { rc = fail("hipMemsetAsync failed"); break; }
         const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, (int64_t)ctx->n_cus * 8);
-        hipLaunchKernelGGL(eval_counts_kernel, dim3(grid), dim3(256), 0, ctx->stream, ctx->r_filter.as<uint8_t>(),
+        UGVC_LAUNCH(eval_counts_kernel, dim3(grid), dim3(256), 0, ctx->stream, ctx->r_filter.as<uint8_t>(),
                            d_lab.as<int8_t>(), d_cat.as<uint16_t>(), n, d_out.as<unsigned long long>());
         if (hipMemcpyAsync(out, d_out.p, kEvalCats * 4 * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = fail("eval_counts: device error"); break; }
     } while (0);
-    for (DeviceBuf* b : {&d_lab, &d_cat, &d_out}) if (b->p) (void)hipFree(b->p);
+    for (DeviceBuf* b : {&d_lab, &d_cat, &d_out}) if (b->p) dev_free(b->p);
     return rc;
 }
 
@@ -138,14 +138,14 @@ int ugvc_pr_curve(ugvc_ctx* ctx, const double* score, const uint8_t* cls, int64_
         if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { rc = fail("hipEventCreate failed"); break; }
         const unsigned grid = (unsigned)((n + 255) / 256);
         (void)hipEventRecord(e0, ctx->stream);
-        hipLaunchKernelGGL(pr_keys_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_s.as<double>(), n, d_k0.as<uint64_t>(), d_i0.as<uint32_t>());
+        UGVC_LAUNCH(pr_keys_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_s.as<double>(), n, d_k0.as<uint64_t>(), d_i0.as<uint32_t>());
         uint64_t* ks = nullptr;
         uint32_t* is = nullptr;
         if ((rc = radix_sort_pairs_u64(ctx, d_tmp, d_k0.as<uint64_t>(), d_k1.as<uint64_t>(), d_i0.as<uint32_t>(), d_i1.as<uint32_t>(), n, &ks, &is))) break;
-        hipLaunchKernelGGL(pr_flags_kernel, dim3(grid), dim3(256), 0, ctx->stream, is, d_cls.as<uint8_t>(), n, d_tf.as<uint64_t>());
+        UGVC_LAUNCH(pr_flags_kernel, dim3(grid), dim3(256), 0, ctx->stream, is, d_cls.as<uint8_t>(), n, d_tf.as<uint64_t>());
         if ((rc = scan_u64(ctx, d_tmp, d_tf.as<uint64_t>(), n, true))) break;
         double* o = d_o.as<double>();
-        hipLaunchKernelGGL(pr_finish_kernel, dim3(grid), dim3(256), 0, ctx->stream, is, d_s.as<double>(),
+        UGVC_LAUNCH(pr_finish_kernel, dim3(grid), dim3(256), 0, ctx->stream, is, d_s.as<double>(),
                            d_tf.as<uint64_t>(), n, initial_tp, initial_fp, initial_fn, o, o + N, o + 2 * N, o + 3 * N,
                            order ? d_ord.as<int32_t>() : nullptr);
         (void)hipEventRecord(e1, ctx->stream);
@@ -159,7 +159,7 @@ int ugvc_pr_curve(ugvc_ctx* ctx, const double* score, const uint8_t* cls, int64_
     } while (0);
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
-    for (DeviceBuf* b : all) if (b->p) (void)hipFree(b->p);
+    for (DeviceBuf* b : all) if (b->p) dev_free(b->p);
     return rc;
 }
 

@@ -331,9 +331,9 @@ __global__ __launch_bounds__(kBlock) void filter_kernel(const FilterArgs a) {
 int launch_filter(ugvc_ctx* ctx, const FilterArgs& a, bool score, bool write_x) {
     if (a.n == 0) return 0;
     const unsigned grid = (unsigned)((a.n + kBlock - 1) / kBlock);
-    if (score && write_x) hipLaunchKernelGGL((filter_kernel<true, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
-    else if (score) hipLaunchKernelGGL((filter_kernel<true, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
-    else hipLaunchKernelGGL((filter_kernel<false, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+    if (score && write_x) UGVC_LAUNCH((filter_kernel<true, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+    else if (score) UGVC_LAUNCH((filter_kernel<true, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+    else UGVC_LAUNCH((filter_kernel<false, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
     UGVC_HIP(hipGetLastError());
     return 0;
 }

@@ -348,11 +348,11 @@ extern "C" int ugvc_forest_gemm(ugvc_ctx* ctx, int group, const int32_t* rows, i
             const unsigned grid = (unsigned)ctx->n_cus;
             if (hipEventRecord(ctx->ev0, ctx->stream) != hipSuccess) rc = fail("event record failed");
             for (int it = 0; it < iters && !rc; ++it) {
-                if (!use_mfma) hipLaunchKernelGGL(forest_rows_kernel, dim3(grid * 4), dim3(256), lds, ctx->stream, g);
-                else if (!v2) hipLaunchKernelGGL(forest_gemm_kernel, dim3(grid), dim3(kGemmThreads), lds, ctx->stream, g);
+                if (!use_mfma) UGVC_LAUNCH(forest_rows_kernel, dim3(grid * 4), dim3(256), lds, ctx->stream, g);
+                else if (!v2) UGVC_LAUNCH(forest_gemm_kernel, dim3(grid), dim3(kGemmThreads), lds, ctx->stream, g);
                 // (two workgroups of eight waves per CU: 110 registers and 66 KB of LDS each)
-                else if (kind == UGVC_MODEL_RF) hipLaunchKernelGGL(forest_gemm2_kernel<true>, dim3(grid * 2), dim3(kGemm2Threads), lds, ctx->stream, g);
-                else hipLaunchKernelGGL(forest_gemm2_kernel<false>, dim3(grid * 2), dim3(kGemm2Threads), lds, ctx->stream, g);
+                else if (kind == UGVC_MODEL_RF) UGVC_LAUNCH(forest_gemm2_kernel<true>, dim3(grid * 2), dim3(kGemm2Threads), lds, ctx->stream, g);
+                else UGVC_LAUNCH(forest_gemm2_kernel<false>, dim3(grid * 2), dim3(kGemm2Threads), lds, ctx->stream, g);
             }
             if (!rc && (hipEventRecord(ctx->ev1, ctx->stream) != hipSuccess || hipEventSynchronize(ctx->ev1) != hipSuccess ||
                         hipGetLastError() != hipSuccess))
@@ -368,6 +368,6 @@ extern "C" int ugvc_forest_gemm(ugvc_ctx* ctx, int group, const int32_t* rows, i
     }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc) rc = fail("stream sync failed");
     for (DeviceBuf* b : {&dn, &dl, &dr, &dout})
-        if (b->p) (void)hipFree(b->p);
+        if (b->p) dev_free(b->p);
     return rc;
 }

@@ -151,10 +151,10 @@ __global__ void narrow_u32_kernel(const uint64_t* __restrict__ in, uint32_t* __r
 static int scan_rec(ugvc_ctx* ctx, uint64_t* data, int64_t n, bool inclusive, uint64_t* scratch, size_t scratch_words) {
     const int64_t tiles = (n + kScanTile - 1) / kScanTile;
     if ((size_t)tiles > scratch_words) return fail("internal: scan scratch too small");
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3((unsigned)tiles), dim3(kSortThreads), 0, ctx->stream, data, n, inclusive ? 1 : 0, scratch);
+    UGVC_LAUNCH(scan_tiles_kernel, dim3((unsigned)tiles), dim3(kSortThreads), 0, ctx->stream, data, n, inclusive ? 1 : 0, scratch);
     if (tiles > 1) {
         if (scan_rec(ctx, scratch, tiles, false, scratch + tiles, scratch_words - (size_t)tiles)) return -1;
-        hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, data, n, scratch);
+        UGVC_LAUNCH(scan_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, data, n, scratch);
     }
     return 0;
 }
@@ -198,7 +198,7 @@ int radix_sort_pairs_u64(ugvc_ctx* ctx, DeviceBuf& tmp, uint64_t* k0, uint64_t* 
     uint64_t* scratch = reinterpret_cast<uint64_t*>(t + off_scan);
     UGVC_HIP(hipMemsetAsync(census, 0, 8 * 256 * 8, ctx->stream));
     const unsigned cgrid = (unsigned)std::min<int64_t>((n + kSortThreads - 1) / kSortThreads, (int64_t)ctx->n_cus * 8);
-    hipLaunchKernelGGL(sort_census_kernel, dim3(cgrid), dim3(kSortThreads), 0, ctx->stream, k0, n, census);
+    UGVC_LAUNCH(sort_census_kernel, dim3(cgrid), dim3(kSortThreads), 0, ctx->stream, k0, n, census);
     unsigned long long h[8 * 256];
     UGVC_HIP(hipMemcpyAsync(h, census, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     UGVC_HIP(hipStreamSynchronize(ctx->stream));
@@ -210,12 +210,12 @@ int radix_sort_pairs_u64(ugvc_ctx* ctx, DeviceBuf& tmp, uint64_t* k0, uint64_t* 
             if (h[p * 256 + d] == (unsigned long long)n) { trivial = true; break; }
         if (trivial) continue;
         const int shift = 8 * p;
-        hipLaunchKernelGGL(sort_hist_kernel, dim3((unsigned)n_blocks), dim3(kSortThreads), 0, ctx->stream, ki, n, shift, hist, n_blocks);
+        UGVC_LAUNCH(sort_hist_kernel, dim3((unsigned)n_blocks), dim3(kSortThreads), 0, ctx->stream, ki, n, shift, hist, n_blocks);
         const unsigned g = (unsigned)((hist_words + 255) / 256);
-        hipLaunchKernelGGL(widen_u32_kernel, dim3(g), dim3(256), 0, ctx->stream, hist, wide, (int64_t)hist_words);
+        UGVC_LAUNCH(widen_u32_kernel, dim3(g), dim3(256), 0, ctx->stream, hist, wide, (int64_t)hist_words);
         if (scan_rec(ctx, wide, (int64_t)hist_words, false, scratch, scan_words)) return -1;
-        hipLaunchKernelGGL(narrow_u32_kernel, dim3(g), dim3(256), 0, ctx->stream, wide, hist, (int64_t)hist_words);
-        hipLaunchKernelGGL(sort_scatter_kernel, dim3((unsigned)n_blocks), dim3(kSortThreads), 0, ctx->stream, ki, vi, ko, vo, n, shift, hist, n_blocks);
+        UGVC_LAUNCH(narrow_u32_kernel, dim3(g), dim3(256), 0, ctx->stream, wide, hist, (int64_t)hist_words);
+        UGVC_LAUNCH(sort_scatter_kernel, dim3((unsigned)n_blocks), dim3(kSortThreads), 0, ctx->stream, ki, vi, ko, vo, n, shift, hist, n_blocks);
         std::swap(ki, ko);
         std::swap(vi, vo);
     }

@@ -375,19 +375,19 @@ int ugvc_sec_db_build(ugvc_ctx* ctx, const uint64_t* keys, const int32_t* counts
             rc = fail("hipMemsetAsync failed");
             break;
         }
-        hipLaunchKernelGGL(sec_iota_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_i0.as<uint32_t>(), n_obs);
+        UGVC_LAUNCH(sec_iota_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_i0.as<uint32_t>(), n_obs);
         uint64_t* ks = nullptr;
         uint32_t* is = nullptr;
         if ((rc = radix_sort_pairs_u64(ctx, d_tmp, d_k0.as<uint64_t>(), d_k1.as<uint64_t>(), d_i0.as<uint32_t>(), d_i1.as<uint32_t>(), n_obs, &ks, &is))) break;
-        hipLaunchKernelGGL(sec_heads_kernel, dim3(grid), dim3(256), 0, ctx->stream, ks, n_obs, d_seg.as<uint64_t>());
+        UGVC_LAUNCH(sec_heads_kernel, dim3(grid), dim3(256), 0, ctx->stream, ks, n_obs, d_seg.as<uint64_t>());
         if ((rc = scan_u64(ctx, d_tmp, d_seg.as<uint64_t>(), n_obs, true))) break;
         uint64_t last = 0;
         if (hipMemcpyAsync(&last, d_seg.as<uint64_t>() + (N - 1), 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = fail("sec_db_build: device error"); break; }
         n_unique = (int64_t)last;
-        hipLaunchKernelGGL(sec_segment_sum_kernel, dim3(grid), dim3(256), 0, ctx->stream, ks, is, d_seg.as<uint64_t>(), d_cnt.as<int32_t>(), n_obs, k,
+        UGVC_LAUNCH(sec_segment_sum_kernel, dim3(grid), dim3(256), 0, ctx->stream, ks, is, d_seg.as<uint64_t>(), d_cnt.as<int32_t>(), n_obs, k,
                            d_uk.as<uint64_t>(), d_sum.as<unsigned long long>());
-        hipLaunchKernelGGL(sec_narrow_kernel, dim3((unsigned)((n_unique * k + 255) / 256)), dim3(256), 0, ctx->stream, d_sum.as<unsigned long long>(),
+        UGVC_LAUNCH(sec_narrow_kernel, dim3((unsigned)((n_unique * k + 255) / 256)), dim3(256), 0, ctx->stream, d_sum.as<unsigned long long>(),
                            n_unique * k, d_out.as<int32_t>(), d_ovf.as<int>());
         int ovf = 0;
         if (hipMemcpyAsync(out_keys, d_uk.p, (size_t)n_unique * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
@@ -397,7 +397,7 @@ int ugvc_sec_db_build(ugvc_ctx* ctx, const uint64_t* keys, const int32_t* counts
         if (ovf) { rc = fail("a summed count exceeds int32"); break; }
         *out_n = n_unique;
     } while (0);
-    for (DeviceBuf* b : all) if (b->p) (void)hipFree(b->p);
+    for (DeviceBuf* b : all) if (b->p) dev_free(b->p);
     return rc;
 }
 
@@ -442,7 +442,7 @@ int ugvc_sec_apply(ugvc_ctx* ctx, double min_ratio, int scale_expected, int mark
         static const bool simple_env = getenv("UGVC_SEC_SIMPLE") != nullptr;
         const bool simple = simple_env || n >= ((int64_t)1 << 32) || ctx->n_sec >= ((int64_t)1 << 32);   // (the hit queue holds 32-bit row numbers)
         if (simple) {
-            hipLaunchKernelGGL(sec_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->v_contig.as<uint16_t>(),
+            UGVC_LAUNCH(sec_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->v_contig.as<uint16_t>(),
                                ctx->v_pos.as<int32_t>(), ctx->v_dp.as<int32_t>(), ctx->v_adr.as<int32_t>(), ctx->v_ada.as<int32_t>(), n,
                                ctx->sec_keys.as<uint64_t>(), ctx->sec_coarse.as<uint64_t>(), ctx->sec_exp.as<int32_t>(), ctx->sec_lgtab.as<double>(), ctx->n_sec,
                                ctx->sec_k,
@@ -472,7 +472,7 @@ int ugvc_sec_apply(ugvc_ctx* ctx, double min_ratio, int scale_expected, int mark
                      : block == 256 ? pick_k(want, std::integral_constant<int, 256>{}) : pick_k(want, std::integral_constant<int, 512>{});
             };
             auto kern = ratio ? pick(std::true_type{}) : pick(std::false_type{});
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, ctx->stream, ctx->v_contig.as<uint16_t>(),
+            UGVC_LAUNCH(kern, dim3(grid), dim3(block), 0, ctx->stream, ctx->v_contig.as<uint16_t>(),
                                ctx->v_pos.as<int32_t>(), ctx->v_dp.as<int32_t>(), ctx->v_adr.as<int32_t>(), ctx->v_ada.as<int32_t>(), n,
                                ctx->sec_keys.as<uint64_t>(), ctx->sec_exp.as<int32_t>(), ctx->sec_lgtab.as<double>(), ctx->n_sec, ctx->sec_k,
                                min_ratio, log_min, scale_expected, ratio ? d_r.as<double>() : nullptr, is_sec ? d_s.as<uint8_t>() : nullptr,
@@ -484,7 +484,7 @@ int ugvc_sec_apply(ugvc_ctx* ctx, double min_ratio, int scale_expected, int mark
             (is_sec && hipMemcpyAsync(is_sec, d_s.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) ||
             ((ratio || is_sec) && hipStreamSynchronize(ctx->stream) != hipSuccess)) { rc = fail("sec_apply: device error"); break; }
     } while (0);
-    for (DeviceBuf* b : {&d_r, &d_s}) if (b->p) (void)hipFree(b->p);
+    for (DeviceBuf* b : {&d_r, &d_s}) if (b->p) dev_free(b->p);
     return rc;
 }
 

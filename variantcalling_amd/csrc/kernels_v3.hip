@@ -959,14 +959,14 @@ int launch_filter_v3(ugvc_ctx* ctx, const FilterArgs& a) {
     v.f = a;
     if (v2_fill_args(ctx, v, a.n)) return -1;
     const int64_t nbr = std::max<int64_t>((int64_t)(v.n_blocks + 1) * 8, UGVC_N_GROUPS * kShards);
-    hipLaunchKernelGGL(bracket3_kernel, dim3((unsigned)((nbr + 255) / 256)), dim3(256), 0, ctx->stream, v);
+    UGVC_LAUNCH(bracket3_kernel, dim3((unsigned)((nbr + 255) / 256)), dim3(256), 0, ctx->stream, v);
     // profiling knobs (tools/tune3.py): bits 12-13 of the kernel variant cap K1's workgroups per CU,
     // bits 14-15 pick K2's wave count; 0 = the defaults
     const int k1_bpc = ((a.ablate >> 12) & 3) ? ((a.ablate >> 12) & 3) : 4;
     const int k1_grid = std::min(v.n_blocks, ctx->n_cus * k1_bpc);
     // kernel variant bit 5 (32): K1 without the one-tile-ahead column prefetch
-    if (a.ablate & 32) hipLaunchKernelGGL(featurize3_kernel<false>, dim3((unsigned)k1_grid), dim3(kBlock), 0, ctx->stream, v);
-    else hipLaunchKernelGGL(featurize3_kernel<true>, dim3((unsigned)k1_grid), dim3(kBlock), 0, ctx->stream, v);
+    if (a.ablate & 32) UGVC_LAUNCH(featurize3_kernel<false>, dim3((unsigned)k1_grid), dim3(kBlock), 0, ctx->stream, v);
+    else UGVC_LAUNCH(featurize3_kernel<true>, dim3((unsigned)k1_grid), dim3(kBlock), 0, ctx->stream, v);
     return launch_forest3(ctx, v, a);
 }
 
@@ -998,7 +998,7 @@ int launch_forest3(ugvc_ctx* ctx, const V2Args& v, const FilterArgs& a) {
                 UGVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
             attr_set[ctx->device & 63] = true;
         }
-        hipLaunchKernelGGL(fn, dim3((unsigned)ctx->n_cus), dim3(n_waves * 64), lds, ctx->stream, v);
+        UGVC_LAUNCH(fn, dim3((unsigned)ctx->n_cus), dim3(n_waves * 64), lds, ctx->stream, v);
     }
     UGVC_HIP(hipGetLastError());
     return 0;

@@ -2059,7 +2059,7 @@ int launch_feature_matrix_v5(ugvc_ctx* ctx, const FilterArgs& a) {
     if (const char* e = getenv("UGVC_FM_INDEL_W")) v.indel_w = std::max(1, (int)(atof(e) * 256.0));      // (profiling)
     if (lds5_bytes(v, v.n_waves) > (size_t)kLds5Limit) return fail("internal: feature-matrix scratch does not fit LDS");
     const unsigned n_wg = (unsigned)((a.n + v.rows_wg - 1) / v.rows_wg);
-    hipLaunchKernelGGL(fused5_wx_for(a.n_tracks), dim3(n_wg), dim3(v.n_waves * 64), lds5_bytes(v, v.n_waves), ctx->stream, v);
+    UGVC_LAUNCH(fused5_wx_for(a.n_tracks), dim3(n_wg), dim3(v.n_waves * 64), lds5_bytes(v, v.n_waves), ctx->stream, v);
     UGVC_HIP(hipGetLastError());
     return 0;
 }
@@ -2082,17 +2082,7 @@ int launch_filter_v5(ugvc_ctx* ctx, const FilterArgs& a) {
     V5Args v;
     if (v5_fill_args(ctx, v, a)) return -1;
     if (v5_warm(ctx)) return -1;
-    // UGVC_DEBUG_SYNC=1: name every launch on stderr and wait for it (a GPU memory fault aborts the process; the
-    // last name printed is the kernel that faulted)
-    static const bool dbg = getenv("UGVC_DEBUG_SYNC") != nullptr;
-    auto step = [&](const char* name) -> int {
-        if (!dbg) return 0;
-        fprintf(stderr, "[v5] %s done? ", name);
-        fflush(stderr);
-        UGVC_HIP(hipStreamSynchronize(ctx->stream));
-        fprintf(stderr, "ok\n");
-        return 0;
-    };
+    static const bool dbg = getenv("UGVC_DEBUG_SYNC") != nullptr;     // (UGVC_LAUNCH names every launch and waits for it)
     // UGVC_WAVE_CLK=<file>: every wave of the fused kernel leaves its entry / first-tile / end clocks and its tile counts; the
     // buffer of the LAST pass is written to the file (tools/wave_clk.py reads it).  Waits for every pass: profiling only.
     static const char* wclk_path = getenv("UGVC_WAVE_CLK");
@@ -2106,8 +2096,7 @@ int launch_filter_v5(ugvc_ctx* ctx, const FilterArgs& a) {
     const size_t lds_f = lds5_bytes(v, v.n_waves);
     if (dbg) fprintf(stderr, "[ugvc v5] fused5: %d waves (%d indel), %zu B of LDS\n", v.n_waves, v.n_indel_waves, lds_f);
     const unsigned n_wg = (unsigned)((a.n + v.rows_wg - 1) / v.rows_wg);
-    hipLaunchKernelGGL(fused5_for(a.n_tracks, (a.ablate & (1 << 28)) != 0), dim3(n_wg), dim3(v.n_waves * 64), lds_f, ctx->stream, v);
-    if (step("fused5")) return -1;
+    UGVC_LAUNCH(fused5_for(a.n_tracks, (a.ablate & (1 << 28)) != 0), dim3(n_wg), dim3(v.n_waves * 64), lds_f, ctx->stream, v);
     if (wclk_path) {
         std::vector<unsigned long long> h(wclk_bytes / 8);
         UGVC_HIP(hipMemcpyAsync(h.data(), wclk_buf.p, wclk_bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -2127,8 +2116,7 @@ int launch_filter_v5(ugvc_ctx* ctx, const FilterArgs& a) {
         }
         if (n_waves == 0) return fail("internal: packed forest does not fit LDS");
         v.forest_lds_tail = (int)lds;
-        hipLaunchKernelGGL(forest5_kernel, dim3((unsigned)ctx->n_cus), dim3(n_waves * 64), lds + 1088, ctx->stream, v);
-        if (step("forest5")) return -1;
+        UGVC_LAUNCH(forest5_kernel, dim3((unsigned)ctx->n_cus), dim3(n_waves * 64), lds + 1088, ctx->stream, v);
     }
     UGVC_HIP(hipGetLastError());
     return 0;

@@ -70,18 +70,18 @@ void v2_destroy(ugvc_ctx* ctx) {
     V2State* s = static_cast<V2State*>(ctx->v2);
     DeviceBuf* bufs[] = {&s->desc, &s->desc3, &s->lut, &s->thr, &s->css, &s->brackets, &s->brackets3, &s->counters, &s->prof,
                          &s->snp_idx, &s->indel_idx, &s->counters5, &s->eyt, &s->gcr};
-    for (auto* b : bufs) if (b->p) (void)hipFree(b->p);
-    for (auto& r : s->rec) if (r.p) (void)hipFree(r.p);
-    for (auto& r : s->rec5) if (r.p) (void)hipFree(r.p);
+    for (auto* b : bufs) if (b->p) dev_free(b->p);
+    for (auto& r : s->rec) if (r.p) dev_free(r.p);
+    for (auto& r : s->rec5) if (r.p) dev_free(r.p);
     for (auto& g : s->g)
-        for (DeviceBuf* b : {&g.d_nodes, &g.d_leaf_idx, &g.d_pairs, &g.d_leaf_f32, &g.d_plane_desc, &g.d_hi4, &g.d_last4, &g.d_p1, &g.d_hi5, &g.d_last5, &g.d_roots5}) if (b->p) (void)hipFree(b->p);
+        for (DeviceBuf* b : {&g.d_nodes, &g.d_leaf_idx, &g.d_pairs, &g.d_leaf_f32, &g.d_plane_desc, &g.d_hi4, &g.d_last4, &g.d_p1, &g.d_hi5, &g.d_last5, &g.d_roots5}) if (b->p) dev_free(b->p);
     delete s;
     ctx->v2 = nullptr;
 }
 
 static void release_group(V2Group& g) {          // device tables of the previous model of this group, then a clean slate
     for (DeviceBuf* b : {&g.d_nodes, &g.d_leaf_idx, &g.d_pairs, &g.d_leaf_f32, &g.d_plane_desc, &g.d_hi4, &g.d_last4, &g.d_p1, &g.d_hi5, &g.d_last5, &g.d_roots5})
-        if (b->p) (void)hipFree(b->p);
+        if (b->p) dev_free(b->p);
     g = V2Group();
 }
 

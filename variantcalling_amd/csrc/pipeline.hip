@@ -103,7 +103,7 @@ void pipe_destroy(ugvc_ctx* ctx) {
     for (void* q : {p->stage[0], p->stage[1], p->stage[2], p->res, p->alle})
         if (q) (void)hipHostFree(q);
     for (DeviceBuf* b : {&p->d_stage[0], &p->d_stage[1], &p->d_stage[2], &p->d_res, &p->d_sums[0], &p->d_sums[1], &p->d_sums[2]})
-        if (b->p) (void)hipFree(b->p);
+        if (b->p) dev_free(b->p);
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     if (p->ev_t0) (void)hipEventDestroy(p->ev_t0);
     if (p->h2d) (void)hipStreamDestroy(p->h2d);
@@ -465,8 +465,8 @@ int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_
             uint32_t* sums = ps->d_sums[slot].as<uint32_t>();
             const uint16_t* rl_d = reinterpret_cast<const uint16_t*>(dst + off[2]);
             const uint16_t* al_d = reinterpret_cast<const uint16_t*>(dst + off[3]);
-            hipLaunchKernelGGL(pipe_offsets_sum_kernel, dim3(nb), dim3(256), 0, ctx->stream, rl_d, al_d, m, sums);
-            hipLaunchKernelGGL(pipe_offsets_fill_kernel, dim3(nb), dim3(256), 0, ctx->stream, rl_d, al_d, m, v->ref_off[a], (const uint32_t*)sums,
+            UGVC_LAUNCH(pipe_offsets_sum_kernel, dim3(nb), dim3(256), 0, ctx->stream, rl_d, al_d, m, sums);
+            UGVC_LAUNCH(pipe_offsets_fill_kernel, dim3(nb), dim3(256), 0, ctx->stream, rl_d, al_d, m, v->ref_off[a], (const uint32_t*)sums,
                                reinterpret_cast<uint32_t*>(dst + off[kColRo]), reinterpret_cast<uint32_t*>(dst + off[kColAo]));
             UGVC_HIP(hipGetLastError());
         }
@@ -506,7 +506,7 @@ int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_
             t.s[NC] = Seg{dr + o[0], reinterpret_cast<uint8_t*>(ctx->r_score.as<float>() + a), (uint64_t)m * 4};
             t.s[NC + 1] = Seg{dr + o[1], ctx->r_filter.as<uint8_t>() + a, (uint64_t)m};
             t.s[NC + 2] = Seg{dr + o[2], ctx->r_flags.as<uint8_t>() + a, (uint64_t)m};
-            hipLaunchKernelGGL(pipe_place_kernel, dim3(64, NC + 3), dim3(256), 0, ctx->stream, t);
+            UGVC_LAUNCH(pipe_place_kernel, dim3(64, NC + 3), dim3(256), 0, ctx->stream, t);
             UGVC_HIP(hipGetLastError());
             UGVC_HIP(hipEventRecord(ev_placed(c), ctx->stream));
         }

@@ -150,6 +150,10 @@ struct ugvc_ctx {
 namespace ugvc {
 void set_error(const std::string& msg);
 int fail(const std::string& msg);
+int dev_alloc(void** out, size_t bytes);          // devmem.hip: hipMalloc, or the guarded / poisoned debug mappings (UGVC_GUARD, UGVC_POISON)
+void dev_free(void* p);
+void launch_note(const char* name);               // breadcrumb ring (+ name on stderr under UGVC_DEBUG_SYNC)
+void launch_done(const char* name, hipStream_t stream);
 int ensure(DeviceBuf& b, size_t bytes);
 int upload(ugvc_ctx* ctx, DeviceBuf& b, const void* src, size_t bytes);
 int build_args(ugvc_ctx* ctx, FilterArgs& a, bool want_x);
@@ -164,4 +168,13 @@ int launch_sec(ugvc_ctx* ctx, const int32_t* d_actual, const int32_t* d_expected
         hipError_t _e = (expr);                                                            \
         if (_e != hipSuccess)                                                              \
             return ugvc::fail(std::string(#expr) + ": " + hipGetErrorString(_e));          \
+    } while (0)
+
+// Every kernel launch of the library: the name goes to the breadcrumb ring (devmem.hip); UGVC_DEBUG_SYNC=1 names the launch on
+// stderr and waits for it, so that the last name printed before a GPU memory fault is the kernel that faulted.
+#define UGVC_LAUNCH(kern, grid, block, lds, stream, ...)                            \
+    do {                                                                            \
+        ugvc::launch_note(#kern);                                                   \
+        hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);            \
+        ugvc::launch_done(#kern, stream);                                           \
     } while (0)

@@ -53,6 +53,7 @@ ABI = {
     "ugvc_device_attr": (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_int64)]),
     "ugvc_reserve": (C.c_int, [_ctx, C.c_int64, C.c_int64]),
     "ugvc_sync": (C.c_int, [_ctx]),
+    "ugvc_selftest": (C.c_int, [_ctx, C.c_int64]),
     "ugvc_ref_upload": (C.c_int, [_ctx, _u8p, C.c_int64, _i64p, C.c_int]),
     "ugvc_runs_upload": (C.c_int, [_ctx, _i32p, _i32p, _i32p, C.c_int64, C.c_int, C.c_int, C.c_int]),
     "ugvc_track_upload": (C.c_int, [_ctx, C.c_int, _i32p, _i32p, _i32p, C.c_int64]),
@@ -178,6 +179,11 @@ class Engine:
         out = C.c_int64()
         self._check(self.lib.ugvc_device_attr(self._h, ("clock_khz", "n_cus", "mem_clock_khz", "lds_bytes").index(what), C.byref(out)))
         return int(out.value)
+
+    def selftest(self, n: int = 1024) -> None:
+        """Device canary: copy round trip + the library's prefix-sum kernel over n words, checked on the host.  Raises with
+        the failing step's name when the GPU cannot be used at all (a dead box is not a kernel bug)."""
+        self._check(self.lib.ugvc_selftest(self._h, n))
 
     def sync(self):
         self._check(self.lib.ugvc_sync(self._h))
