@@ -17,9 +17,9 @@ per_file() {   # per_file <log> <env...>
     for f in tests/test_*.py; do
         grep -q "mark.gpu" $f || continue
         echo "---- $f" >> $log
-        env "$@" timeout 900 python -m pytest $f -q -m gpu -p no:cacheprovider >> $log 2>&1
+        env "$@" timeout 420 python -m pytest $f -q -s -m gpu -p no:cacheprovider >> $log 2>&1
         rc=$?
-        line=$(grep -E "passed|failed|error|no tests ran" $log | tail -1)
+        line=$(grep -E "passed|failed|no tests ran|Memory access fault" $log | tail -1 | cut -c1-160)
         echo "rc=$rc $f :: $line" >> $sum
         [ $rc -ne 0 ] && [ $rc -ne 5 ] && bad=$((bad+1))
         total=$((total+1))

@@ -72,6 +72,8 @@ int guard_alloc(void** out, size_t bytes, int mode, int poison) {
     size_t gran = 0;
     UGVC_HIP(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum));
     if (gran == 0) return fail("UGVC_GUARD: the device reports no virtual-memory allocation granularity");
+    static bool said = false;
+    if (!said && getenv("UGVC_DEBUG_SYNC")) { said = true; fprintf(stderr, "[ugvc] guard allocations: granularity %zu bytes\n", gran); }
     const size_t fence = round_up(kFence, gran);
     const size_t align = (size_t)std::max(1, env_int("UGVC_GUARD_ALIGN", 16));
     const size_t used = round_up(bytes, align);
@@ -154,7 +156,11 @@ void dev_free(void* p) {
     (void)hipDeviceSynchronize();
     (void)hipMemUnmap(r.map, r.map_size);
     (void)hipMemRelease(r.handle);
-    (void)hipMemAddressFree(r.va, r.va_size);
+    // The address range is NOT given back (hipMemAddressFree): a later reservation that lands on the same addresses sees the
+    // old translations on this stack (measured, profiles/r05_guard_va_reuse.txt: a prefix sum over a freshly uploaded buffer
+    // returns the previous mapping's bytes; with the ranges kept the same suite is green).  A freed buffer therefore stays
+    // unmapped for the life of the process - a use after free faults too.  48 bits of address space outlast any test run.
+    if (env_int("UGVC_GUARD_OPTS", 0) & 2) (void)hipMemAddressFree(r.va, r.va_size);
 }
 
 bool debug_sync() { return getenv("UGVC_DEBUG_SYNC") != nullptr; }
