@@ -34,6 +34,17 @@ for mode in "$@"; do
         echo "fresh smoke rc=$?" >> $sum
         timeout 1500 python -m pytest tests/ -x -q -m gpu -p no:cacheprovider >> $log 2>&1
         echo "fresh pytest rc=$? :: $(grep -E 'passed|failed' $log | tail -1)" >> $sum ;;
+    quick)   # one lease's short form of the driver's sequence: smoke FIRST, then the canary and the small GPU tests
+        timeout 600 python -c 'import __graft_entry__ as e; e.smoke(); print("__SMOKE_OK__")' >> $log 2>&1
+        echo "quick smoke (first GPU process of the lease) rc=$?" >> $sum
+        timeout 900 python -m pytest tests/test_00_gpu_canary.py tests/test_annotate.py tests/test_gpu_fuzz.py tests/test_gpu_sec.py tests/test_gpu_eval.py tests/test_gpu_pipelines.py -x -q -m gpu -p no:cacheprovider >> $log 2>&1
+        echo "quick pytest rc=$? :: $(grep -E 'passed|failed' $log | tail -1)" >> $sum ;;
+    ldsrand) # the small GPU tests with other kinds of LDS garbage in front of every launch: zeros, ones, small and wide random words
+        for pat in 00000000 00000001 r2 r8 r32; do
+            echo "---- UGVC_POISON_LDS=$pat" >> $log
+            UGVC_POISON=1 UGVC_POISON_LDS=$pat timeout 900 python -m pytest tests/test_00_gpu_canary.py tests/test_annotate.py tests/test_gpu_fuzz.py tests/test_gpu_sec.py tests/test_gpu_eval.py tests/test_gpu_pipelines.py -q -s -m gpu -p no:cacheprovider >> $log 2>&1
+            echo "ldsrand $pat rc=$? :: $(grep -E 'passed|failed|Memory access fault' $log | tail -1 | cut -c1-160)" >> $sum
+        done ;;
     guard1) per_file $log UGVC_GUARD=1 UGVC_POISON=1 UGVC_DEBUG_SYNC=1 ;;
     guard2) per_file $log UGVC_GUARD=2 UGVC_POISON=2 UGVC_DEBUG_SYNC=1 ;;
     poison) per_file $log UGVC_POISON=1 ;;

@@ -251,6 +251,17 @@ int ugvc_selftest(ugvc_ctx* ctx, int64_t n) {
     } while (0);
     dev_free(d.p);
     dev_free(tmp.p);
+    // under UGVC_POISON the harness itself is checked: a kernel that reads LDS it never wrote must see the pattern on every CU
+    const char* pm = getenv("UGVC_POISON");
+    const char* pl = getenv("UGVC_POISON_LDS");
+    if (!rc && pm && atoi(pm) > 0 && !(pl && pl[0] == 'r')) {
+        const uint32_t want = pl ? (uint32_t)strtoul(pl, nullptr, 16) : atoi(pm) == 2 ? 0xFFFFFFFFu : 0xA5A5A5A5u;
+        const int n_wg = ctx->n_cus * 4;
+        std::vector<uint32_t> w((size_t)n_wg * 8);
+        if (lds_probe(ctx, w.data(), n_wg)) return -1;
+        for (size_t q = 0; q < w.size(); ++q)
+            if (w[q] != want) return fail("selftest: LDS poison did not reach workgroup " + std::to_string(q / 8) + " (the debug harness is not covering every CU)");
+    }
     return rc;
 }
 

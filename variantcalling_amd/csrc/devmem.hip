@@ -9,7 +9,11 @@
 //                 of whatever the allocator put next.  UGVC_GUARD=2 puts the unmapped range in FRONT of the first byte.
 //   UGVC_POISON=1 every new buffer (and, with UGVC_GUARD, the slack of its mapping) is filled with 0xA5 before first use
 //                 (UGVC_POISON=2: 0xFF): a kernel that reads a list entry, a counter or a pad it never wrote computes
-//                 on garbage that no box hands out by accident.
+//                 on garbage that no box hands out by accident.  The same mode fills the LDS of EVERY compute unit with the
+//                 pattern in front of every kernel launch (lds_poison_kernel: one 160 KB workgroup per CU, several rounds):
+//                 LDS is not cleared between kernels or between processes, so a kernel that reads a word of LDS it did not
+//                 write sees whatever the box's previous tenant left there - on the developer's box usually the same
+//                 kernel's own data from the launch before, i.e. the right answer.
 //
 // Launch breadcrumbs: UGVC_LAUNCH() records the name of every kernel it launches in a small ring; with UGVC_BREADCRUMB=1 a
 // SIGABRT handler (the HSA runtime aborts the process on a GPU memory fault) prints the ring before the process dies, and
@@ -104,6 +108,70 @@ int guard_alloc(void** out, size_t bytes, int mode, int poison) {
     return 0;
 }
 
+// ---- LDS poison ----------------------------------------------------------------------------------------------------
+constexpr int kLdsAll = 160 * 1024;
+
+// pat: the word every LDS dword gets; rand_bits > 0: dword q gets a hash of q cut to that many bits instead (small integers are
+// a different kind of garbage than 0xA5A5A5A5: they pass for ranks, contig numbers, "ready" words)
+__global__ __launch_bounds__(1024) void lds_poison_kernel(uint32_t pat, int rand_bits, uint32_t* sink) {
+    extern __shared__ uint32_t lds_all[];
+    volatile uint32_t* l = lds_all;
+    for (int q = threadIdx.x; q < kLdsAll / 4; q += 1024) {
+        uint32_t h = (uint32_t)q * 2654435761u + pat;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        l[q] = rand_bits > 0 ? (h >> (32 - rand_bits)) : pat;
+    }
+    __syncthreads();
+    // (keep the workgroup on its CU for a moment, so that the dispatcher hands the next ones to the other CUs, and keep
+    // the stores observable)
+    uint32_t acc = 0;
+    for (int r = 0; r < 8; ++r) acc += l[(threadIdx.x * 37 + r * 1031) % (kLdsAll / 4)];
+    if (acc == 0x12345u && sink) sink[0] = acc;
+}
+
+int lds_poison(hipStream_t stream, int mode) {
+    static std::atomic<int> n_cus{0};
+    if (n_cus.load() == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        UGVC_HIP(hipGetDevice(&dev));
+        UGVC_HIP(hipGetDeviceProperties(&prop, dev));
+        UGVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lds_poison_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsAll));
+        n_cus.store(prop.multiProcessorCount);
+    }
+    // UGVC_POISON_LDS: a pattern of the caller's choice (hex), or "r<bits>": pseudo-random values of that many bits per dword
+    const char* e = getenv("UGVC_POISON_LDS");
+    const int rand_bits = e && e[0] == 'r' ? std::min(std::max(atoi(e + 1), 1), 32) : 0;
+    static std::atomic<uint32_t> salt{0};
+    const uint32_t pat = rand_bits ? salt.fetch_add(1) : e ? (uint32_t)strtoul(e, nullptr, 16) : mode == 2 ? 0xFFFFFFFFu : 0xA5A5A5A5u;
+    hipLaunchKernelGGL(lds_poison_kernel, dim3((unsigned)n_cus.load() * 4), dim3(1024), kLdsAll, stream, pat, rand_bits, (uint32_t*)nullptr);
+    UGVC_HIP(hipGetLastError());
+    return 0;
+}
+
+// What a kernel that reads LDS it never wrote would see: every workgroup reports a few words of its (unwritten) dynamic LDS.
+__global__ __launch_bounds__(1024) void lds_probe_kernel(uint32_t* out) {
+    extern __shared__ uint32_t lds_all[];
+    volatile uint32_t* l = lds_all;
+    if (threadIdx.x < 8) out[blockIdx.x * 8 + threadIdx.x] = l[(threadIdx.x * 5119 + 7) % (kLdsAll / 4)];
+}
+
+int lds_probe(ugvc_ctx* ctx, uint32_t* host_out, int n_wg) {
+    static std::atomic<bool> attr{false};
+    if (!attr.load()) {
+        UGVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lds_probe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsAll));
+        attr.store(true);
+    }
+    DeviceBuf d;
+    if (ensure(d, (size_t)n_wg * 8 * 4)) return -1;
+    UGVC_LAUNCH(lds_probe_kernel, dim3((unsigned)n_wg), dim3(1024), kLdsAll, ctx->stream, d.as<uint32_t>());
+    int rc = 0;
+    if (hipMemcpyAsync(host_out, d.p, (size_t)n_wg * 8 * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail("lds_probe: device error");
+    dev_free(d.p);
+    return rc;
+}
+
 // ---- launch breadcrumbs --------------------------------------------------------------------------------------------
 constexpr int kRing = 8;
 const char* volatile g_ring[kRing];
@@ -150,6 +218,9 @@ void dev_free(void* p) {
         }
     }
     if (!guarded) {
+        // (hipFree is documented to wait for the device; the context's stream is a non-blocking one and a buffer may be re-sized
+        // between two passes - the wait is made explicit: frees happen at configuration time, never inside a pass)
+        (void)hipDeviceSynchronize();
         (void)hipFree(p);
         return;
     }
@@ -165,7 +236,8 @@ void dev_free(void* p) {
 
 bool debug_sync() { return getenv("UGVC_DEBUG_SYNC") != nullptr; }
 
-void launch_note(const char* name) {
+void launch_note(const char* name, hipStream_t stream) {
+    if (const int pm = poison_mode()) (void)lds_poison(stream, pm);
     if (g_handler.load() == 0) {
         int expect = 0;
         if (g_handler.compare_exchange_strong(expect, 1) && getenv("UGVC_BREADCRUMB")) signal(SIGABRT, on_abort);

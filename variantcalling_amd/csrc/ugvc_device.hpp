@@ -152,8 +152,9 @@ void set_error(const std::string& msg);
 int fail(const std::string& msg);
 int dev_alloc(void** out, size_t bytes);          // devmem.hip: hipMalloc, or the guarded / poisoned debug mappings (UGVC_GUARD, UGVC_POISON)
 void dev_free(void* p);
-void launch_note(const char* name);               // breadcrumb ring (+ name on stderr under UGVC_DEBUG_SYNC)
+void launch_note(const char* name, hipStream_t stream);   // breadcrumb ring (+ name on stderr under UGVC_DEBUG_SYNC; LDS poison under UGVC_POISON)
 void launch_done(const char* name, hipStream_t stream);
+int lds_probe(ugvc_ctx* ctx, uint32_t* host_out, int n_wg);   // devmem.hip: 8 words of unwritten LDS per workgroup
 int ensure(DeviceBuf& b, size_t bytes);
 int upload(ugvc_ctx* ctx, DeviceBuf& b, const void* src, size_t bytes);
 int build_args(ugvc_ctx* ctx, FilterArgs& a, bool want_x);
@@ -174,7 +175,7 @@ int launch_sec(ugvc_ctx* ctx, const int32_t* d_actual, const int32_t* d_expected
 // stderr and waits for it, so that the last name printed before a GPU memory fault is the kernel that faulted.
 #define UGVC_LAUNCH(kern, grid, block, lds, stream, ...)                            \
     do {                                                                            \
-        ugvc::launch_note(#kern);                                                   \
+        ugvc::launch_note(#kern, stream);                                                 \
         hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);            \
         ugvc::launch_done(#kern, stream);                                           \
     } while (0)
