@@ -156,6 +156,8 @@ __global__ __launch_bounds__(1024) void lds_probe_kernel(uint32_t* out) {
     if (threadIdx.x < 8) out[blockIdx.x * 8 + threadIdx.x] = l[(threadIdx.x * 5119 + 7) % (kLdsAll / 4)];
 }
 
+}  // namespace
+
 int lds_probe(ugvc_ctx* ctx, uint32_t* host_out, int n_wg) {
     static std::atomic<bool> attr{false};
     if (!attr.load()) {
@@ -171,6 +173,8 @@ int lds_probe(ugvc_ctx* ctx, uint32_t* host_out, int n_wg) {
     dev_free(d.p);
     return rc;
 }
+
+namespace {
 
 // ---- launch breadcrumbs --------------------------------------------------------------------------------------------
 constexpr int kRing = 8;
