@@ -158,8 +158,14 @@ int ugvc_filter_variants(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_resul
  *   events, the worker pool) and the first use of the kernels' code object, without touching a row.  Optional: a tool that
  *   knows its callset's size early calls it from a helper thread beside its other set-up (reference / table / model uploads
  *   on another thread are fine; a pass is not) - the first ugvc_filter_variants over 5 M rows spends 44 of its 49 ms there.
+ *   A callset that is resident survives the call only if no resident column has to grow for the reserved size; otherwise
+ *   the context is left EMPTY (n = 0: ugvc_filter_resident / ugvc_results_download / ugvc_sec_apply see no rows).
  *   Replaces nothing in the reference (its loops allocate as they go: ugvc/pipelines/vcfbed/calibrate_bridging_snvs.py:101-130). */
 int ugvc_reserve(ugvc_ctx* ctx, int64_t n_variants, int64_t alleles_len);
+/* What is resident: the row count of the callset ugvc_filter_resident / ugvc_results_download / ugvc_sec_apply would work on
+ * (0 after any failed upload and after a reservation that had to re-allocate a resident column) and whether the result columns
+ * hold a scoring pass over it.  Either pointer may be NULL.  (Builder-defined; the reference keeps its callset in a DataFrame.) */
+int ugvc_resident_count(ugvc_ctx* ctx, int64_t* n_variants, int* scored);
 int ugvc_variants_upload(ugvc_ctx* ctx, const ugvc_variants* v);
 int ugvc_filter_resident(ugvc_ctx* ctx);
 int ugvc_results_download(ugvc_ctx* ctx, const ugvc_results* out);

@@ -380,6 +380,19 @@ def test_reserve_changes_nothing_but_the_first_calls_allocations(frozen_models):
                 cs.variants.slice(0, 5000), cs.ref, cs.runs, cs.tracks, cs.blacklist, forests), "small callset after reserve")
             with pytest.raises(RuntimeError, match="reserve"):
                 eng.reserve(-1, 0)
+            # a reservation that fits what is resident leaves it alone; one that must grow a resident column empties the
+            # context instead of leaving the old row count beside fresh, uninitialised columns
+            res = eng.filter_variants(cs.variants)
+            assert eng.resident_count() == (cs.variants.n, True)
+            eng.reserve(cs.variants.n, int(cs.variants.alleles.size))
+            assert eng.resident_count() == (cs.variants.n, True)
+            _assert_same(eng.download_results(), res, "resident results after a reservation that fits")
+            eng.reserve(4 * cs.variants.n, 4 * int(cs.variants.alleles.size))
+            assert eng.resident_count() == (0, False) and eng.download_results().filter.size == 0
+            eng.set_sec_db(np.array([5], np.uint64), np.ones((1, 3), np.int32))
+            ratio, hit = eng.sec_apply()                              # (no rows: nothing to apply the database to)
+            assert ratio.size == 0 and hit.size == 0
+            _assert_same(eng.filter_variants(cs.variants), exp, "after an emptying reservation")
 
 
 def test_chunk_pipeline_boundary(engine, frozen_models):

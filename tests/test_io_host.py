@@ -61,6 +61,17 @@ def test_bed_merge_and_interval_list(tmp_path):
     assert np.array_equal(again.starts, tr.starts) and np.array_equal(again.ends, tr.ends)
 
 
+
+def test_track_from_arrays_unsorted_unsigned_contigs():
+    """a decreasing contig column of an UNSIGNED dtype must not pass the sortedness shortcut (differences wrap)"""
+    from variantcalling_amd.io import bed
+    contig = np.array([1, 1, 0, 0], np.uint16)
+    starts, ends = np.array([10, 50, 5, 30]), np.array([20, 60, 9, 40])
+    tr = bed.track_from_arrays(contig, starts, ends, 2, merge=False)
+    ref = bed.track_from_arrays(contig.astype(np.int64), starts, ends, 2, merge=False)
+    assert tr.starts.tolist() == ref.starts.tolist() == [5, 30, 10, 50] and tr.contig_ptr.tolist() == [0, 2, 4]
+    assert tr.ends.tolist() == [9, 40, 20, 60]
+
 def test_blacklist_formats(tmp_path):
     names = ["chr1", "chr2"]
     want = np.array([(0 << 32) | 5, (0 << 32) | 9, (1 << 32) | 7], dtype=np.uint64)

@@ -262,6 +262,11 @@ def test_unrelated_value_error_keeps_its_message(tmp_path):
         legacy_pickle.load(raw)
     assert legacy_pickle.is_tree_state_mismatch(ValueError("node array from the pickle has an incompatible dtype:\n- expected: x"))
     assert not legacy_pickle.is_tree_state_mismatch(ValueError("invalid literal for int() with base 10: 'x'"))
+    # older scikit-learn generations and cross-platform pickles raise other texts from the same Tree.__setstate__
+    assert legacy_pickle.is_tree_state_mismatch(ValueError("Did not recognise loaded array layout"))
+    assert legacy_pickle.is_tree_state_mismatch(ValueError("Did not recognise loaded array dimensions"))
+    assert legacy_pickle.is_tree_state_mismatch(ValueError("Buffer dtype mismatch, expected 'SIZE_t' but got 'long long'"))
+    assert not legacy_pickle.is_tree_state_mismatch(TypeError("Buffer dtype mismatch, expected 'SIZE_t' but got 'long long'"))
 
 
 def test_model_file_maps_annotation_columns_by_bed_stem(tmp_path):

@@ -485,6 +485,10 @@ int ugvc_variants_upload(ugvc_ctx* ctx, const ugvc_variants* v) {
     int64_t n_indel = 0, bad = -1;                             // (n_indel sizes the indel tiles' table slices: model_pack.hip)
     if (const int what = validate_rows(v, 0, (int64_t)n, ctx->n_contigs, &n_indel, &bad))
         return fail(std::string(row_error_text(what)) + std::to_string(bad));
+    // from here on the resident columns change: on any error below the context is EMPTY, not the previous callset's row
+    // count beside re-allocated columns
+    UGVC_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->n = 0; ctx->n_indel = 0; ctx->scored = 0; ctx->density_n = 0;
     if (upload(ctx, ctx->v_contig, v->contig, n * 2)) return -1;
     if (upload(ctx, ctx->v_pos, v->pos, n * 4)) return -1;
     if (upload(ctx, ctx->v_rl, v->ref_len, n * 2)) return -1;
@@ -548,7 +552,8 @@ int ugvc_filter_variants(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_resul
 
 int ugvc_reserve(ugvc_ctx* ctx, int64_t n_variants, int64_t alleles_len) {
     // Everything ugvc_filter_variants allocates once per size - resident columns, pinned staging slots, streams, events, the
-    // worker pool - and the first use of the kernels' code object, without touching a row: a tool calls it from a helper
+    // worker pool - and the first use of the kernels' code object, without touching a row of the CALLER's: a resident callset
+    // survives only if no resident column has to grow (else the context is left empty - filter_variants_pipelined).  A tool calls it from a helper
     // thread as soon as it knows the callset's size, beside its other set-up work (the first pass over 5 M rows spent 44 of
     // its 49 ms there).  Safe beside uploads of the reference / tables / model on another thread; not beside a pass.
     if (!ctx) return fail("ctx is NULL");
@@ -564,6 +569,13 @@ int ugvc_reserve(ugvc_ctx* ctx, int64_t n_variants, int64_t alleles_len) {
     v.n = n_variants;
     v.alleles_len = alleles_len;
     return filter_variants_pipelined(ctx, &v, nullptr, chunks, true);
+}
+
+int ugvc_resident_count(ugvc_ctx* ctx, int64_t* n_variants, int* scored) {
+    if (!ctx) return fail("ctx is NULL");
+    if (n_variants) *n_variants = ctx->n;
+    if (scored) *scored = ctx->scored;
+    return 0;
 }
 
 int ugvc_timed_filter(ugvc_ctx* ctx, int iters, float* ms_total) {

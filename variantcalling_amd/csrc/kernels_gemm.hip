@@ -13,6 +13,8 @@
 // traversal kernel and to the oracle.  C is the same for every tree (heap-ordered complete trees), so
 // the B operand lives in 16 VGPRs for the whole kernel.  The GEMM does 2*64*64 = 8192 int-ops per tree and
 // variant against 6 node visits for the traversal: it is reported beside it, not instead of it.
+#include <atomic>
+#include <string.h>
 #include "ugvc_v2.hpp"
 
 namespace ugvc {
@@ -332,7 +334,40 @@ extern "C" int ugvc_forest_gemm(ugvc_ctx* ctx, int group, const int32_t* rows, i
                    T, kind, base, dout.as<float>()};
         const size_t lds_tables = (size_t)T * 64 * 12;
         // use_mfma: 1 = the round-4 kernel (register-indexed predicates, transposed product), 2 = the round-1 kernel (LDS gathers)
-        const bool v2 = use_mfma == 1 && !(ctx->kernel_variant & 512);
+        bool v2 = use_mfma == 1 && !(ctx->kernel_variant & 512);
+        // forest_gemm2_kernel reads its predicates' operands through VGPR index mode and relies on where the compiler put the row's
+        // 32 feature registers (UGVC_PRED_ASM: checked in the listing of THIS build, not guaranteed by the compiler).  First use per
+        // process: the margins of up to 512 rows against the scalar kernel's, bit for bit; on a mismatch the round-1 MFMA kernel
+        // (LDS gathers, no register indexing) serves every later call and stderr says so once.
+        static std::atomic<int> gemm2_state{0};                  // 0 unchecked, 1 agrees, 2 differs
+        if (v2 && gemm2_state.load() == 0 && lds_tables <= 156 * 1024) {
+            const int64_t m = std::min<int64_t>(n, 512);
+            DeviceBuf dchk;
+            std::vector<float> h((size_t)(2 * m));
+            const size_t lds2 = (size_t)T * 64 * 4 + (size_t)(kGemm2Threads / 64) * 64 * kGemm2RowB;
+            bool ran = ensure(dchk, (size_t)(2 * m) * 4) == 0 &&
+                       hipFuncSetAttribute(reinterpret_cast<const void*>(forest_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) == hipSuccess &&
+                       hipFuncSetAttribute(kind == UGVC_MODEL_RF ? reinterpret_cast<const void*>(forest_gemm2_kernel<true>) : reinterpret_cast<const void*>(forest_gemm2_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) == hipSuccess;
+            if (ran) {
+                GemmArgs ga = g, gb = g;
+                ga.n = gb.n = m;
+                ga.out = dchk.as<float>();
+                gb.out = dchk.as<float>() + m;
+                UGVC_LAUNCH(forest_rows_kernel, dim3((unsigned)ctx->n_cus * 4), dim3(256), lds_tables, ctx->stream, ga);
+                if (kind == UGVC_MODEL_RF) UGVC_LAUNCH(forest_gemm2_kernel<true>, dim3((unsigned)ctx->n_cus * 2), dim3(kGemm2Threads), lds2, ctx->stream, gb);
+                else UGVC_LAUNCH(forest_gemm2_kernel<false>, dim3((unsigned)ctx->n_cus * 2), dim3(kGemm2Threads), lds2, ctx->stream, gb);
+                ran = hipMemcpyAsync(h.data(), dchk.p, (size_t)(2 * m) * 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                      hipStreamSynchronize(ctx->stream) == hipSuccess && hipGetLastError() == hipSuccess;
+            }
+            dev_free(dchk.p);
+            if (ran) {
+                const bool same = memcmp(h.data(), h.data() + m, (size_t)m * 4) == 0;
+                gemm2_state.store(same ? 1 : 2);
+                if (!same) fprintf(stderr, "[ugvc] forest_gemm2_kernel disagrees with the scalar kernel on this build: using forest_gemm_kernel\n");
+            }
+        }
+        if (gemm2_state.load() == 2) v2 = false;
         const size_t lds = !use_mfma ? lds_tables
                          : v2 ? (size_t)T * 64 * 4 + (size_t)(kGemm2Threads / 64) * 64 * kGemm2RowB
                               : lds_tables + (size_t)(kGemmThreads / 64) * 16 * kGemmXStride * 4;

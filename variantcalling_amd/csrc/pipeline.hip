@@ -260,6 +260,19 @@ int filter_variants_pipelined(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_
     const bool derive_offsets = dv_env ? atoi(dv_env) != 0 : true;
     size_t row_bytes = 0;
     for (const Col& c : cols) row_bytes += c.w;
+    {
+        // A resident column that must grow is freed and allocated afresh: whatever callset was resident is gone from that
+        // moment on, whether this call then succeeds, fails or was only a reservation (ugvc_reserve) - the context says so
+        // before the first buffer moves (a later ugvc_filter_resident / ugvc_results_download / ugvc_sec_apply
+        // used to find the old row count beside uninitialised columns).
+        bool grows = (size_t)v->alleles_len + 16 > ctx->v_alleles.cap || (size_t)n * 4 > ctx->r_score.cap || (size_t)n > ctx->r_filter.cap ||
+                     (size_t)n > ctx->r_flags.cap;
+        for (const Col& c : cols) grows |= (size_t)n * c.w > c.dst->cap;
+        if (grows && ctx->n > 0) {
+            UGVC_HIP(hipStreamSynchronize(ctx->stream));
+            ctx->n = 0; ctx->n_indel = 0; ctx->scored = 0; ctx->density_n = 0;
+        }
+    }
     for (const Col& c : cols)
         if (ensure(*c.dst, (size_t)n * c.w)) return -1;
     if (ensure(ctx->v_alleles, (size_t)v->alleles_len + 16)) return -1;

@@ -1059,8 +1059,15 @@ int ugvc_vcf_get_view(const ugvc_vcf* h, ugvc_vcf_view* v) {
     return 0;
 }
 
-int ugvc_vcf_write_filtered(const ugvc_vcf* h, const char* out_path, const float* tree_score, const uint8_t* filter,
-                            const uint8_t* flags, const uint8_t* cohort_extra, int64_t n, int n_threads, int write_index) {
+// (a std::thread that is still joinable when it is destroyed ends the process: the helper thread of the writer is joined on
+// every way out of its scope, an exception included - ADVICE r4)
+struct JoinedThread {
+    std::thread t;
+    ~JoinedThread() { if (t.joinable()) t.join(); }
+};
+
+static int write_filtered_impl(const ugvc_vcf* h, const char* out_path, const float* tree_score, const uint8_t* filter,
+                               const uint8_t* flags, const uint8_t* cohort_extra, int64_t n, int n_threads, int write_index, FILE*& fh) {
     if (!h || !out_path || !tree_score || !filter || !flags) return fail("NULL argument");
     if (n != h->n) return fail("result columns do not match the record count of the input");
     if (h->n != h->n_total) return fail("this handle holds one part of the file (ugvc_vcf_read_part): the write-back needs the whole file");
@@ -1068,7 +1075,7 @@ int ugvc_vcf_write_filtered(const ugvc_vcf* h, const char* out_path, const float
     const char* base = h->text.data();
     const size_t plen = strlen(out_path);
     const bool gz = plen >= 3 && strcmp(out_path + plen - 3, ".gz") == 0;
-    FILE* fh = fopen(out_path, "wb");
+    fh = fopen(out_path, "wb");
     if (!fh) return fail(std::string(out_path) + ": cannot open for writing");
 
     StageTimer st("write");
@@ -1203,7 +1210,8 @@ int ugvc_vcf_write_filtered(const ugvc_vcf* h, const char* out_path, const float
     // it is compressed.  (Round 4: format + gather were 0.17 s of the 5 M-record write-back's 0.45 s, in front of 0.26 s of deflate.)
     // (the per-thread text buffers and the two gather buffers live across the batches: fresh ones were ~90 MB of first-touch
     // page faults per batch, taken under the address-space lock that the compressing threads' allocations want too)
-    std::thread flusher;
+    JoinedThread flusher_guard;
+    std::thread& flusher = flusher_guard.t;
     std::vector<std::string> part;
     std::unique_ptr<char[]> gbuf[2];
     size_t gcap[2] = {0, 0};
@@ -1300,6 +1308,7 @@ int ugvc_vcf_write_filtered(const ugvc_vcf* h, const char* out_path, const float
     if (io_ok) (void)flush_blocks(stream.data(), stream.size(), true, true);
     if (io_ok && gz && fwrite(kEof, 1, 28, fh) != 28) io_ok = false;
     if (fclose(fh) != 0) io_ok = false;
+    fh = nullptr;
     if (!io_ok) return fail(std::string(out_path) + ": write failed");
     st.lap("tail + close");
     if (gz && write_index) {
@@ -1308,6 +1317,22 @@ int ugvc_vcf_write_filtered(const ugvc_vcf* h, const char* out_path, const float
         return rc;
     }
     return 0;
+}
+
+int ugvc_vcf_write_filtered(const ugvc_vcf* h, const char* out_path, const float* tree_score, const uint8_t* filter,
+                            const uint8_t* flags, const uint8_t* cohort_extra, int64_t n, int n_threads, int write_index) {
+    // nothing thrown inside (an allocation of a batch buffer, a thread that cannot start) crosses the C boundary
+    FILE* fh = nullptr;
+    int rc;
+    try {
+        rc = write_filtered_impl(h, out_path, tree_score, filter, flags, cohort_extra, n, n_threads, write_index, fh);
+    } catch (const std::exception& e) {
+        rc = fail(std::string("write-back failed: ") + e.what());
+    } catch (...) {
+        rc = fail("write-back failed: unknown exception");
+    }
+    if (fh) (void)fclose(fh);                                    // (left open by an error or an exception)
+    return rc;
 }
 
 }  // extern "C"

@@ -53,6 +53,7 @@ ABI = {
     "ugvc_device_attr": (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_int64)]),
     "ugvc_reserve": (C.c_int, [_ctx, C.c_int64, C.c_int64]),
     "ugvc_sync": (C.c_int, [_ctx]),
+    "ugvc_resident_count": (C.c_int, [_ctx, _i64p, C.POINTER(C.c_int)]),
     "ugvc_selftest": (C.c_int, [_ctx, C.c_int64]),
     "ugvc_ref_upload": (C.c_int, [_ctx, _u8p, C.c_int64, _i64p, C.c_int]),
     "ugvc_runs_upload": (C.c_int, [_ctx, _i32p, _i32p, _i32p, C.c_int64, C.c_int, C.c_int, C.c_int]),
@@ -144,6 +145,7 @@ class Engine:
         self._check(self.lib.ugvc_ctx_create(device, C.byref(h)))
         self._h = h
         self.n_tracks = 0
+        self.n = 0
         self._keep = []   # host arrays that must outlive async calls
 
     def _check(self, rc: int):
@@ -253,6 +255,13 @@ class Engine:
         """Allocate what `filter_variants` allocates once per callset size, and load the kernels, without touching data
         (a tool calls it from a helper thread while it reads / uploads its other inputs)."""
         self._check(self.lib.ugvc_reserve(self._h, int(n_variants), int(alleles_len)))
+        self.n = self.resident_count()[0]           # (a reservation that re-allocates a resident column empties the context)
+
+    def resident_count(self):
+        """(rows resident, whether the resident result columns hold a scoring pass over them)."""
+        n, sc = C.c_int64(), C.c_int()
+        self._check(self.lib.ugvc_resident_count(self._h, C.byref(n), C.byref(sc)))
+        return int(n.value), bool(sc.value)
 
     def set_kernel_variant(self, v: int):
         self._check(self.lib.ugvc_set_kernel_variant(self._h, v))

@@ -26,8 +26,10 @@ def track_from_arrays(contig: np.ndarray, starts: np.ndarray, ends: np.ndarray, 
     contig, starts, ends = np.asarray(contig), np.asarray(starts, dtype=np.int64), np.asarray(ends, dtype=np.int64)
     # (a BED file is sorted as a rule: one vectorised check instead of a three-key sort of 3 M rows - 0.25 s of the tool's first stage)
     if contig.size > 1:
-        dc, ds = contig[1:] - contig[:-1], starts[1:] - starts[:-1]
-        in_order = bool(np.all((dc > 0) | ((dc == 0) & ((ds > 0) | ((ds == 0) & (ends[1:] >= ends[:-1]))))))
+        # (comparisons, not differences: a decreasing UNSIGNED contig column - the variant table's is uint16 - wraps to a large
+        # positive difference and would pass for sorted)
+        c0, c1, s0, s1 = contig[:-1], contig[1:], starts[:-1], starts[1:]
+        in_order = bool(np.all((c1 > c0) | ((c1 == c0) & ((s1 > s0) | ((s1 == s0) & (ends[1:] >= ends[:-1]))))))
     else:
         in_order = True
     if not in_order:

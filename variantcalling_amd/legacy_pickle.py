@@ -85,9 +85,14 @@ class _ShimUnpickler(pickle.Unpickler):
 def is_tree_state_mismatch(exc: BaseException) -> bool:
     """scikit-learn's `Tree.__setstate__` refusing the node / value arrays of another generation's pickle (the messages of
     sklearn/tree/_tree.pyx: "node array from the pickle has an incompatible dtype", "... value array ...", "Wrong dimensions
-    for node array from the pickle")."""
+    for node array from the pickle"; scikit-learn < 1.3: "Did not recognise loaded array layout" / "... dimensions"; a pickle from
+    another platform: Cython's "Buffer dtype mismatch, expected ..." raised from the same __setstate__)."""
+    if not isinstance(exc, ValueError):
+        return False
     msg = str(exc)
-    return isinstance(exc, ValueError) and "from the pickle" in msg and ("array" in msg or "n_classes" in msg)
+    if "from the pickle" in msg and ("array" in msg or "n_classes" in msg):
+        return True
+    return "Did not recognise loaded array" in msg or "Buffer dtype mismatch" in msg
 
 
 def load(path_or_bytes):
