@@ -138,7 +138,7 @@ def cpu_baseline(cs, forests, sample_n):
 
 def _git_head():
     """Short commit hash of the tree the bench runs from (the GPU box gets a snapshot without .git: profiles/HEAD, written
-    by tools/gpu_*.sh callers before the snapshot is taken, stands in)."""
+    by whoever calls tools/gpu_evidence.sh before the snapshot is taken, stands in)."""
     try:
         h = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip()
         if h:

@@ -1,4 +1,4 @@
-"""Turn rocprofv3 PMC passes (tools/gpu_profile.sh) into one entry of profiles/hbm_traffic.json.
+"""Turn rocprofv3 PMC passes (tools/gpu_evidence.sh prof) into one entry of profiles/hbm_traffic.json.
 
 HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE summed over the kernels of the workload (counter unit: KB).  The
 factor 2 is the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md (FETCH_SIZE tallies 128-byte requests at 64

@@ -538,7 +538,7 @@ int ugvc_filter_variants(ugvc_ctx* ctx, const ugvc_variants* v, const ugvc_resul
     // large callsets: a chunk pipeline - host validation + staging || H2D || pass || D2H (pipeline.hip); UGVC_PIPE_CHUNKS
     // sets the number of chunks (1 = the plain upload / pass / download sequence below)
     if (ctx && v && out && v->n >= 262144 && check_variants(v) == 0 && ctx->n_contigs > 0) {
-        const char* e = getenv("UGVC_PIPE_CHUNKS");          // (read per call: tools/e2e_ab.py sweeps it in one process)
+        const char* e = getenv("UGVC_PIPE_CHUNKS");          // (read per call: a sweep changes it inside one process)
         const int chunks = std::min(e ? atoi(e) : 8, 64);
         if (chunks > 1) {
             UGVC_HIP(hipSetDevice(ctx->device));

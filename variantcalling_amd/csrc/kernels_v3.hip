@@ -102,7 +102,7 @@ __global__ __launch_bounds__(kBlock, 4) void featurize3_kernel(const V2Args v) {
     css_lds[tid] = v.css_lut[tid];
     __syncthreads();
 
-    // phase clocks (tools/phase3.py, kernel variant bit 6): wave 0 accumulates the core-clock cycles between
+    // phase clocks (kernel variant bit 6, ugvc_debug_phase_clocks): wave 0 accumulates the core-clock cycles between
     // the phase boundaries of its tiles; slot 6 counts tiles
     __shared__ unsigned long long prof_lds[8];
     const bool prof_on = (a.ablate & 64) != 0 && v.prof != nullptr;
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(kBlock, 4) void featurize3_kernel(const V2Args v) {
         if (prof_on && tid == 0) { const unsigned long long now_ = clock64(); prof_lds[1] += now_ - prof_t; prof_t = now_; }
 
         // ---- stage the slices this tile can touch: wave w copies segments w, w+4, w+8, w+12
-        const int abl = a.ablate;       // profiling only (tools/ablate3.py): 2 joins, 4 quantise, 8 window features, 16 append
+        const int abl = a.ablate;       // profiling only (ugvc_set_kernel_variant): 2 joins, 4 quantise, 8 window features, 16 append
         const int staged = rfl(plan.staged);
         if (staged && !(abl & 2)) {
             const int wave = tid >> 6;
@@ -960,7 +960,7 @@ int launch_filter_v3(ugvc_ctx* ctx, const FilterArgs& a) {
     if (v2_fill_args(ctx, v, a.n)) return -1;
     const int64_t nbr = std::max<int64_t>((int64_t)(v.n_blocks + 1) * 8, UGVC_N_GROUPS * kShards);
     UGVC_LAUNCH(bracket3_kernel, dim3((unsigned)((nbr + 255) / 256)), dim3(256), 0, ctx->stream, v);
-    // profiling knobs (tools/tune3.py): bits 12-13 of the kernel variant cap K1's workgroups per CU,
+    // profiling knobs (ugvc_set_kernel_variant): bits 12-13 of the kernel variant cap K1's workgroups per CU,
     // bits 14-15 pick K2's wave count; 0 = the defaults
     const int k1_bpc = ((a.ablate >> 12) & 3) ? ((a.ablate >> 12) & 3) : 4;
     const int k1_grid = std::min(v.n_blocks, ctx->n_cus * k1_bpc);
