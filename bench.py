@@ -249,6 +249,7 @@ def run_filter(args):
         eng.filter_resident()
     res = eng.download_results()
     check = None
+    gathered_ok = None
     checked_rows = 0
     if grp.rank == 0:
         # --check-rows K: the first K and the last K rows of this rank's shard (all of it if that covers it; K < 0: all),
@@ -271,6 +272,16 @@ def run_filter(args):
         ok = bool(allr.filter.size == n_total and np.array_equal(allr.filter[lo:lo + mine.n], res.filter)
                   and np.array_equal(allr.tree_score[lo:lo + mine.n], res.tree_score))
         ok_all = grp.sum_float(1.0 if ok else 0.0) == grp.world
+        # --check-rows -1 under a collective: rank 0 also compares EVERY row of the gathered callset with the oracle on the
+        # unsharded tables (tools/scale_selfcheck.sh) - the shards, the per-rank table slices and the rank order of the gather
+        if grp.rank == 0 and args.check_rows < 0:
+            from oracle import oracle as O
+            gathered_ok = True
+            for a in range(0, n_total, 250_000):
+                b_ = min(a + 250_000, n_total)
+                exp = O.filter_variants(cs.variants.slice(a, b_), cs.ref, cs.runs, cs.tracks, cs.blacklist, forests)
+                gathered_ok = gathered_ok and bool(np.array_equal(allr.filter[a:b_], exp.filter) and np.array_equal(allr.flags[a:b_], exp.flags)
+                                                   and np.array_equal(allr.tree_score[a:b_], exp.tree_score))
     else:
         ok_all = True
     # ---- PCIe-inclusive rate of the host-buffer boundary (never `value`): upload + one pass + download
@@ -335,7 +346,8 @@ def run_filter(args):
                           kernel_ms_p95=_pct(step_ms, 95), alg_bytes_per_variant=alg, variants_per_launch=mine.n,
                           issue_bound=issue),
             e2e_incl_pcie=e2e, spinup=ramp,
-            parity=dict(oracle_slice_bit_exact=check, oracle_rows_checked=checked_rows, gather_consistent=ok_all),
+            parity=dict(oracle_slice_bit_exact=check, oracle_rows_checked=checked_rows, gather_consistent=ok_all,
+                        gathered_all_rows_bit_exact=gathered_ok),
             setup_s=round(t_setup, 1), cpu_baseline=cpu)
         print(json.dumps(out), flush=True)
     eng.close()

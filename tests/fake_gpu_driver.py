@@ -1,8 +1,10 @@
-"""TEST INFRASTRUCTURE: runs `filter_variants_pipeline.run(argv)` with the GPU engine replaced by a stand-in that scores
-with the CPU oracle and "all-gathers" through files - so the tool's multi-rank ORCHESTRATION (equal-count shards, per-rank
-context slices, rank-order reassembly, multi-allelic fold, rank-0-only write, rendezvous over dist.Group) runs in this
-GPU-less container with WORLD_SIZE = 2.  The product path never imports this module.
-Usage: python tests/fake_gpu_driver.py <exchange dir> <tool argv...>"""
+"""TEST INFRASTRUCTURE: runs `filter_variants_pipeline.run(argv)` - or, with `--bench`, `bench.py`'s own main() - with the GPU
+engine replaced by a stand-in that scores with the CPU oracle and "all-gathers" through files, so the multi-rank ORCHESTRATION
+(equal-count shards, per-rank context slices, rank-order reassembly, multi-allelic fold, rank-0-only write, rendezvous over
+dist.Group; bench.py: shard bookkeeping, the max-over-ranks clock, the gather consistency and every-row checks, the JSON line)
+runs in this GPU-less container with WORLD_SIZE = 2.  The product path never imports this module; the numbers such a bench
+line carries are meaningless and say so (device name).
+Usage: python tests/fake_gpu_driver.py <exchange dir> <tool argv...>  |  <exchange dir> --bench <bench.py argv...>"""
 import os
 import sys
 import time
@@ -34,12 +36,49 @@ class FakeEngine:
     def reserve(self, n_variants, alleles_len):               # (Engine.reserve: allocations only)
         assert n_variants >= 0 and alleles_len >= 0
 
+    # ---- what bench.py asks of an engine beyond the tool's calls
+    def close(self):
+        pass
+
+    def device_info(self):
+        return dict(name="CPU oracle stand-in (tests/fake_gpu_driver.py): timings meaningless", n_cus=1, hbm_bytes=0)
+
+    def device_attr(self, what):
+        return {"clock_khz": 1_000_000, "n_cus": 1, "mem_clock_khz": 1, "lds_bytes": 0}[what]
+
+    def set_kernel_variant(self, v):
+        assert v == 0
+
+    def device_sync(self):
+        pass
+
+    def selftest(self, n=1024):
+        pass
+
+    def timed_steps(self, iters, cap=0, gather=False):
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            if self.res is None:                              # (one oracle pass stands for every step: the result cannot differ)
+                self.filter_resident()
+            if gather:
+                self.allgather_resident(cap)
+        ms = (time.perf_counter() - t0) * 1e3
+        self._step_ms = [ms / iters] * iters
+        return ms, ms
+
+    def last_step_ms(self, n):
+        return np.asarray(self._step_ms[:n], np.float64)
+
+    def download_results(self):
+        return self.res
+
     def filter_variants(self, vt):
         ref, runs, tracks, bl, forests, flow, hp_len, hp_dist, mark = self.cfg
         return O.filter_variants(vt, ref, runs, tracks, bl, forests, flow, hp_len, hp_dist, mark)
 
     def upload_variants(self, vt):
         self.vt = vt
+        self.res = None
 
     def filter_resident(self):
         self.res = self.filter_variants(self.vt)
@@ -83,6 +122,11 @@ def fake_configure(eng, ref, runs, tracks, bl, forests, flow_order="TGCA", hpol_
 
 real_engine.Engine = FakeEngine
 real_engine.configure = fake_configure
+if len(sys.argv) > 2 and sys.argv[2] == "--bench":
+    import bench  # noqa: E402
+    sys.argv = ["bench.py"] + sys.argv[3:]
+    bench.main()
+    sys.exit(0)
 from variantcalling_amd.pipelines import filter_variants_pipeline  # noqa: E402
 
 sys.exit(filter_variants_pipeline.run(sys.argv[2:]) or 0)
