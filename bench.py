@@ -223,24 +223,33 @@ def run_filter(args):
     # lag-1 autocorrelation 0.74: a ramp, not noise.  A production stream scores callset after callset; the timed region
     # below measures that state.  The ramp itself is reported (first / last 20 passes of the spin-up) in `spinup`.
     ramp = None
+    probe = []                                                   # per-pass kernel times, each bracketed by its own event pair (untimed part)
     if args.spinup > 0:
         eng.timed_steps(args.spinup, cap, gather)
         sp = np.asarray(eng.last_step_ms(args.spinup), np.float64)
         k = min(20, sp.size)
         ramp = dict(passes=int(args.spinup), first_ms=float(sp[:k].mean()), last_ms=float(sp[-k:].mean()))
+        probe += list(sp[-min(40, sp.size):])
     # ---- warm-up (untimed)
     if args.warmup > 0:
         eng.timed_steps(args.warmup, cap, gather)
-    # ---- timed region: exactly K steps between barrier + device sync on both sides
+        probe += list(np.asarray(eng.last_step_ms(args.warmup), np.float64))
+    # ---- timed region: exactly K steps between barrier + device sync on both sides.  ONE event pair on the launch stream
+    # brackets the K steps (per-step pairs are markers the stream drains to: ~9 us of every step - round 5; the per-pass
+    # percentiles below come from the untimed passes just before, which keep their pairs)
     eng.device_sync()
     grp.barrier()
     t0 = time.perf_counter()
-    ms_total, ms_kernel = eng.timed_steps(args.steps, cap, gather)
+    ms_total, ms_kernel = eng.timed_steps(args.steps, cap, gather, per_step_events=args.step_events)
     eng.device_sync()
     grp.barrier()
     wall = grp.max_float(time.perf_counter() - t0)
     ms_kernel_max = grp.max_float(ms_kernel)
-    step_ms = eng.last_step_ms(args.steps)
+    step_ms = eng.last_step_ms(args.steps) if args.step_events else np.asarray(probe, np.float64)
+    if gather and not args.step_events:
+        # with a collective the single pair also spans the wait for the last gather: the kernel's own duration is the mean of
+        # the bracketed passes just before the timed region (same kernels, same buffers)
+        ms_kernel_max = grp.max_float(float(np.mean(probe)) * args.steps if len(probe) else ms_kernel)
 
     # ---- post-run correctness spot check against the oracle (rank 0, small slice; untimed).  With a
     # collective the timed passes wrote straight into the gather buffers: one more pass fills the
@@ -318,13 +327,23 @@ def run_filter(args):
         td = [int(f.n_trees) * int(f.max_depth) if f is not None else 0 for f in forests]
         td_indel = max(td[1:]) if len(td) > 1 else 0
         visits = float(n_sub) * td[0] + float(mine.n - n_sub) * td_indel
-        clk = _device_clock_ghz(eng)
+        clk_peak = _device_clock_ghz(eng)
+        # the clock the pass SUSTAINS, read by the kernel itself (s_memtime against the constant 100 MHz s_memrealtime across one
+        # wave of the last of 40 back-to-back passes: ugvc_pass_clock) - the floor is priced at it, the peak clock stays beside it
+        clk_meas = None
+        try:
+            clk_meas = eng.pass_clock_ghz(40)[0] if args.variant == 0 and not gather else None
+        except Exception:
+            clk_meas = None
+        clk = clk_meas or clk_peak
         issue = None
         if clk:
             floor_ms = visits / 64.0 * 16.0 / (info["n_cus"] * 4) / (clk * 1e9) * 1e3
             issue = dict(bound="valu_issue", visits_per_launch=visits, cycles_per_visit_floor=16,
                          what="4 vector instructions per tree-node visit x 4 issue cycles per wave-64 instruction on a 16-lane SIMD",
-                         simds=info["n_cus"] * 4, clock_ghz=clk, floor_ms=floor_ms, kernel_ms=kern_ms, frac=floor_ms / kern_ms)
+                         simds=info["n_cus"] * 4, clock_ghz=clk, clock_source=("measured inside the pass (s_memtime / s_memrealtime)" if clk_meas
+                                                                                else "hipDeviceProp_t::clockRate (peak)"),
+                         clock_ghz_peak=clk_peak, floor_ms=floor_ms, kernel_ms=kern_ms, frac=floor_ms / kern_ms)
         out = dict(
             metric="variants/sec filtered (whole node), 5M-call WGS", value=n_total * args.steps / wall,
             unit="variants/s", n_gpus=grp.world, steps=args.steps, warmup=args.warmup,
@@ -343,7 +362,13 @@ def run_filter(args):
             roofline=dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBPS, unit="GB/s",
                           frac=achieved / HBM_PEAK_GBPS, traffic=traffic, traffic_measured_at_commit=traffic_commit,
                           kernel=PASS_KERNELS, kernel_ms=kern_ms, kernel_ms_p5=_pct(step_ms, 5), kernel_ms_p50=_pct(step_ms, 50),
-                          kernel_ms_p95=_pct(step_ms, 95), alg_bytes_per_variant=alg, variants_per_launch=mine.n,
+                          kernel_ms_p95=_pct(step_ms, 95),
+                          kernel_ms_from=("one HIP event pair on the launch stream around the K timed steps / K" if not args.step_events and not gather
+                                          else "mean of the per-pass event pairs of the untimed passes just before the timed region" if not args.step_events
+                                          else "sum of the per-step event pairs of the timed region / K"),
+                          percentiles_from=("the per-step event pairs of the timed region" if args.step_events else
+                                            "per-pass event pairs of the warm-up steps and the last 40 spin-up passes (untimed)"),
+                          alg_bytes_per_variant=alg, variants_per_launch=mine.n,
                           issue_bound=issue),
             e2e_incl_pcie=e2e, spinup=ramp,
             parity=dict(oracle_slice_bit_exact=check, oracle_rows_checked=checked_rows, gather_consistent=ok_all,
@@ -532,6 +557,8 @@ def main():
     ap.add_argument("--check-rows", type=int, default=5000,
                     help="rows at either end of the shard compared with the CPU oracle after the timed region (-1: every row)")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (debug)")
+    ap.add_argument("--step-events", action="store_true",
+                    help="bracket every TIMED step with its own HIP event pair (round 4's measurement; costs ~9 us per step)")
     args = ap.parse_args()
     if args.snv_only:
         args.workload = "c2"

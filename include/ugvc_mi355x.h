@@ -175,6 +175,15 @@ int ugvc_timed_filter(ugvc_ctx* ctx, int iters, float* ms_total);
  * event pairs (what bench.py's roofline figure divides by). */
 int ugvc_timed_steps(ugvc_ctx* ctx, int iters, int64_t shard_cap, int gather, float* ms_total,
                      float* ms_kernel);
+/* on = 1 (default): ugvc_timed_steps brackets EVERY step with its own event pair (per-step times: ugvc_last_step_ms);
+ * on = 0: one pair around the whole run, the passes back to back as a production stream issues them - an event record is a
+ * marker the stream drains to, ~9 us per step; ms_kernel is then the time between that pair (measurement knob, builder-defined) */
+int ugvc_set_step_events(ugvc_ctx* ctx, int on);
+/* The shader clock the resident scoring pass sustains (what bench.py prices its instruction-issue floor at, instead of the
+ * device's peak clock): `passes` passes back to back, the last one probed by two counters inside the kernel - the constant
+ * 100 MHz s_memrealtime and the shader-clock s_memtime at the entry and the end of one wave.  wave_ms (nullable): that wave's
+ * span in milliseconds.  Builder-defined measurement aid. */
+int ugvc_pass_clock(ugvc_ctx* ctx, int passes, double* shader_ghz, double* wave_ms);
 /* per-step kernel milliseconds of the last ugvc_timed_steps (HIP event pairs on the launch stream): copies at most
  * `cap` values, returns how many (bench.py's p5 / p95) */
 int ugvc_last_step_ms(ugvc_ctx* ctx, float* out, int cap);

@@ -55,7 +55,10 @@ class FakeEngine:
     def selftest(self, n=1024):
         pass
 
-    def timed_steps(self, iters, cap=0, gather=False):
+    def pass_clock_ghz(self, passes=40):
+        return 1.0, 0.0
+
+    def timed_steps(self, iters, cap=0, gather=False, per_step_events=True):
         t0 = time.perf_counter()
         for _ in range(iters):
             if self.res is None:                              # (one oracle pass stands for every step: the result cannot differ)

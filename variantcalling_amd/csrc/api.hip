@@ -604,12 +604,47 @@ int ugvc_gather_fence(ugvc_ctx* ctx);
 int ugvc_gather_target(ugvc_ctx* ctx, int64_t shard_cap, float** score, uint8_t** filter, uint8_t** flags);
 int ugvc_gather_launch(ugvc_ctx* ctx, int64_t shard_cap);
 
+int ugvc_pass_clock(ugvc_ctx* ctx, int passes, double* shader_ghz, double* wave_ms) {
+    // The shader clock the scoring pass actually runs at: `passes` resident passes back to back (the clock state settles over
+    // tens of dispatches), the last of them probed - workgroup 0's first wave reads the constant 100 MHz counter (s_memrealtime)
+    // and the shader-clock counter (s_memtime) at its entry and at its end; GHz = shader ticks / (100 MHz ticks x 10 ns).
+    if (!ctx || !shader_ghz || passes < 1) return fail("bad arguments");
+    UGVC_HIP(hipSetDevice(ctx->device));
+    FilterArgs a;
+    if (build_args(ctx, a, false)) return -1;
+    if (!(!(ctx->kernel_variant & 256) && v2_available(ctx) && !(ctx->kernel_variant & 65536) && v5_available(ctx)))
+        return fail("ugvc_pass_clock: the clock words are written by the v5 pass, which this configuration does not take");
+    for (int it = 0; it + 1 < passes; ++it)
+        if (launch_score(ctx, a)) return -1;
+    ctx->clk_probe = 1;
+    ctx->clk_rt = ctx->clk_sh = 0;
+    const int rc = launch_score(ctx, a);
+    ctx->clk_probe = 0;
+    if (rc) return -1;
+    UGVC_HIP(hipStreamSynchronize(ctx->stream));
+    if (!ctx->clk_rt || !ctx->clk_sh) return fail("ugvc_pass_clock: no clock words came back (no rows resident?)");
+    *shader_ghz = (double)ctx->clk_sh / ((double)ctx->clk_rt * 10.0);
+    if (wave_ms) *wave_ms = (double)ctx->clk_rt * 1e-5;
+    return 0;
+}
+
+int ugvc_set_step_events(ugvc_ctx* ctx, int on) {
+    if (!ctx) return fail("ctx is NULL");
+    ctx->step_events = on ? 1 : 0;
+    return 0;
+}
+
 int ugvc_timed_steps(ugvc_ctx* ctx, int iters, int64_t shard_cap, int gather, float* ms_total, float* ms_kernel) {
     if (!ctx || !ms_total || !ms_kernel || iters < 1) return fail("bad arguments");
     UGVC_HIP(hipSetDevice(ctx->device));
     FilterArgs a;
     if (build_args(ctx, a, false)) return -1;
-    std::vector<hipEvent_t> ev(2 * (size_t)iters);
+    // Per-step event pairs are a measurement aid with a price: an event record is a marker packet between two launches (the
+    // stream drains to it) - ~9 us of every step of a 5 M pass, ~10 % of a 625 k-variant shard's.  ugvc_set_step_events(ctx, 0):
+    // ONE pair around the whole run, the passes back to back as a production stream issues them; *ms_kernel is then the time
+    // between that pair (without a collective: exactly the launches) and every step's entry of ugvc_last_step_ms its mean.
+    const bool per_step = ctx->step_events != 0;
+    std::vector<hipEvent_t> ev(per_step ? 2 * (size_t)iters : 0);
     for (auto& e : ev) UGVC_HIP(hipEventCreate(&e));
     int rc = 0;
     UGVC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
@@ -617,9 +652,9 @@ int ugvc_timed_steps(ugvc_ctx* ctx, int iters, int64_t shard_cap, int gather, fl
         // with a collective the pass writes straight into this step's gather buffer (no copies)
         if (gather) rc = ugvc_gather_target(ctx, shard_cap, &a.score, &a.filter, &a.flags);
         if (rc) break;
-        UGVC_HIP(hipEventRecord(ev[2 * it], ctx->stream));
+        if (per_step) UGVC_HIP(hipEventRecord(ev[2 * it], ctx->stream));
         rc = launch_score(ctx, a);
-        UGVC_HIP(hipEventRecord(ev[2 * it + 1], ctx->stream));
+        if (per_step) UGVC_HIP(hipEventRecord(ev[2 * it + 1], ctx->stream));
         if (!rc && gather) rc = ugvc_gather_launch(ctx, shard_cap);
     }
     if (!rc && gather) rc = ugvc_gather_fence(ctx);      // the timed region ends when the last gather has landed
@@ -628,13 +663,15 @@ int ugvc_timed_steps(ugvc_ctx* ctx, int iters, int64_t shard_cap, int gather, fl
     if (!rc) {
         UGVC_HIP(hipEventElapsedTime(ms_total, ctx->ev0, ctx->ev1));
         float sum = 0.f;
-        ctx->step_ms.assign((size_t)iters, 0.f);
-        for (int it = 0; it < iters; ++it) {
-            float ms = 0.f;
-            UGVC_HIP(hipEventElapsedTime(&ms, ev[2 * it], ev[2 * it + 1]));
-            ctx->step_ms[(size_t)it] = ms;
-            sum += ms;
-        }
+        ctx->step_ms.assign((size_t)iters, *ms_total / (float)iters);
+        if (per_step) {
+            for (int it = 0; it < iters; ++it) {
+                float ms = 0.f;
+                UGVC_HIP(hipEventElapsedTime(&ms, ev[2 * it], ev[2 * it + 1]));
+                ctx->step_ms[(size_t)it] = ms;
+                sum += ms;
+            }
+        } else sum = *ms_total;
         *ms_kernel = sum;
     }
     for (auto& e : ev) (void)hipEventDestroy(e);

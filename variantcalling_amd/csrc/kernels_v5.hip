@@ -1513,6 +1513,12 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
 #endif
     if (lds_addr(smem) != 0u) __builtin_trap();                  // (walk_forest: payloads are absolute LDS addresses)
     const uint64_t wclk_entry = v.wave_clk ? __builtin_readcyclecounter() : 0;
+    // (the sustained shader clock of the pass: workgroup 0's first wave leaves the constant 100 MHz counter and the shader-clock
+    // counter at its entry and at its end behind the per-wave records - ugvc_pass_clock; stored at once, nothing stays live)
+    if (v.wave_clk && blockIdx.x == 0 && tid == 0) {
+        v.wave_clk[0] = __builtin_amdgcn_s_memrealtime();          // (the four clock words sit in FRONT of the per-wave records)
+        v.wave_clk[2] = __builtin_readcyclecounter();
+    }
     const int64_t r0 = (int64_t)blockIdx.x * v.rows_wg;
     if (r0 >= a.n) return;                                       // (uniform: before the first barrier)
     const int64_t r1 = min(r0 + (int64_t)v.rows_wg, a.n);
@@ -1749,7 +1755,7 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
             __builtin_amdgcn_wave_barrier();
         }
         if (v.wave_clk && lane == 0) {
-            unsigned long long* w = v.wave_clk + ((size_t)blockIdx.x * 16 + wave) * 4;
+            unsigned long long* w = v.wave_clk + 4 + ((size_t)blockIdx.x * 16 + wave) * 4;
             w[0] = wclk_entry; w[1] = wclk_first; w[2] = __builtin_readcyclecounter(); w[3] = (unsigned long long)n_done | ((unsigned long long)n_done << 32);
         }
 #ifdef UGVC_PHASE_CLOCK
@@ -1850,8 +1856,12 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
         CLK(pc, 5);
     }
     if (v.wave_clk && lane == 0) {
-        unsigned long long* w = v.wave_clk + ((size_t)blockIdx.x * 16 + wave) * 4;
+        unsigned long long* w = v.wave_clk + 4 + ((size_t)blockIdx.x * 16 + wave) * 4;
         w[0] = wclk_entry; w[1] = wclk_first; w[2] = __builtin_readcyclecounter(); w[3] = (unsigned long long)n_done;
+        if (blockIdx.x == 0 && wave == 0) {
+            v.wave_clk[1] = __builtin_amdgcn_s_memrealtime();
+            v.wave_clk[3] = __builtin_readcyclecounter();
+        }
     }
 #ifdef UGVC_PHASE_CLOCK
     if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 133))
@@ -2087,8 +2097,9 @@ int launch_filter_v5(ugvc_ctx* ctx, const FilterArgs& a) {
     // buffer of the LAST pass is written to the file (tools/wave_clk.py reads it).  Waits for every pass: profiling only.
     static const char* wclk_path = getenv("UGVC_WAVE_CLK");
     static DeviceBuf wclk_buf;
-    const size_t wclk_bytes = (size_t)((a.n + v.rows_wg - 1) / v.rows_wg) * 16 * 4 * 8;
-    if (wclk_path) {
+    const size_t wclk_bytes = (size_t)((a.n + v.rows_wg - 1) / v.rows_wg) * 16 * 4 * 8 + 32;     // (+ the pass clock words)
+    const bool want_clk = wclk_path || ctx->clk_probe;
+    if (want_clk) {
         if (ensure(wclk_buf, wclk_bytes)) return -1;
         UGVC_HIP(hipMemsetAsync(wclk_buf.p, 0, wclk_bytes, ctx->stream));
         v.wave_clk = wclk_buf.as<unsigned long long>();
@@ -2097,13 +2108,19 @@ int launch_filter_v5(ugvc_ctx* ctx, const FilterArgs& a) {
     if (dbg) fprintf(stderr, "[ugvc v5] fused5: %d waves (%d indel), %zu B of LDS\n", v.n_waves, v.n_indel_waves, lds_f);
     const unsigned n_wg = (unsigned)((a.n + v.rows_wg - 1) / v.rows_wg);
     UGVC_LAUNCH(fused5_for(a.n_tracks, (a.ablate & (1 << 28)) != 0), dim3(n_wg), dim3(v.n_waves * 64), lds_f, ctx->stream, v);
-    if (wclk_path) {
+    if (want_clk) {
         std::vector<unsigned long long> h(wclk_bytes / 8);
         UGVC_HIP(hipMemcpyAsync(h.data(), wclk_buf.p, wclk_bytes, hipMemcpyDeviceToHost, ctx->stream));
         UGVC_HIP(hipStreamSynchronize(ctx->stream));
-        static int wclk_pass = 0;                                  // (the previous pass stays beside it as <file>.prev: are the slow workgroups the same ones?)
-        if (wclk_pass++ > 0) (void)rename(wclk_path, (std::string(wclk_path) + ".prev").c_str());
-        if (FILE* f = fopen(wclk_path, "wb")) { fwrite(h.data(), 1, wclk_bytes, f); fclose(f); }
+        const unsigned long long* tail = h.data();
+        // {100 MHz ticks, shader-clock ticks} between the entry and the end of workgroup 0's first wave
+        ctx->clk_rt = tail[1] > tail[0] ? tail[1] - tail[0] : 0;
+        ctx->clk_sh = tail[3] > tail[2] ? tail[3] - tail[2] : 0;
+        if (wclk_path) {
+            static int wclk_pass = 0;                              // (the previous pass stays beside it as <file>.prev: are the slow workgroups the same ones?)
+            if (wclk_pass++ > 0) (void)rename(wclk_path, (std::string(wclk_path) + ".prev").c_str());
+            if (FILE* f = fopen(wclk_path, "wb")) { fwrite(h.data() + 4, 1, wclk_bytes - 32, f); fclose(f); }
+        }
     }
     if (v.run_forest) {
         int n_waves = 0;

@@ -141,6 +141,9 @@ struct ugvc_ctx {
     int gather_pending[2] = {0, 0};
     int rank = 0, world = 1;
     int kernel_variant = 0;
+    int clk_probe = 0;              // the next scoring passes leave their clock words (ugvc_pass_clock)
+    unsigned long long clk_rt = 0, clk_sh = 0;   // 100 MHz ticks / shader-clock ticks across workgroup 0's first wave of the last probed pass
+    int step_events = 1;            // ugvc_timed_steps: an event pair around every step (0: one pair around the run)
     std::vector<float> step_ms;     // per-step kernel times of the last ugvc_timed_steps
     void* v2 = nullptr;             // ugvc::V2State (model_pack.hip)
     void* pipe = nullptr;           // ugvc::PipeState (pipeline.hip): host pool, pinned staging, copy streams

@@ -70,6 +70,8 @@ ABI = {
     "ugvc_results_download": (C.c_int, [_ctx, C.POINTER(CResults)]),
     "ugvc_timed_filter": (C.c_int, [_ctx, C.c_int, _f32p]),
     "ugvc_timed_steps": (C.c_int, [_ctx, C.c_int, C.c_int64, C.c_int, _f32p, _f32p]),
+    "ugvc_set_step_events": (C.c_int, [_ctx, C.c_int]),
+    "ugvc_pass_clock": (C.c_int, [_ctx, C.c_int, _f64p, _f64p]),
     "ugvc_device_sync": (C.c_int, [_ctx]),
     "ugvc_last_step_ms": (C.c_int, [_ctx, _f32p, C.c_int]),
     "ugvc_feature_matrix": (C.c_int, [_ctx, _f32p, _u8p]),
@@ -351,11 +353,24 @@ class Engine:
         self._check(self.lib.ugvc_timed_filter(self._h, iters, C.byref(ms)))
         return ms.value
 
-    def timed_steps(self, iters: int, shard_cap: int = 0, gather: bool = False):
-        """(ms_total, ms_kernel_sum) of `iters` steps = kernel [+ RCCL all-gather] on the stream."""
+    def timed_steps(self, iters: int, shard_cap: int = 0, gather: bool = False, per_step_events: bool = True):
+        """(ms_total, ms_kernel_sum) of `iters` steps = kernel [+ RCCL all-gather] on the stream.  per_step_events=False: one
+        event pair around the whole run instead of one per step (a marker between two launches costs ~9 us: the passes then run
+        back to back as a production stream issues them; ms_kernel_sum = ms_total, `last_step_ms` holds the mean)."""
         tot, ker = C.c_float(), C.c_float()
-        self._check(self.lib.ugvc_timed_steps(self._h, iters, shard_cap, int(gather), C.byref(tot), C.byref(ker)))
+        self._check(self.lib.ugvc_set_step_events(self._h, int(per_step_events)))
+        try:
+            self._check(self.lib.ugvc_timed_steps(self._h, iters, shard_cap, int(gather), C.byref(tot), C.byref(ker)))
+        finally:
+            self.lib.ugvc_set_step_events(self._h, 1)
         return tot.value, ker.value
+
+    def pass_clock_ghz(self, passes: int = 40):
+        """(shader clock in GHz the resident scoring pass sustains, span of the probed wave in ms): `passes` passes back to back,
+        the last one read by the kernel's own counters (s_memtime against the constant 100 MHz s_memrealtime)."""
+        ghz, ms = C.c_double(), C.c_double()
+        self._check(self.lib.ugvc_pass_clock(self._h, int(passes), C.byref(ghz), C.byref(ms)))
+        return float(ghz.value), float(ms.value)
 
     def last_step_ms(self, n: int) -> np.ndarray:
         """Per-step kernel milliseconds of the last timed_steps call."""
