@@ -496,16 +496,19 @@ def run_c5(args):
     fm_ms = eng.timed_feature_matrix(max(args.steps, 5))
     fm_bytes = ALG_BYTES_C3 + 4.0 * X.shape[1]
     fm_gbps = fm_bytes * N / (fm_ms * 1e-3) / 1e9
-    tot_gemm = tot_trav = tot_gemm_r1 = 0.0
+    tot_gemm2 = tot_trav = tot_gemm_r1 = 0.0
     same = True
     t0 = time.perf_counter()
+    rows_g = [np.flatnonzero(group == g).astype(np.int32) for g in range(3)]
+    # round 5: ONE launch for the three variant-type groups (forest_gemm3_kernel: exit leaf by a maximum, margins by row)
+    m3, tot_gemm = eng.forest_gemm3(rows_g, iters=args.steps)
     for g in range(3):
-        rows = np.flatnonzero(group == g).astype(np.int32)
-        a, ms_a = eng.forest_gemm(g, rows, use_mfma=1, iters=args.steps)     # round-4 kernel: register-indexed predicates, transposed product
+        rows = rows_g[g]
+        a, ms_a = eng.forest_gemm(g, rows, use_mfma=1, iters=max(args.steps // 2, 1))   # round-4 kernel, one launch per group: for the record
         b, ms_b = eng.forest_gemm(g, rows, use_mfma=0, iters=args.steps)
         c, ms_c = eng.forest_gemm(g, rows, use_mfma=2, iters=max(args.steps // 4, 1))   # round-1 kernel (predicates by LDS gathers), for the record
-        same &= bool(np.array_equal(a, b) and np.array_equal(a, c))
-        tot_gemm += ms_a
+        same &= bool(np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(m3[rows], b))
+        tot_gemm2 += ms_a
         tot_trav += ms_b
         tot_gemm_r1 += ms_c
     wall = time.perf_counter() - t0
@@ -529,8 +532,9 @@ def run_c5(args):
           f"C5: {N} variants, on-GPU N x 20 feature matrix, XGBoost-shaped T=100 depth-6 ensemble x 3 groups as path-matrix GEMM (i8 MFMA) "
           "next to the row traversal",
           dict(bound="mfma", achieved=tops, peak=MFMA_I8_PEAK_TOPS, unit="TOP/s (int8)", frac=tops / MFMA_I8_PEAK_TOPS, traffic=None,
-               kernel="forest_gemm2_kernel<false> (csrc/kernels_gemm.hip), v_mfma_i32_16x16x64_i8; HIP events around the launches, the three "
-                      "variant-type groups' launches summed", kernel_ms=tot_gemm, round1_kernel_ms=tot_gemm_r1,
+               kernel="forest_gemm3_kernel<false> (csrc/kernels_gemm.hip), v_mfma_i32_16x16x64_i8: ONE launch for the three variant-type "
+                      "groups; HIP events around the launches", kernel_ms=tot_gemm, round4_kernel_ms_three_launches=tot_gemm2,
+               round1_kernel_ms=tot_gemm_r1,
                alg_ops_per_variant=2.0 * I * L * T, traversal_ms=tot_trav, traversal_variants_per_s=N / (tot_trav * 1e-3),
                tops_vs_measured_i8_ceiling=tops / 3944.0,
                feature_build=dict(bound="hbm", ms=fm_ms, achieved=fm_gbps, peak=HBM_PEAK_GBPS, unit="GB/s", frac=fm_gbps / HBM_PEAK_GBPS,

@@ -201,6 +201,12 @@ int ugvc_n_features(ugvc_ctx* ctx);
  * kernel time of `iters` launches (HIP events). */
 int ugvc_forest_gemm(ugvc_ctx* ctx, int group, const int32_t* rows, int64_t n_rows, int use_mfma, int iters,
                      float* margin_out, float* ms_per_launch);
+/* The three variant-type groups in ONE launch (round 5): rows[k] / n_rows[k] = group k's rows of the resident matrix (n_rows[k]
+ * may be 0), every group with rows holding an additive depth <= 6 ensemble of the same kind; margin_out[row] (N floats, by row of
+ * the resident matrix) receives each named row's margin, other entries are left as they are.  Identical f32 margins to the
+ * traversal (same compares, same additions in tree order). */
+int ugvc_forest_gemm3(ugvc_ctx* ctx, const int32_t* const* rows, const int64_t* n_rows, int iters, float* margin_out,
+                      float* ms_per_launch);
 /* Host-only (no GPU): the single-base-substitution cycle-skip table the kernels use for a flow
  * order; index = (last left base)<<6 | ref<<4 | alt<<2 | (first right base), bases A,C,G,T = 0..3,
  * value 0 non-skip / 1 possible-cycle-skip / 2 cycle-skip.  Exposed so CPU tests can check it

@@ -636,6 +636,22 @@ def test_c5_leaf_matrix_gemm(engine, small_callset, frozen_models):
             got, ms = engine.forest_gemm(g, rows, use_mfma=mfma)
             assert np.array_equal(got, exp_margin), (g, mfma, np.flatnonzero(got != exp_margin)[:5])
             assert ms > 0
+    # round 5: the three groups in ONE launch, margins by row of the resident matrix - every row against the oracle; then with an
+    # empty group, a group of one row, and rows named in descending order
+    rows_g = [np.flatnonzero(group == g).astype(np.int32) for g in range(S.N_GROUPS)]
+    exp_all = np.zeros(X.shape[0], np.float32)
+    for g in range(S.N_GROUPS):
+        exp_all[rows_g[g]] = O.forest_predict(forests[g], X[rows_g[g]])[0]
+    got3, ms3 = engine.forest_gemm3(rows_g)
+    assert np.array_equal(got3, exp_all) and ms3 > 0
+    odd = [rows_g[0][:1], None, rows_g[2][::-1][:130]]
+    got3, _ = engine.forest_gemm3(odd)
+    named = np.zeros(X.shape[0], bool)
+    named[odd[0]] = True
+    named[odd[2]] = True
+    assert np.array_equal(got3[named], exp_all[named]) and not got3[~named].any()
+    with pytest.raises(RuntimeError, match="out of range"):
+        engine.forest_gemm3([np.array([X.shape[0]], np.int32), None, None])
     # all rows with one group's model, ragged tail (n not a multiple of 16), tiny inputs
     got, _ = engine.forest_gemm(0, None, use_mfma=True)
     assert np.array_equal(got, O.forest_predict(forests[0], X)[0])

@@ -264,6 +264,118 @@ __global__ __launch_bounds__(kGemm2Threads) void forest_gemm2_kernel(const GemmA
     }
 }
 
+// ---- round 5: ONE launch for the three variant-type groups, the exit leaf by a maximum instead of 64 compares -------------
+// forest_gemm2_kernel spends, per tree and 64-row tile, ~126 vector instructions on the predicates and ~128 on FINDING the exit
+// leaf (a compare + a select for each of a lane's sixteen D elements per row tile) around sixteen MFMAs - and runs once per
+// variant-type group, three launches with three tails.  Here (i) the path matrix is scaled by 64 and the bias of leaf l is
+// -64 popcount(l) + l, so that D = 64 (agreements - ancestors) + l is the leaf's own INDEX (>= 0) for the exit leaf and negative
+// for every other leaf: the exit leaf of a row is the MAXIMUM of its 64 D values - eight v_max3 per row tile and lane, two
+// cross-lane maxima - and its margin ONE LDS read by the row's own lane (|64 C| = 64 fits int8; |D| <= 6 x 64 + 63); (ii) a
+// workgroup serves ONE group (its leaves in LDS, its nodes by scalar loads), the workgroups are split over the groups by rows x
+// trees, margins are written by ROW of the resident matrix.  Same compares, same f32 additions in tree order: bit-identical.
+struct Gemm3Args {
+    GemmArgs g[UGVC_N_GROUPS];
+    int wg_end[UGVC_N_GROUPS];       // workgroups [wg_end[k-1], wg_end[k]) serve group k
+};
+
+template <bool RF>
+__global__ __launch_bounds__(kGemm2Threads) void forest_gemm3_kernel(const Gemm3Args a3) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int gi = 0;
+#pragma unroll
+    for (int k = 0; k + 1 < UGVC_N_GROUPS; ++k) gi += (int)blockIdx.x >= a3.wg_end[k] ? 1 : 0;
+    gi = __builtin_amdgcn_readfirstlane(gi);
+    const GemmArgs& g = a3.g[gi];
+    const int wg0 = gi == 0 ? 0 : a3.wg_end[gi - 1];
+    const int lb = (int)blockIdx.x - wg0, nb = a3.wg_end[gi] - wg0;
+    float* leaves = reinterpret_cast<float*>(smem);                                        // [T][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int k = tid; k < g.T * 16; k += kGemm2Threads) reinterpret_cast<float4*>(leaves)[k] = reinterpret_cast<const float4*>(g.leaves)[k];
+    __syncthreads();
+    unsigned char* stage = smem + (size_t)g.T * 64 * 4 + (size_t)wave * 64 * kGemm2RowB;
+    const uint32_t stage_b = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)stage;
+    const uint32_t leaves_b = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)leaves;
+    i32x4_t CT[4], bias[4];
+    const int col = lane & 15, kb = (lane >> 4) * 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 16; ++q) w[q >> 2] |= ((64 * path_entry(kb + q, 16 * j + col)) & 0xff) << (8 * (q & 3));
+        CT[j] = i32x4_t{w[0], w[1], w[2], w[3]};
+        const int l0 = 16 * j + 4 * (lane >> 4);                  // D[leaf = l0 + q][row = lane & 15]
+        bias[j] = i32x4_t{l0 - 64 * (int)__popc(l0), l0 + 1 - 64 * (int)__popc(l0 + 1), l0 + 2 - 64 * (int)__popc(l0 + 2), l0 + 3 - 64 * (int)__popc(l0 + 3)};
+    }
+    const uint32_t zero = 0u, one = 1u;
+    const f32x2_t UGVC_GEMM_CONST* const nodes = (const f32x2_t UGVC_GEMM_CONST*)(uintptr_t)g.nodes;
+    const int64_t n_tiles = (g.n + 63) / 64;
+    const int F = g.F;
+    for (int64_t tile = (int64_t)lb * (kGemm2Threads / 64) + wave; tile < n_tiles; tile += (int64_t)nb * (kGemm2Threads / 64)) {
+        int64_t gr = tile * 64 + lane;
+        const bool live = gr < g.n;
+        if (!live) gr = g.n - 1;
+        const int64_t src = g.rows ? (int64_t)g.rows[gr] : gr;
+        const float* xr = g.X + src * F;
+        f32x32_t xv;
+#pragma unroll
+        for (int f = 0; f < 32; ++f) xv[f] = 0.f;
+        if ((F & 3) == 0) {
+#pragma unroll
+            for (int q = 0; q < kMaxFeatures / 4 + 1; ++q)
+                if (4 * q < F) {
+                    const float4 x4 = reinterpret_cast<const float4*>(xr)[q];
+                    xv[4 * q] = x4.x; xv[4 * q + 1] = x4.y; xv[4 * q + 2] = x4.z; xv[4 * q + 3] = x4.w;
+                }
+        } else {
+#pragma unroll
+            for (int f = 0; f < kMaxFeatures; ++f)
+                if (f < F) xv[f] = xr[f];
+        }
+        float margin = g.base;
+        for (int t = 0; t < g.T; ++t) {
+            uint32_t a[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) a[q] = 0u;
+            const f32x2_t UGVC_GEMM_CONST* tn = nodes + (size_t)t * 64;
+#pragma unroll
+            for (int i = 0; i < 63; ++i) {
+                const f32x2_t nd = tn[i];
+                const float thr = nd[0];
+                const int fidx = __float_as_int(nd[1]);
+                if ((i & 3) == 0) pred_byte<0, RF>(a[i >> 2], xv, fidx, thr, zero, one);
+                else if ((i & 3) == 1) pred_byte<1, RF>(a[i >> 2], xv, fidx, thr, zero, one);
+                else if ((i & 3) == 2) pred_byte<2, RF>(a[i >> 2], xv, fidx, thr, zero, one);
+                else pred_byte<3, RF>(a[i >> 2], xv, fidx, thr, zero, one);
+            }
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t wr = stage_b + (uint32_t)lane * kGemm2RowB;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                *(__attribute__((address_space(3))) i32x4_t*)(uintptr_t)(wr + 16u * c) = i32x4_t{(int)a[4 * c], (int)a[4 * c + 1], (int)a[4 * c + 2], (int)a[4 * c + 3]};
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            int lx = 0;                                              // the exit leaf of THIS lane's row (row tile lane >> 4)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const i32x4_t P = *(const __attribute__((address_space(3))) i32x4_t*)(uintptr_t)(stage_b + (uint32_t)((16 * r + col) * kGemm2RowB + kb));
+                int m = -1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const i32x4_t D = __builtin_amdgcn_mfma_i32_16x16x64_i8(CT[j], P, bias[j], 0, 0, 0);
+                    m = max(m, max(max(D[0], D[1]), max(D[2], D[3])));
+                }
+                // the four lanes of a row (same lane & 15) hold its 64 leaves: the one non-negative value is the exit leaf's index
+                m = max(m, __shfl_xor(m, 16));
+                m = max(m, __shfl_xor(m, 32));
+                lx = (lane >> 4) == r ? m : lx;
+            }
+            margin += *(const __attribute__((address_space(3))) float*)(uintptr_t)(leaves_b + 4u * (uint32_t)(t * 64 + lx));   // tree order, f32
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (live) g.out[src] = margin;
+    }
+}
+
 // Traversal over the same matrix and the same dense node table: one lane per row, fixed 6-level walk.
 __global__ __launch_bounds__(256) void forest_rows_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -404,5 +516,119 @@ extern "C" int ugvc_forest_gemm(ugvc_ctx* ctx, int group, const int32_t* rows, i
     if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc) rc = fail("stream sync failed");
     for (DeviceBuf* b : {&dn, &dl, &dr, &dout})
         if (b->p) dev_free(b->p);
+    return rc;
+}
+
+// All three variant-type groups of the resident feature matrix in ONE launch (forest_gemm3_kernel): rows[k] / n_rows[k] name
+// group k's rows of the resident matrix (ascending or not), margin_out[row] receives every named row's margin (other rows are
+// left as they were).  Every group with rows must have an additive (XGBoost-style) depth <= 6 ensemble of the same kind.
+extern "C" int ugvc_forest_gemm3(ugvc_ctx* ctx, const int32_t* const* rows, const int64_t* n_rows, int iters, float* margin_out,
+                                 float* ms_per_launch) {
+    if (!ctx || !rows || !n_rows || !margin_out) return fail("NULL argument");
+    if (iters < 1) iters = 1;
+    UGVC_HIP(hipSetDevice(ctx->device));
+    const int F = UGVC_N_BASE_FEATURES + ctx->n_tracks;
+    if (!ctx->x_mat.p || ctx->x_mat.cap < (size_t)ctx->n * F * 4) return fail("no resident feature matrix (ugvc_feature_matrix first)");
+    Gemm3Args a3;
+    memset(&a3, 0, sizeof a3);
+    DeviceBuf dn[UGVC_N_GROUPS], dl[UGVC_N_GROUPS], dr[UGVC_N_GROUPS], dout;
+    int rc = 0, kind_all = -1, t_max = 0;
+    double work[UGVC_N_GROUPS] = {0, 0, 0}, tot = 0.0;
+    if (ensure(dout, (size_t)std::max<int64_t>(ctx->n, 1) * 4)) rc = -1;
+    if (!rc && hipMemcpyAsync(dout.p, margin_out, (size_t)ctx->n * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = fail("H2D copy failed");
+    for (int k = 0; k < UGVC_N_GROUPS && !rc; ++k) {
+        if (n_rows[k] <= 0) continue;
+        if (!rows[k]) { rc = fail("NULL row list"); break; }
+        for (int64_t i = 0; i < n_rows[k]; ++i)
+            if (rows[k][i] < 0 || rows[k][i] >= ctx->n) { rc = fail("row index out of range"); break; }
+        if (rc) break;
+        std::vector<float2> nodes;
+        std::vector<float> leaves;
+        int T = 0, kind = 0;
+        float base = 0.f;
+        if (gemm_model(ctx, k, nodes, leaves, T, kind, base)) { rc = -1; break; }
+        if (kind_all >= 0 && kind != kind_all) { rc = fail("ugvc_forest_gemm3: the groups' ensembles must be of one kind"); break; }
+        kind_all = kind;
+        t_max = std::max(t_max, T);
+        if (upload(ctx, dn[k], nodes.data(), nodes.size() * sizeof(float2)) || upload(ctx, dl[k], leaves.data(), leaves.size() * 4) ||
+            upload(ctx, dr[k], rows[k], (size_t)n_rows[k] * 4)) { rc = -1; break; }
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = fail("stream sync failed"); break; }   // (nodes / leaves go out of scope)
+        a3.g[k] = GemmArgs{ctx->x_mat.as<float>(), F, dr[k].as<int32_t>(), n_rows[k], dn[k].as<float2>(), dl[k].as<float>(), T, kind, base, dout.as<float>()};
+        work[k] = (double)n_rows[k] * T;
+        tot += work[k];
+    }
+    if (!rc && tot > 0.0) {
+        const size_t lds = (size_t)t_max * 64 * 4 + (size_t)(kGemm2Threads / 64) * 64 * kGemm2RowB;
+        if (lds > 156 * 1024) rc = fail("ensemble too large for the LDS-resident GEMM formulation");
+        // two workgroups of eight waves per CU, split over the groups by rows x trees (every group with rows gets at least one)
+        const int grid = ctx->n_cus * 2;
+        int used = 0, big = 0;
+        int nbk[UGVC_N_GROUPS] = {0, 0, 0};
+        for (int k = 0; k < UGVC_N_GROUPS; ++k) {
+            nbk[k] = work[k] > 0 ? std::max(1, (int)(grid * (work[k] / tot) + 0.5)) : 0;
+            used += nbk[k];
+            if (work[k] > work[big]) big = k;
+        }
+        nbk[big] = std::max(1, nbk[big] + grid - used);
+        int end = 0;
+        for (int k = 0; k < UGVC_N_GROUPS; ++k) { end += nbk[k]; a3.wg_end[k] = end; }
+        const void* fn = kind_all == UGVC_MODEL_RF ? reinterpret_cast<const void*>(forest_gemm3_kernel<true>) : reinterpret_cast<const void*>(forest_gemm3_kernel<false>);
+        if (!rc && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess) rc = fail("cannot raise the dynamic LDS limit");
+        // first use per process: this kernel shares forest_gemm2_kernel's register-indexed predicates (UGVC_PRED_ASM relies on
+        // where the compiler put the row's feature registers) - up to 512 rows of the largest group against the scalar traversal,
+        // bit for bit; a build on which they differ fails HERE, loudly, instead of returning margins (ugvc_forest_gemm serves then)
+        static std::atomic<int> gemm3_state{0};                  // 0 unchecked, 1 agrees, 2 differs
+        const size_t lds_rows = (size_t)a3.g[big].T * 64 * 12;
+        if (!rc && gemm3_state.load() == 0 && lds_rows <= 156 * 1024) {
+            const int64_t m = std::min<int64_t>(a3.g[big].n, 512);
+            DeviceBuf dchk;
+            std::vector<float> h((size_t)m), all((size_t)ctx->n);
+            Gemm3Args c3;
+            memset(&c3, 0, sizeof c3);
+            c3.g[big] = a3.g[big];
+            c3.g[big].n = m;
+            for (int k = 0; k < UGVC_N_GROUPS; ++k) c3.wg_end[k] = k < big ? 0 : 4;
+            GemmArgs ga = a3.g[big];
+            ga.n = m;
+            bool ran = ensure(dchk, (size_t)m * 4) == 0 &&
+                       hipFuncSetAttribute(reinterpret_cast<const void*>(forest_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) == hipSuccess;
+            if (ran) {
+                ga.out = dchk.as<float>();
+                UGVC_LAUNCH(forest_rows_kernel, dim3(8), dim3(256), lds_rows, ctx->stream, ga);
+                if (kind_all == UGVC_MODEL_RF) UGVC_LAUNCH(forest_gemm3_kernel<true>, dim3(4), dim3(kGemm2Threads), lds, ctx->stream, c3);
+                else UGVC_LAUNCH(forest_gemm3_kernel<false>, dim3(4), dim3(kGemm2Threads), lds, ctx->stream, c3);
+                ran = hipMemcpyAsync(h.data(), dchk.p, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                      hipMemcpyAsync(all.data(), dout.p, (size_t)ctx->n * 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                      hipStreamSynchronize(ctx->stream) == hipSuccess && hipGetLastError() == hipSuccess;
+            }
+            dev_free(dchk.p);
+            if (ran) {
+                bool same = true;
+                for (int64_t i = 0; i < m && same; ++i) same = memcmp(&h[(size_t)i], &all[(size_t)rows[big][i]], 4) == 0;
+                gemm3_state.store(same ? 1 : 2);
+            }
+        }
+        if (!rc && gemm3_state.load() == 2)
+            rc = fail("forest_gemm3_kernel disagrees with the scalar traversal on this build (register-indexed predicates): use ugvc_forest_gemm");
+        if (!rc) {
+            if (hipEventRecord(ctx->ev0, ctx->stream) != hipSuccess) rc = fail("event record failed");
+            for (int it = 0; it < iters && !rc; ++it) {
+                if (kind_all == UGVC_MODEL_RF) UGVC_LAUNCH(forest_gemm3_kernel<true>, dim3((unsigned)end), dim3(kGemm2Threads), lds, ctx->stream, a3);
+                else UGVC_LAUNCH(forest_gemm3_kernel<false>, dim3((unsigned)end), dim3(kGemm2Threads), lds, ctx->stream, a3);
+            }
+            if (!rc && (hipEventRecord(ctx->ev1, ctx->stream) != hipSuccess || hipEventSynchronize(ctx->ev1) != hipSuccess || hipGetLastError() != hipSuccess))
+                rc = fail("forest GEMM launch failed");
+            if (!rc && ms_per_launch) {
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+                *ms_per_launch = ms / iters;
+            }
+        }
+    }
+    if (!rc && ctx->n > 0 && hipMemcpyAsync(margin_out, dout.p, (size_t)ctx->n * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = fail("D2H copy failed");
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc) rc = fail("stream sync failed");
+    for (int k = 0; k < UGVC_N_GROUPS; ++k)
+        for (DeviceBuf* b : {&dn[k], &dl[k], &dr[k]}) dev_free(b->p);
+    dev_free(dout.p);
     return rc;
 }

@@ -162,7 +162,6 @@ __device__ __forceinline__ void brk_refresh(const FilterArgs& a, Brk<NT>& bk, in
 // contig before its own tiles and publishes the state at `rec_b` (gtab + 512: 24 dwords); a wave that meets that contig adopts
 // it if it is there by then, and searches itself if not.  The published ranks belong to the second contig's FIRST row of
 // either class: lower bounds for every later row of it (rows ascend by position: validated at upload).
-constexpr int kBndRecDw = 6 + 3 * kJoin5;                       // ready | Lb | clo | chi | plo[] | phi[] | L[]
 template <int NT>
 __device__ __forceinline__ void brk_publish(uint32_t rec_b, const Brk<NT>& bk, int lane) {
     if (lane == 0) {

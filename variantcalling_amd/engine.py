@@ -77,6 +77,7 @@ ABI = {
     "ugvc_feature_matrix": (C.c_int, [_ctx, _f32p, _u8p]),
     "ugvc_n_features": (C.c_int, [_ctx]),
     "ugvc_forest_gemm": (C.c_int, [_ctx, C.c_int, _i32p, C.c_int64, C.c_int, C.c_int, _f32p, _f32p]),
+    "ugvc_forest_gemm3": (C.c_int, [_ctx, C.POINTER(_i32p), _i64p, C.c_int, _f32p, _f32p]),
     "ugvc_host_css_lut": (C.c_int, [C.c_char_p, _u8p]),
     "ugvc_set_kernel_variant": (C.c_int, [_ctx, C.c_int]),
     "ugvc_debug_phase_clocks": (C.c_int, [_ctx, C.POINTER(C.c_uint64), C.c_int]),
@@ -411,6 +412,17 @@ class Engine:
         r = None if rows is None else _col(rows, np.int32)
         self._check(self.lib.ugvc_forest_gemm(self._h, group, None if r is None else _p(r, _i32p), n, int(use_mfma),
                                               iters, _p(out, _f32p), C.byref(ms)))
+        return out, ms.value
+
+    def forest_gemm3(self, rows_by_group: list, iters: int = 1):
+        """(f32 margin per row of the resident feature matrix, ms per launch): every variant-type group's additive ensemble on
+        its rows (rows_by_group[k]: int32 row numbers, or None / empty) in ONE launch of the leaf-matrix GEMM (round 5)."""
+        keep = [None if r is None else _col(r, np.int32) for r in rows_by_group]
+        ptrs = (_i32p * 3)(*[C.cast(None, _i32p) if r is None or r.size == 0 else _p(r, _i32p) for r in keep])
+        counts = np.array([0 if r is None else r.size for r in keep], np.int64)
+        out = np.zeros(self.n, np.float32)
+        ms = C.c_float()
+        self._check(self.lib.ugvc_forest_gemm3(self._h, ptrs, _p(counts, _i64p), iters, _p(out, _f32p), C.byref(ms)))
         return out, ms.value
 
     # ---- pileup
