@@ -8,6 +8,7 @@
 #         prof     rocprofv3 --kernel-trace --stats + FETCH_SIZE / WRITE_SIZE passes of every workload
 #                                                                   -> <tag>_kernel_stats.txt, <tag>_rocprof_summary.txt, hbm_traffic.json
 #         sq       SQ instruction counters of the pass (all / without the SNP walk) -> <tag>_sq_counters.txt
+#         c5sq     SQ counters of the C5 GEMM kernels (vector vs MFMA work)  -> <tag>_c5_sq_counters.txt
 #         wclk     per-wave clocks (UGVC_WAVE_CLK, tools/wave_clk.py) -> <tag>_wave_clk.txt
 #         cli      filter_variants_pipeline on a 5 M-record VCF, stage table -> <tag>_c1_pipeline_5M.txt
 # Everything lands in gpurun_out/; copy what is to be judged into profiles/.
@@ -90,6 +91,23 @@ with open(f"gpurun_out/{tag}_sq_counters.txt", "a") as out:
 PY
   done
   rm -rf $O/pm; cat $O/${T}_sq_counters.txt ;;
+c5sq)
+  rm -rf $O/pm5
+  timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pm5 -o pmc -- python bench.py --workload c5_gemm --steps 4 --warmup 1 --cpu-sample 0 > $O/pm5.log 2>&1 || tail -3 $O/pm5.log
+  python - "$T" <<'PY'
+import csv, glob, sys, collections
+tag = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("gpurun_out/pm5/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        agg[r["Kernel_Name"].split("(")[0].replace("void ", "")[:48]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+with open(f"gpurun_out/{tag}_c5_sq_counters.txt", "w") as out:
+    out.write("# rocprofv3 --pmc ... -- python bench.py --workload c5_gemm: mean per launch, millions (SQ_* summed over the chip)\n")
+    for k, d in sorted(agg.items()):
+        if "forest_" not in k: continue
+        out.write(f"{k:48s} launches {len(next(iter(d.values()))):3d}  " + "  ".join(f"{c[3:]}={sum(v)/len(v)/1e6:.2f}M" for c, v in sorted(d.items())) + "\n")
+PY
+  rm -rf $O/pm5; cat $O/${T}_c5_sq_counters.txt ;;
 wclk)
   for n in 5000000 625000; do
     UGVC_WAVE_CLK=/tmp/wclk.bin python bench.py --variants $n --steps 3 --warmup 2 --spinup 20 --cpu-sample 0 --no-e2e --check-rows 0 > /tmp/wclk.json 2>/tmp/wclk.err || tail -3 /tmp/wclk.err

@@ -60,6 +60,14 @@ __device__ __forceinline__ uint32_t lds_u8(uint32_t a) { return *(UGVC_LDS const
 
 // Element `idx` of a resident array through `SGPR base + 32-bit byte offset` addressing (one 32-bit shift instead of
 // 64-bit address arithmetic per lane): every array of this pass is shorter than 4 GiB (v5_available checks the row counts).
+// A reference window is read ONCE per pass, at a place no other lane shares (variants lie ~600 bases apart): a NON-TEMPORAL load,
+// so that the window lines do not push the side-table slices - which every tile re-reads - out of the caches (round 5, two builds
+// alternating on one box: pass 0.4144 against 0.4165 ms, HBM traffic 1.829 against 1.867 GB, profiles/r05_nt_window_ab.txt).
+typedef uint32_t u32x4_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 load_window16(const uint8_t* p) {
+    const u32x4_nt x = __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt*>(p));
+    return make_uint4(x.x, x.y, x.z, x.w);
+}
 template <class T> __device__ __forceinline__ T ldg32(const T* base, uint32_t idx) {
     return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (uint32_t)(idx * (uint32_t)sizeof(T)));
 }
@@ -685,7 +693,7 @@ __device__ __forceinline__ void featurize_snp_tile(const V5Args& v, const Scratc
     // bytes at both ends)
     const int64_t wa = (g0 - 5) & ~(int64_t)3;
     const uint32_t sh = (uint32_t)(g0 - 5) & 3u;
-    const uint4 xw = *reinterpret_cast<const uint4*>(a.ref + wa);
+    const uint4 xw = load_window16(a.ref + wa);
     const uint32_t rbase = a.alleles[ro], abase = a.alleles[ao];
 
     const uint64_t key = ((uint64_t)(uint32_t)c << 32) | (uint32_t)pos;
@@ -896,8 +904,7 @@ __device__ __forceinline__ void featurize_indel_tile(const V5Args& v, const Scra
     // (bases 1..8 of the allele as ONE unaligned 8-byte load - the pool is padded by 16 bytes, api.hip: ugvc_upload_variants)
     const U2u abw = *reinterpret_cast<const U2u*>(apool + lo_off + 1);
     {
-        const uint4* src = reinterpret_cast<const uint4*>(a.ref + ws);
-        const uint4 x0 = src[0], x1 = src[1], x2 = src[2];
+        const uint4 x0 = load_window16(a.ref + ws), x1 = load_window16(a.ref + ws + 16), x2 = load_window16(a.ref + ws + 32);
         uint32_t w[kWinDw] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w};
         if (ws < clo || ws + kWinBytes > chi) {               // contig-edge lanes: bytes outside the contig read as N
 #pragma unroll
