@@ -31,7 +31,7 @@ int ensure(DeviceBuf& b, size_t bytes) {
 
 int upload(ugvc_ctx* ctx, DeviceBuf& b, const void* src, size_t bytes) {
     if (ensure(b, bytes)) return -1;
-    if (bytes) UGVC_HIP(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (bytes) UGVC_HIP(copy_in(ctx, b.p, src, bytes));
     return 0;
 }
 
@@ -168,6 +168,7 @@ int ugvc_ctx_destroy(ugvc_ctx* ctx) {
     ugvc_comm_destroy(ctx);
     pipe_destroy(ctx);
     v2_destroy(ctx);
+    bounce_destroy(ctx);
     DeviceBuf* all[] = {&ctx->ref, &ctx->contig_off, &ctx->runs_s, &ctx->runs_e, &ctx->runs_p, &ctx->runs_c, &ctx->bl, &ctx->bl_c,
                         &ctx->v_contig, &ctx->v_pos, &ctx->v_rl, &ctx->v_al, &ctx->v_ro, &ctx->v_ao,
                         &ctx->v_alleles, &ctx->v_qual, &ctx->v_sor, &ctx->v_dp, &ctx->v_adr, &ctx->v_ada,
@@ -237,11 +238,11 @@ int ugvc_selftest(ugvc_ctx* ctx, int64_t n) {
     int rc = 0;
     do {
         if ((rc = upload(ctx, d, h.data(), (size_t)n * 8))) break;
-        if (hipMemcpyAsync(back.data(), d.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        if (copy_out(ctx, back.data(), d.p, (size_t)n * 8) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = fail("selftest: copy round trip failed (device error)"); break; }
         if (memcmp(h.data(), back.data(), (size_t)n * 8)) { rc = fail("selftest: copy round trip returned different bytes"); break; }
         if ((rc = scan_u64(ctx, tmp, d.as<uint64_t>(), n, true))) break;
-        if (hipMemcpyAsync(back.data(), d.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        if (copy_out(ctx, back.data(), d.p, (size_t)n * 8) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = fail("selftest: scan kernel failed (device error)"); break; }
         uint64_t run = 0;
         for (int64_t i = 0; i < n && !rc; ++i) {
@@ -278,8 +279,7 @@ int ugvc_ref_upload(ugvc_ctx* ctx, const uint8_t* codes, int64_t total_len, cons
     if (ensure(ctx->ref, (size_t)total_len + 64 + kRefFrontPad)) return -1;
     UGVC_HIP(hipMemsetAsync(ctx->ref.p, 0, kRefFrontPad, ctx->stream));
     UGVC_HIP(hipMemsetAsync(static_cast<uint8_t*>(ctx->ref.p) + kRefFrontPad + total_len, 0, 64, ctx->stream));
-    if (total_len) UGVC_HIP(hipMemcpyAsync(static_cast<uint8_t*>(ctx->ref.p) + kRefFrontPad, codes, (size_t)total_len,
-                                           hipMemcpyHostToDevice, ctx->stream));
+    if (total_len) UGVC_HIP(copy_in(ctx, static_cast<uint8_t*>(ctx->ref.p) + kRefFrontPad, codes, (size_t)total_len));
     if (upload(ctx, ctx->contig_off, contig_off, sizeof(int64_t) * (n_contigs + 1))) return -1;
     UGVC_HIP(hipStreamSynchronize(ctx->stream));
     ctx->n_contigs = n_contigs;
@@ -526,9 +526,9 @@ int ugvc_results_download(ugvc_ctx* ctx, const ugvc_results* out) {
     UGVC_HIP(hipSetDevice(ctx->device));
     const size_t n = (size_t)ctx->n;
     if (n) {
-        if (out->tree_score) UGVC_HIP(hipMemcpyAsync(out->tree_score, ctx->r_score.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-        if (out->filter) UGVC_HIP(hipMemcpyAsync(out->filter, ctx->r_filter.p, n, hipMemcpyDeviceToHost, ctx->stream));
-        if (out->flags) UGVC_HIP(hipMemcpyAsync(out->flags, ctx->r_flags.p, n, hipMemcpyDeviceToHost, ctx->stream));
+        if (out->tree_score) UGVC_HIP(copy_out(ctx, out->tree_score, ctx->r_score.p, n * 4));
+        if (out->filter) UGVC_HIP(copy_out(ctx, out->filter, ctx->r_filter.p, n));
+        if (out->flags) UGVC_HIP(copy_out(ctx, out->flags, ctx->r_flags.p, n));
     }
     UGVC_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
@@ -709,8 +709,8 @@ int ugvc_feature_matrix(ugvc_ctx* ctx, float* x_host, uint8_t* group_host) {
     // the fused kernel's featurize waves (kernels_v5.hip, WX) when the side tables allow, else the universal kernel
     if (fm5_available(ctx) ? launch_feature_matrix_v5(ctx, a) : launch_filter(ctx, a, false, true)) return -1;
     if (n) {
-        UGVC_HIP(hipMemcpyAsync(x_host, ctx->x_mat.p, n * F * 4, hipMemcpyDeviceToHost, ctx->stream));
-        if (group_host) UGVC_HIP(hipMemcpyAsync(group_host, ctx->x_group.p, n, hipMemcpyDeviceToHost, ctx->stream));
+        UGVC_HIP(copy_out(ctx, x_host, ctx->x_mat.p, n * F * 4));
+        if (group_host) UGVC_HIP(copy_out(ctx, group_host, ctx->x_group.p, n));
     }
     UGVC_HIP(hipStreamSynchronize(ctx->stream));
     return 0;

@@ -211,9 +211,9 @@ int ugvc_gathered_download(ugvc_ctx* ctx, int64_t shard_cap, int world, const ug
     const int b = ctx->g_cur;
     if (ctx->g_score[b].cap < tot * 4) return fail("nothing gathered yet (ugvc_allgather_resident)");
     if (ugvc_gather_fence(ctx)) return -1;
-    if (out->tree_score) UGVC_HIP(hipMemcpyAsync(out->tree_score, ctx->g_score[b].p, tot * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (out->filter) UGVC_HIP(hipMemcpyAsync(out->filter, ctx->g_filter[b].p, tot, hipMemcpyDeviceToHost, ctx->stream));
-    if (out->flags) UGVC_HIP(hipMemcpyAsync(out->flags, ctx->g_flags[b].p, tot, hipMemcpyDeviceToHost, ctx->stream));
+    if (out->tree_score) UGVC_HIP(copy_out(ctx, out->tree_score, ctx->g_score[b].p, tot * 4));
+    if (out->filter) UGVC_HIP(copy_out(ctx, out->filter, ctx->g_filter[b].p, tot));
+    if (out->flags) UGVC_HIP(copy_out(ctx, out->flags, ctx->g_flags[b].p, tot));
     UGVC_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
 }

@@ -24,9 +24,12 @@
 #include <string.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <mutex>
+#include <thread>
 #include <unordered_map>
+#include <vector>
 
 #include "ugvc_device.hpp"
 
@@ -168,7 +171,7 @@ int lds_probe(ugvc_ctx* ctx, uint32_t* host_out, int n_wg) {
     if (ensure(d, (size_t)n_wg * 8 * 4)) return -1;
     UGVC_LAUNCH(lds_probe_kernel, dim3((unsigned)n_wg), dim3(1024), kLdsAll, ctx->stream, d.as<uint32_t>());
     int rc = 0;
-    if (hipMemcpyAsync(host_out, d.p, (size_t)n_wg * 8 * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+    if (copy_out(ctx, host_out, d.p, (size_t)n_wg * 8 * 4) != hipSuccess ||
         hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail("lds_probe: device error");
     dev_free(d.p);
     return rc;
@@ -236,6 +239,118 @@ void dev_free(void* p) {
     // returns the previous mapping's bytes; with the ranges kept the same suite is green).  A freed buffer therefore stays
     // unmapped for the life of the process - a use after free faults too.  48 bits of address space outlast any test run.
     if (env_int("UGVC_GUARD_OPTS", 0) & 2) (void)hipMemAddressFree(r.va, r.va_size);
+}
+
+// ---- host <-> device copies through the library's own pinned memory ------------------------------------------------
+// The library never asks the runtime to DMA from (or into) the caller's PAGEABLE memory: a copy of more than a staging buffer's
+// worth makes the runtime pin the caller's pages for the duration (a userptr mapping the kernel driver must keep valid while
+// the host's memory manager migrates, splits or frees pages under it - NUMA balancing moves a freshly written array as soon as
+// its thread is scheduled elsewhere).  Every copy goes through two pinned slots of the context instead: the CPU moves the
+// bytes between the caller's buffer and a slot (a few threads for large pieces), the DMA engine only ever sees pinned pages.
+// copy_in returns when the source is no longer referenced (the last piece may still be in flight on the context stream, in
+// order with everything queued before it); copy_out returns when the bytes are in the caller's buffer.
+constexpr size_t kBounceSlot = 16u << 20;
+struct Bounce {
+    void* slot[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool busy[2] = {false, false};
+    int next = 0;
+};
+
+static void host_copy(void* dst, const void* src, size_t n) {
+    const size_t kPar = 4u << 20;
+    unsigned t = n >= kPar ? std::min<unsigned>(4u, std::max(1u, std::thread::hardware_concurrency() / 2)) : 1u;
+    if (t <= 1) { memcpy(dst, src, n); return; }
+    std::vector<std::thread> th;
+    const size_t piece = (n / t + 63) & ~(size_t)63;
+    for (unsigned k = 1; k < t; ++k) {
+        const size_t a = std::min(n, k * piece), b = std::min(n, (k + 1) * piece);
+        if (b > a) th.emplace_back([=] { memcpy(static_cast<char*>(dst) + a, static_cast<const char*>(src) + a, b - a); });
+    }
+    memcpy(dst, src, std::min(n, piece));
+    for (auto& x : th) x.join();
+}
+
+static Bounce* bounce_of(ugvc_ctx* ctx) {
+    if (ctx->bounce) return static_cast<Bounce*>(ctx->bounce);
+    Bounce* b = new Bounce();
+    for (int k = 0; k < 2; ++k) {
+        if (hipHostMalloc(&b->slot[k], kBounceSlot, hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&b->ev[k], hipEventDisableTiming) != hipSuccess) {
+            for (int q = 0; q < 2; ++q) { if (b->slot[q]) (void)hipHostFree(b->slot[q]); if (b->ev[q]) (void)hipEventDestroy(b->ev[q]); }
+            delete b;
+            return nullptr;
+        }
+    }
+    ctx->bounce = b;
+    return b;
+}
+
+void bounce_destroy(ugvc_ctx* ctx) {
+    if (!ctx->bounce) return;
+    Bounce* b = static_cast<Bounce*>(ctx->bounce);
+    for (int k = 0; k < 2; ++k) {
+        if (b->busy[k]) (void)hipEventSynchronize(b->ev[k]);
+        (void)hipHostFree(b->slot[k]);
+        (void)hipEventDestroy(b->ev[k]);
+    }
+    delete b;
+    ctx->bounce = nullptr;
+}
+
+hipError_t copy_in(ugvc_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
+    if (!bytes) return hipSuccess;
+    Bounce* b = bounce_of(ctx);
+    if (!b) { set_error("cannot allocate the pinned staging slots"); return hipErrorOutOfMemory; }
+    for (size_t off = 0; off < bytes; off += kBounceSlot) {
+        const size_t len = std::min(kBounceSlot, bytes - off);
+        const int k = b->next;
+        b->next ^= 1;
+        if (b->busy[k]) {                                             // the slot's previous piece must have left it
+            const hipError_t e = hipEventSynchronize(b->ev[k]);
+            if (e != hipSuccess) return e;
+            b->busy[k] = false;
+        }
+        host_copy(b->slot[k], static_cast<const char*>(src_host) + off, len);
+        hipError_t e = hipMemcpyAsync(static_cast<char*>(dst_dev) + off, b->slot[k], len, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipEventRecord(b->ev[k], ctx->stream);
+        if (e != hipSuccess) return e;
+        b->busy[k] = true;
+    }
+    return hipSuccess;
+}
+
+hipError_t copy_out(ugvc_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes) {
+    if (!bytes) return hipSuccess;
+    Bounce* b = bounce_of(ctx);
+    if (!b) { set_error("cannot allocate the pinned staging slots"); return hipErrorOutOfMemory; }
+    size_t pend_off = 0, pend_len = 0;
+    int pend_k = -1;
+    auto drain = [&]() -> hipError_t {                                  // the piece in flight -> the caller's buffer
+        if (pend_k < 0) return hipSuccess;
+        const hipError_t e = hipEventSynchronize(b->ev[pend_k]);
+        if (e != hipSuccess) return e;
+        b->busy[pend_k] = false;
+        host_copy(static_cast<char*>(dst_host) + pend_off, b->slot[pend_k], pend_len);
+        pend_k = -1;
+        return hipSuccess;
+    };
+    for (size_t off = 0; off < bytes; off += kBounceSlot) {
+        const size_t len = std::min(kBounceSlot, bytes - off);
+        const int k = b->next;
+        b->next ^= 1;
+        if (b->busy[k]) {
+            if (k == pend_k) { const hipError_t e = drain(); if (e != hipSuccess) return e; }
+            else { const hipError_t e = hipEventSynchronize(b->ev[k]); if (e != hipSuccess) return e; b->busy[k] = false; }
+        }
+        hipError_t e = hipMemcpyAsync(b->slot[k], static_cast<const char*>(src_dev) + off, len, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipEventRecord(b->ev[k], ctx->stream);
+        if (e != hipSuccess) return e;
+        b->busy[k] = true;
+        if (pend_k >= 0) { e = drain(); if (e != hipSuccess) return e; }   // the previous piece, while this one is in flight
+        pend_k = k; pend_off = off; pend_len = len;
+    }
+    return drain();
 }
 
 bool debug_sync() { return getenv("UGVC_DEBUG_SYNC") != nullptr; }

@@ -399,10 +399,10 @@ int ugvc_pileup_tally(ugvc_ctx* ctx, const int64_t* offsets, const uint16_t* obs
         // 20 bytes per locus come back; dp, other and vaf are derived here (the caller's columns are 4 bytes wide)
         std::vector<uint16_t> c16(5 * n);
         if (n) {
-            if (out->bq_ref) UGVC_HIP(hipMemcpyAsync(out->bq_ref, o, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-            if (out->bq_alt) UGVC_HIP(hipMemcpyAsync(out->bq_alt, o + n, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-            if (out->sor) UGVC_HIP(hipMemcpyAsync(out->sor, o + 2 * n, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-            UGVC_HIP(hipMemcpyAsync(c16.data(), o + 3 * n, n * 10, hipMemcpyDeviceToHost, ctx->stream));
+            if (out->bq_ref) UGVC_HIP(copy_out(ctx, out->bq_ref, o, n * 4));
+            if (out->bq_alt) UGVC_HIP(copy_out(ctx, out->bq_alt, o + n, n * 4));
+            if (out->sor) UGVC_HIP(copy_out(ctx, out->sor, o + 2 * n, n * 4));
+            UGVC_HIP(copy_out(ctx, c16.data(), o + 3 * n, n * 10));
         }
         UGVC_HIP(hipStreamSynchronize(ctx->stream));
         int32_t* cols[4] = {out->ref_fwd, out->ref_rev, out->alt_fwd, out->alt_rev};
@@ -420,7 +420,7 @@ int ugvc_pileup_tally(ugvc_ctx* ctx, const int64_t* offsets, const uint16_t* obs
     void* dst[10] = {out->ref_fwd, out->ref_rev, out->alt_fwd, out->alt_rev, out->other,
                      out->dp, out->bq_ref, out->bq_alt, out->vaf, out->sor};
     for (int k = 0; k < 10; ++k)
-        if (dst[k] && n) UGVC_HIP(hipMemcpyAsync(dst[k], o + k * n, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (dst[k] && n) UGVC_HIP(copy_out(ctx, dst[k], o + k * n, n * 4));
     UGVC_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -453,8 +453,8 @@ int ugvc_sec_likelihood_ratio(ugvc_ctx* ctx, const int32_t* actual, const int32_
         rc = -1;
     if (!rc) rc = launch_sec(ctx, da.as<int32_t>(), de.as<int32_t>(), n_loci, k, dl.as<double>(), dr.as<double>());
     if (!rc && n_loci) {
-        if (hipMemcpyAsync(likelihood, dl.p, (size_t)n_loci * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-            hipMemcpyAsync(ratio, dr.p, (size_t)n_loci * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+        if (copy_out(ctx, likelihood, dl.p, (size_t)n_loci * 8) != hipSuccess ||
+            copy_out(ctx, ratio, dr.p, (size_t)n_loci * 8) != hipSuccess)
             rc = fail("D2H copy failed");
     }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc) rc = fail("stream sync failed");
@@ -491,8 +491,8 @@ int ugvc_bridging_snvs(ugvc_ctx* ctx, const ugvc_variants* v, const uint8_t* is_
         if (hipGetLastError() != hipSuccess) rc = fail("bridging kernel launch failed");
     }
     if (!rc) {
-        if (hipMemcpyAsync(out_hmer_snp, oh.p, n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-            hipMemcpyAsync(out_pass, op.p, n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+        if (copy_out(ctx, out_hmer_snp, oh.p, n) != hipSuccess ||
+            copy_out(ctx, out_pass, op.p, n) != hipSuccess)
             rc = fail("D2H copy failed");
     }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc) rc = fail("stream sync failed");

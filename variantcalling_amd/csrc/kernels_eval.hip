@@ -111,7 +111,7 @@ int ugvc_eval_counts(ugvc_ctx* ctx, const int8_t* label, const uint16_t* cat_bit
         const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, (int64_t)ctx->n_cus * 8);
         UGVC_LAUNCH(eval_counts_kernel, dim3(grid), dim3(256), 0, ctx->stream, ctx->r_filter.as<uint8_t>(),
                            d_lab.as<int8_t>(), d_cat.as<uint16_t>(), n, d_out.as<unsigned long long>());
-        if (hipMemcpyAsync(out, d_out.p, kEvalCats * 4 * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        if (copy_out(ctx, out, d_out.p, kEvalCats * 4 * 8) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = fail("eval_counts: device error"); break; }
     } while (0);
     for (DeviceBuf* b : {&d_lab, &d_cat, &d_out}) if (b->p) dev_free(b->p);
@@ -149,11 +149,11 @@ int ugvc_pr_curve(ugvc_ctx* ctx, const double* score, const uint8_t* cls, int64_
                            d_tf.as<uint64_t>(), n, initial_tp, initial_fp, initial_fn, o, o + N, o + 2 * N, o + 3 * N,
                            order ? d_ord.as<int32_t>() : nullptr);
         (void)hipEventRecord(e1, ctx->stream);
-        bool ok = hipMemcpyAsync(sorted_score, o, N * 8, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
-                  hipMemcpyAsync(recall, o + N, N * 8, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
-                  hipMemcpyAsync(precision, o + 2 * N, N * 8, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
-                  hipMemcpyAsync(f1, o + 3 * N, N * 8, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
-        if (ok && order) ok = hipMemcpyAsync(order, d_ord.p, N * 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+        bool ok = copy_out(ctx, sorted_score, o, N * 8) == hipSuccess &&
+                  copy_out(ctx, recall, o + N, N * 8) == hipSuccess &&
+                  copy_out(ctx, precision, o + 2 * N, N * 8) == hipSuccess &&
+                  copy_out(ctx, f1, o + 3 * N, N * 8) == hipSuccess;
+        if (ok && order) ok = copy_out(ctx, order, d_ord.p, N * 4) == hipSuccess;
         if (!ok || hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = fail("pr_curve: device error"); break; }
         if (ms_device) (void)hipEventElapsedTime(ms_device, e0, e1);
     } while (0);

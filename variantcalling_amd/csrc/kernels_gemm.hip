@@ -469,7 +469,7 @@ extern "C" int ugvc_forest_gemm(ugvc_ctx* ctx, int group, const int32_t* rows, i
                 UGVC_LAUNCH(forest_rows_kernel, dim3((unsigned)ctx->n_cus * 4), dim3(256), lds_tables, ctx->stream, ga);
                 if (kind == UGVC_MODEL_RF) UGVC_LAUNCH(forest_gemm2_kernel<true>, dim3((unsigned)ctx->n_cus * 2), dim3(kGemm2Threads), lds2, ctx->stream, gb);
                 else UGVC_LAUNCH(forest_gemm2_kernel<false>, dim3((unsigned)ctx->n_cus * 2), dim3(kGemm2Threads), lds2, ctx->stream, gb);
-                ran = hipMemcpyAsync(h.data(), dchk.p, (size_t)(2 * m) * 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                ran = copy_out(ctx, h.data(), dchk.p, (size_t)(2 * m) * 4) == hipSuccess &&
                       hipStreamSynchronize(ctx->stream) == hipSuccess && hipGetLastError() == hipSuccess;
             }
             dev_free(dchk.p);
@@ -510,7 +510,7 @@ extern "C" int ugvc_forest_gemm(ugvc_ctx* ctx, int group, const int32_t* rows, i
                 *ms_per_launch = ms / iters;
             }
         }
-        if (!rc && hipMemcpyAsync(margin_out, dout.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+        if (!rc && copy_out(ctx, margin_out, dout.p, (size_t)n * 4) != hipSuccess)
             rc = fail("D2H copy failed");
     }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc) rc = fail("stream sync failed");
@@ -535,7 +535,7 @@ extern "C" int ugvc_forest_gemm3(ugvc_ctx* ctx, const int32_t* const* rows, cons
     int rc = 0, kind_all = -1, t_max = 0;
     double work[UGVC_N_GROUPS] = {0, 0, 0}, tot = 0.0;
     if (ensure(dout, (size_t)std::max<int64_t>(ctx->n, 1) * 4)) rc = -1;
-    if (!rc && hipMemcpyAsync(dout.p, margin_out, (size_t)ctx->n * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = fail("H2D copy failed");
+    if (!rc && copy_in(ctx, dout.p, margin_out, (size_t)ctx->n * 4) != hipSuccess) rc = fail("H2D copy failed");
     for (int k = 0; k < UGVC_N_GROUPS && !rc; ++k) {
         if (n_rows[k] <= 0) continue;
         if (!rows[k]) { rc = fail("NULL row list"); break; }
@@ -597,8 +597,8 @@ extern "C" int ugvc_forest_gemm3(ugvc_ctx* ctx, const int32_t* const* rows, cons
                 UGVC_LAUNCH(forest_rows_kernel, dim3(8), dim3(256), lds_rows, ctx->stream, ga);
                 if (kind_all == UGVC_MODEL_RF) UGVC_LAUNCH(forest_gemm3_kernel<true>, dim3(4), dim3(kGemm2Threads), lds, ctx->stream, c3);
                 else UGVC_LAUNCH(forest_gemm3_kernel<false>, dim3(4), dim3(kGemm2Threads), lds, ctx->stream, c3);
-                ran = hipMemcpyAsync(h.data(), dchk.p, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
-                      hipMemcpyAsync(all.data(), dout.p, (size_t)ctx->n * 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                ran = copy_out(ctx, h.data(), dchk.p, (size_t)m * 4) == hipSuccess &&
+                      copy_out(ctx, all.data(), dout.p, (size_t)ctx->n * 4) == hipSuccess &&
                       hipStreamSynchronize(ctx->stream) == hipSuccess && hipGetLastError() == hipSuccess;
             }
             dev_free(dchk.p);
@@ -625,7 +625,7 @@ extern "C" int ugvc_forest_gemm3(ugvc_ctx* ctx, const int32_t* const* rows, cons
             }
         }
     }
-    if (!rc && ctx->n > 0 && hipMemcpyAsync(margin_out, dout.p, (size_t)ctx->n * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = fail("D2H copy failed");
+    if (!rc && ctx->n > 0 && copy_out(ctx, margin_out, dout.p, (size_t)ctx->n * 4) != hipSuccess) rc = fail("D2H copy failed");
     if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc) rc = fail("stream sync failed");
     for (int k = 0; k < UGVC_N_GROUPS; ++k)
         for (DeviceBuf* b : {&dn[k], &dl[k], &dr[k]}) dev_free(b->p);

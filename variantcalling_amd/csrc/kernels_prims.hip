@@ -200,7 +200,7 @@ int radix_sort_pairs_u64(ugvc_ctx* ctx, DeviceBuf& tmp, uint64_t* k0, uint64_t* 
     const unsigned cgrid = (unsigned)std::min<int64_t>((n + kSortThreads - 1) / kSortThreads, (int64_t)ctx->n_cus * 8);
     UGVC_LAUNCH(sort_census_kernel, dim3(cgrid), dim3(kSortThreads), 0, ctx->stream, k0, n, census);
     unsigned long long h[8 * 256];
-    UGVC_HIP(hipMemcpyAsync(h, census, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    UGVC_HIP(copy_out(ctx, h, census, sizeof(h)));
     UGVC_HIP(hipStreamSynchronize(ctx->stream));
     uint64_t* ki = k0; uint64_t* ko = k1;
     uint32_t* vi = v0; uint32_t* vo = v1;

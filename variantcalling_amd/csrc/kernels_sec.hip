@@ -382,7 +382,7 @@ int ugvc_sec_db_build(ugvc_ctx* ctx, const uint64_t* keys, const int32_t* counts
         UGVC_LAUNCH(sec_heads_kernel, dim3(grid), dim3(256), 0, ctx->stream, ks, n_obs, d_seg.as<uint64_t>());
         if ((rc = scan_u64(ctx, d_tmp, d_seg.as<uint64_t>(), n_obs, true))) break;
         uint64_t last = 0;
-        if (hipMemcpyAsync(&last, d_seg.as<uint64_t>() + (N - 1), 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        if (copy_out(ctx, &last, d_seg.as<uint64_t>() + (N - 1), 8) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = fail("sec_db_build: device error"); break; }
         n_unique = (int64_t)last;
         UGVC_LAUNCH(sec_segment_sum_kernel, dim3(grid), dim3(256), 0, ctx->stream, ks, is, d_seg.as<uint64_t>(), d_cnt.as<int32_t>(), n_obs, k,
@@ -390,9 +390,9 @@ int ugvc_sec_db_build(ugvc_ctx* ctx, const uint64_t* keys, const int32_t* counts
         UGVC_LAUNCH(sec_narrow_kernel, dim3((unsigned)((n_unique * k + 255) / 256)), dim3(256), 0, ctx->stream, d_sum.as<unsigned long long>(),
                            n_unique * k, d_out.as<int32_t>(), d_ovf.as<int>());
         int ovf = 0;
-        if (hipMemcpyAsync(out_keys, d_uk.p, (size_t)n_unique * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-            hipMemcpyAsync(out_expected, d_out.p, (size_t)n_unique * k * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-            hipMemcpyAsync(&ovf, d_ovf.p, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        if (copy_out(ctx, out_keys, d_uk.p, (size_t)n_unique * 8) != hipSuccess ||
+            copy_out(ctx, out_expected, d_out.p, (size_t)n_unique * k * 4) != hipSuccess ||
+            copy_out(ctx, &ovf, d_ovf.p, 4) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = fail("sec_db_build: device error"); break; }
         if (ovf) { rc = fail("a summed count exceeds int32"); break; }
         *out_n = n_unique;
@@ -480,8 +480,8 @@ int ugvc_sec_apply(ugvc_ctx* ctx, double min_ratio, int scale_expected, int mark
         }
         if (hipGetLastError() != hipSuccess) { rc = fail("sec_apply: launch failed"); break; }
         // (mark-only calls stay stream-ordered: nothing to wait for on the host)
-        if ((ratio && hipMemcpyAsync(ratio, d_r.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) ||
-            (is_sec && hipMemcpyAsync(is_sec, d_s.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) ||
+        if ((ratio && copy_out(ctx, ratio, d_r.p, (size_t)n * 8) != hipSuccess) ||
+            (is_sec && copy_out(ctx, is_sec, d_s.p, (size_t)n) != hipSuccess) ||
             ((ratio || is_sec) && hipStreamSynchronize(ctx->stream) != hipSuccess)) { rc = fail("sec_apply: device error"); break; }
     } while (0);
     for (DeviceBuf* b : {&d_r, &d_s}) if (b->p) dev_free(b->p);

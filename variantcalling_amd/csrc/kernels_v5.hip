@@ -2116,7 +2116,7 @@ int launch_filter_v5(ugvc_ctx* ctx, const FilterArgs& a) {
     UGVC_LAUNCH(fused5_for(a.n_tracks, (a.ablate & (1 << 28)) != 0), dim3(n_wg), dim3(v.n_waves * 64), lds_f, ctx->stream, v);
     if (want_clk) {
         std::vector<unsigned long long> h(wclk_bytes / 8);
-        UGVC_HIP(hipMemcpyAsync(h.data(), wclk_buf.p, wclk_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        UGVC_HIP(copy_out(ctx, h.data(), wclk_buf.p, wclk_bytes));
         UGVC_HIP(hipStreamSynchronize(ctx->stream));
         const unsigned long long* tail = h.data();
         // {100 MHz ticks, shader-clock ticks} between the entry and the end of workgroup 0's first wave

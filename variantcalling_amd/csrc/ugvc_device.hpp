@@ -141,6 +141,7 @@ struct ugvc_ctx {
     int gather_pending[2] = {0, 0};
     int rank = 0, world = 1;
     int kernel_variant = 0;
+    void* bounce = nullptr;         // ugvc::Bounce (devmem.hip): the two pinned slots every host <-> device copy goes through
     int clk_probe = 0;              // the next scoring passes leave their clock words (ugvc_pass_clock)
     unsigned long long clk_rt = 0, clk_sh = 0;   // 100 MHz ticks / shader-clock ticks across workgroup 0's first wave of the last probed pass
     int step_events = 1;            // ugvc_timed_steps: an event pair around every step (0: one pair around the run)
@@ -157,6 +158,9 @@ int dev_alloc(void** out, size_t bytes);          // devmem.hip: hipMalloc, or t
 void dev_free(void* p);
 void launch_note(const char* name, hipStream_t stream);   // breadcrumb ring (+ name on stderr under UGVC_DEBUG_SYNC; LDS poison under UGVC_POISON)
 void launch_done(const char* name, hipStream_t stream);
+hipError_t copy_in(ugvc_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);    // devmem.hip: through the context's pinned slots,
+hipError_t copy_out(ugvc_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);   // never a DMA on the caller's pageable memory
+void bounce_destroy(ugvc_ctx* ctx);
 int lds_probe(ugvc_ctx* ctx, uint32_t* host_out, int n_wg);   // devmem.hip: 8 words of unwritten LDS per workgroup
 int ensure(DeviceBuf& b, size_t bytes);
 int upload(ugvc_ctx* ctx, DeviceBuf& b, const void* src, size_t bytes);
