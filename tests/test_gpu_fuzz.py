@@ -1,12 +1,19 @@
 """Randomised differential test: every production kernel path against the oracle on callsets whose shape,
 side tables, parameters and model are drawn at random (seeded).  Complements the targeted cases of
 tests/test_gpu_parity.py: the bar is the same - bit-exact FILTER / flags / RF tree_score, 1e-6 on the XGBoost sigmoid."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 RF = "rf_model_ignore_gt_incl_hpol_runs"
 XGB = "xgb_model_ignore_gt_incl_hpol_runs"
+
+
+# UGVC_FUZZ_OFFSET=k: the same tests over OTHER random draws (every seed below is shifted by 100 000 k) - tools/gpu_suite.sh
+# `fuzzmore` runs a few offsets under the guard-page / poison allocation modes; the default suite is offset 0
+_OFF = 100_000 * int(os.environ.get("UGVC_FUZZ_OFFSET", "0"))
 
 
 def _draw(seed):
@@ -45,7 +52,7 @@ def _draw(seed):
 def test_random_configurations(engine, frozen_models, seed):
     from oracle import oracle as O
     from variantcalling_amd.engine import configure
-    cs, vt, runs, tracks, bl, flow, hp_len, hp_dist, model = _draw(1000 + seed)
+    cs, vt, runs, tracks, bl, flow, hp_len, hp_dist, model = _draw(_OFF + 1000 + seed)
     forests = frozen_models[model]
     if any(f is not None and f.n_features > 17 + len(tracks) for f in forests):
         tracks = list(cs.tracks)                              # the frozen models test all three track features
@@ -69,7 +76,7 @@ def test_random_pileups(engine, seed):
     """Pileup tally on random depth profiles (empty loci, single reads, loci far deeper than a wave's LDS span),
     one-sided strands (zero cells of the SOR table), every allele code and the full base-quality range."""
     from oracle import oracle as O
-    rng = np.random.default_rng(7000 + seed)
+    rng = np.random.default_rng(_OFF + 7000 + seed)
     n = int(rng.choice([1, 63, 64, 65, 1000, 30_000]))
     shape = rng.choice(["poisson", "geometric", "spiky"])
     if shape == "poisson":
@@ -148,7 +155,7 @@ def test_random_models(engine, small_callset, seed):
     from variantcalling_amd import schema as S
     from variantcalling_amd.engine import configure
     cs = small_callset
-    rng = np.random.default_rng(9000 + seed)
+    rng = np.random.default_rng(_OFF + 9000 + seed)
     kind = S.MODEL_RF if rng.random() < 0.7 else S.MODEL_GBT
     nf = 17 + len(cs.tracks)
     forests = []
@@ -189,7 +196,7 @@ def test_random_side_tables_and_clustered_variants(engine, small_callset, frozen
     from variantcalling_amd.io import bed
     cs = small_callset
     ref = cs.ref
-    rng = np.random.default_rng(11_000 + seed)
+    rng = np.random.default_rng(_OFF + 11_000 + seed)
     nc = ref.n_contigs
     clen = np.diff(ref.contig_off).astype(np.int64)
     n = int(rng.choice([300, 5_000, 30_000]))
@@ -275,7 +282,7 @@ def test_random_alleles_on_a_homopolymer_rich_reference(engine, frozen_models, s
     from oracle import oracle as O
     from variantcalling_amd import schema as S
     from variantcalling_amd.engine import configure
-    rng = np.random.default_rng(13_000 + seed)
+    rng = np.random.default_rng(_OFF + 13_000 + seed)
     nc = int(rng.choice([1, 3, 6]))
     parts = []
     for c in range(nc):

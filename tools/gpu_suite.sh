@@ -5,6 +5,9 @@
 #   guard2   ... every buffer's START behind an unmapped range
 #   poison   ... every new buffer filled with 0xA5 (no guard mapping)
 #   sync     ... plain allocator, every launch named and waited for
+#   ldsrand  the small GPU tests with other kinds of LDS garbage in front of every launch
+#   fuzzmore the randomised differential tests over three more sets of draws, under guard1 + poison
+#   quick    smoke first, then the canary and the small GPU tests (one lease's short form of `fresh`)
 # Logs: gpurun_out/<tag>_<mode>.txt (+ a one-line verdict per mode in gpurun_out/<tag>_summary.txt)
 set -u
 tag=$1; shift
@@ -44,6 +47,12 @@ for mode in "$@"; do
             echo "---- UGVC_POISON_LDS=$pat" >> $log
             UGVC_POISON=1 UGVC_POISON_LDS=$pat timeout 900 python -m pytest tests/test_00_gpu_canary.py tests/test_annotate.py tests/test_gpu_fuzz.py tests/test_gpu_sec.py tests/test_gpu_eval.py tests/test_gpu_pipelines.py -q -s -m gpu -p no:cacheprovider >> $log 2>&1
             echo "ldsrand $pat rc=$? :: $(grep -E 'passed|failed|Memory access fault' $log | tail -1 | cut -c1-160)" >> $sum
+        done ;;
+    fuzzmore) # the randomised differential tests over other draws, under the guard-end + poison mode
+        for k in 1 2 3; do
+            echo "---- UGVC_FUZZ_OFFSET=$k" >> $log
+            UGVC_FUZZ_OFFSET=$k UGVC_GUARD=1 UGVC_POISON=1 timeout 900 python -m pytest tests/test_gpu_fuzz.py -q -s -m gpu -p no:cacheprovider >> $log 2>&1
+            echo "fuzzmore offset $k (guard1 + poison) rc=$? :: $(grep -E 'passed|failed|Memory access fault' $log | tail -1 | cut -c1-160)" >> $sum
         done ;;
     guard1) per_file $log UGVC_GUARD=1 UGVC_POISON=1 UGVC_DEBUG_SYNC=1 ;;
     guard2) per_file $log UGVC_GUARD=2 UGVC_POISON=2 UGVC_DEBUG_SYNC=1 ;;

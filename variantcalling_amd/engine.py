@@ -119,6 +119,8 @@ def load_library(path: str = LIB_PATH):
         raise RuntimeError(
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C variantcalling_amd/csrc`.  There is no CPU fallback.")
+    # (multi-process GPU work on this stack needs dmabuf IPC: without it RCCL fails with `hipIpcGetMemHandle: invalid argument`)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
     for name, (res, args) in ABI.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing

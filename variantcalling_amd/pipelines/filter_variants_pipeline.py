@@ -163,7 +163,7 @@ def run(argv: list[str]):
             if info["nranks"] != grp.world or info["rank"] != grp.rank:
                 raise RuntimeError(f"RCCL communicator reports {info}, launcher says rank {grp.rank} of {grp.world}")
             lap("context + uploads (reference slice, table slices, model) + RCCL communicator")
-            cap = max(counts)
+            cap = -(-max(max(counts), 1) // 256) * 256          # (every rank's slot of the gather buffers 256-byte aligned: shard.shard_cap)
             eng.upload_variants(mine_r)
             eng.filter_resident()
             eng.allgather_resident(cap)

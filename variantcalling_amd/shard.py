@@ -25,8 +25,10 @@ def shard_bounds(n: int, world: int) -> np.ndarray:
 
 
 def shard_cap(n: int, world: int) -> int:
-    """Padded shard length used as the all-gather count (max shard size)."""
-    return int(-(-n // world))
+    """Padded shard length used as the all-gather count: the largest shard, rounded up to 256 rows - every rank's slot of the
+    three gather buffers (f32, u8, u8 at rank * cap elements) then starts on a 256-byte boundary, whatever RCCL's copy kernels
+    prefer, and the scoring pass writes its result columns to aligned bases."""
+    return int(-(-max(int(-(-n // world)), 1) // 256) * 256)
 
 
 def shard_of(vt: S.VariantTable, rank: int, world: int) -> S.VariantTable:
