@@ -210,7 +210,17 @@ def run_filter(args):
     gather = grp.world > 1
     if gather:
         uid = grp.broadcast_bytes(eng.comm_unique_id() if grp.rank == 0 else None, 0)
-        eng.comm_init(uid, grp.rank, grp.world)
+        # (RCCL prints a version banner on STDOUT when its first communicator comes up: this process's stdout is for ONE JSON
+        # line, so file descriptor 1 points at stderr for the duration of the call)
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            eng.comm_init(uid, grp.rank, grp.world)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
         rccl = eng.comm_info()                                   # what RCCL itself reports: a silent one-rank run cannot pass for N
         if rccl["nranks"] != grp.world or rccl["rank"] != grp.rank:
             raise SystemExit(f"RCCL communicator reports {rccl}, launcher says rank {grp.rank} of {grp.world}")
