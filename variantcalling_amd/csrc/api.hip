@@ -23,14 +23,21 @@ int ensure(DeviceBuf& b, size_t bytes) {
     dev_free(b.p);
     b.p = nullptr;
     b.cap = 0;
-    size_t want = std::max<size_t>(bytes, 256);
+    // (a table of a few bytes still gets 256 in production; under UGVC_GUARD it gets what was asked for, so that a read past a
+    // three-entry contig_ptr or a one-key blacklist faults as well)
+    size_t want = guard_on() ? std::max<size_t>(bytes, 1) : std::max<size_t>(bytes, 256);
     if (dev_alloc(&b.p, want)) { b.p = nullptr; return -1; }
     b.cap = want;
     return 0;
 }
 
 int upload(ugvc_ctx* ctx, DeviceBuf& b, const void* src, size_t bytes) {
-    if (ensure(b, bytes)) return -1;
+    // every uploaded table holds at least 16 bytes, zero where nothing was uploaded: the slice loads of the scoring pass clamp
+    // their row index into [0, max(rows - 1, 0)], i.e. they read row 0 of an EMPTY interval table / blacklist (the row is
+    // discarded: its contig's row range is empty).  Found by the byte-exact guard mode (UGVC_GUARD_ALIGN=1) on the CLI test
+    // with an empty runs file - the 256-byte floor of production allocations had been hiding it (round 5).
+    if (ensure(b, std::max<size_t>(bytes, 16))) return -1;
+    if (bytes < 16) UGVC_HIP(hipMemsetAsync(b.p, 0, 16, ctx->stream));
     if (bytes) UGVC_HIP(copy_in(ctx, b.p, src, bytes));
     return 0;
 }

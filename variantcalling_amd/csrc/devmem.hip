@@ -203,6 +203,8 @@ void on_abort(int) {
 
 }  // namespace
 
+bool guard_on() { return guard_mode() != 0; }
+
 int dev_alloc(void** out, size_t bytes) {
     const int mode = guard_mode(), poison = poison_mode();
     if (mode) return guard_alloc(out, bytes, mode, poison);

@@ -156,6 +156,7 @@ void set_error(const std::string& msg);
 int fail(const std::string& msg);
 int dev_alloc(void** out, size_t bytes);          // devmem.hip: hipMalloc, or the guarded / poisoned debug mappings (UGVC_GUARD, UGVC_POISON)
 void dev_free(void* p);
+bool guard_on();                                  // UGVC_GUARD is set (tests)
 void launch_note(const char* name, hipStream_t stream);   // breadcrumb ring (+ name on stderr under UGVC_DEBUG_SYNC; LDS poison under UGVC_POISON)
 void launch_done(const char* name, hipStream_t stream);
 hipError_t copy_in(ugvc_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);    // devmem.hip: through the context's pinned slots,
