@@ -333,3 +333,32 @@ def test_host_row_checks_name_the_first_offending_row(lib):
                 dst = np.full(ln + 200, 0xEE, np.uint8)
                 cs(dst.ctypes.data + 100 + da, src.ctypes.data + sa, ln)
                 assert np.array_equal(dst[100 + da:100 + da + ln], src[sa:sa + ln]) and dst[99 + da] == 0xEE and dst[100 + da + ln] == 0xEE
+
+
+def test_abort_names_the_last_launches_and_keeps_pythons_traceback():
+    """What a GPU memory fault leaves behind (the HSA runtime aborts the process): with UGVC_BREADCRUMB=1 the library's SIGABRT
+    handler prints the last kernel launches and then hands over to the handler that was there before - Python's faulthandler
+    under pytest, i.e. the traceback of the test.  No GPU needed: the launch bookkeeping is called directly, then abort()."""
+    code = r'''
+import os, sys, faulthandler, ctypes
+os.environ["UGVC_BREADCRUMB"] = "1"
+faulthandler.enable()
+sys.path.insert(0, %r)
+from variantcalling_amd import engine
+lib = engine.load_library()
+note = getattr(lib, "_ZN4ugvc11launch_noteEPKcP12ihipStream_t")
+note.argtypes = [ctypes.c_char_p, ctypes.c_void_p]
+note.restype = None
+names = [ctypes.c_char_p(("kernel_%%d" %% k).encode()) for k in range(11)]
+for n in names:
+    note(n, None)
+ctypes.CDLL(None).abort()
+''' % ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("UGVC_POISON", "UGVC_DEBUG_SYNC", "UGVC_GUARD")}
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode == -6, (p.returncode, p.stderr[-500:])
+    err = p.stderr
+    assert "[ugvc] process aborted; last kernel launches (oldest first):" in err
+    crumbs = [l.split()[-1] for l in err.splitlines() if l.startswith("[ugvc]   kernel_")]
+    assert crumbs == [f"kernel_{k}" for k in range(3, 11)]                  # the ring keeps the last eight, oldest first
+    assert err.index("[ugvc] process aborted") < err.index("Fatal Python error: Aborted")

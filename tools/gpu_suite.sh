@@ -32,11 +32,18 @@ per_file() {   # per_file <log> <env...>
 for mode in "$@"; do
     log=$out/${tag}_${mode}.txt; : > $log
     case $mode in
-    fresh)
-        timeout 600 python -c 'import __graft_entry__ as e; e.smoke(); print("__SMOKE_OK__")' >> $log 2>&1
-        echo "fresh smoke rc=$?" >> $sum
-        timeout 1500 python -m pytest tests/ -x -q -m gpu -p no:cacheprovider >> $log 2>&1
-        echo "fresh pytest rc=$? :: $(grep -E 'passed|failed' $log | tail -1)" >> $sum ;;
+    fresh)   # FRESH_ORDER=driver: pytest first, then smoke (the driver's order); default: smoke as the lease's first GPU process
+        if [ "${FRESH_ORDER:-smoke}" = driver ]; then
+            timeout 1500 python -m pytest tests/ -x -q -m gpu -p no:cacheprovider >> $log 2>&1
+            echo "fresh pytest (first GPU process) rc=$? :: $(grep -E 'passed|failed' $log | tail -1)" >> $sum
+            timeout 600 python -c 'import __graft_entry__ as e; e.smoke(); print("__SMOKE_OK__")' >> $log 2>&1
+            echo "fresh smoke rc=$?" >> $sum
+        else
+            timeout 600 python -c 'import __graft_entry__ as e; e.smoke(); print("__SMOKE_OK__")' >> $log 2>&1
+            echo "fresh smoke (first GPU process) rc=$?" >> $sum
+            timeout 1500 python -m pytest tests/ -x -q -m gpu -p no:cacheprovider >> $log 2>&1
+            echo "fresh pytest rc=$? :: $(grep -E 'passed|failed' $log | tail -1)" >> $sum
+        fi ;;
     quick)   # one lease's short form of the driver's sequence: smoke FIRST, then the canary and the small GPU tests
         timeout 600 python -c 'import __graft_entry__ as e; e.smoke(); print("__SMOKE_OK__")' >> $log 2>&1
         echo "quick smoke (first GPU process of the lease) rc=$?" >> $sum

@@ -185,6 +185,8 @@ const char* volatile g_ring[kRing];
 std::atomic<unsigned> g_ring_n{0};
 std::atomic<int> g_handler{0};
 
+struct sigaction g_prev_abort;
+
 void put(const char* s) { (void)!write(2, s, strlen(s)); }
 
 void on_abort(int) {
@@ -197,7 +199,8 @@ void on_abort(int) {
         put("\n");
     }
     if (n == 0) put("[ugvc]   (none: the fault is not from a kernel of this library)\n");
-    signal(SIGABRT, SIG_DFL);
+    // whoever handled SIGABRT before (Python's faulthandler under pytest: the traceback of the test) runs next
+    sigaction(SIGABRT, &g_prev_abort, nullptr);
     raise(SIGABRT);
 }
 
@@ -361,7 +364,16 @@ void launch_note(const char* name, hipStream_t stream) {
     if (const int pm = poison_mode()) (void)lds_poison(stream, pm);
     if (g_handler.load() == 0) {
         int expect = 0;
-        if (g_handler.compare_exchange_strong(expect, 1) && getenv("UGVC_BREADCRUMB")) signal(SIGABRT, on_abort);
+        if (g_handler.compare_exchange_strong(expect, 1) && getenv("UGVC_BREADCRUMB")) {
+            struct sigaction sa;
+            memset(&sa, 0, sizeof sa);
+            sa.sa_handler = on_abort;
+            sigemptyset(&sa.sa_mask);
+            sa.sa_flags = SA_NODEFER;                             // (the re-raised signal reaches the previous handler at once)
+            memset(&g_prev_abort, 0, sizeof g_prev_abort);
+            g_prev_abort.sa_handler = SIG_DFL;
+            (void)sigaction(SIGABRT, &sa, &g_prev_abort);
+        }
     }
     const unsigned k = g_ring_n.fetch_add(1);
     g_ring[k % kRing] = name;
