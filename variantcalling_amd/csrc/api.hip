@@ -241,9 +241,21 @@ int ugvc_selftest(ugvc_ctx* ctx, int64_t n) {
     UGVC_HIP(hipSetDevice(ctx->device));
     std::vector<uint64_t> h((size_t)n), back((size_t)n, ~0ull);
     for (int64_t i = 0; i < n; ++i) h[(size_t)i] = (uint64_t)((i * 2654435761ll) % 97);
-    DeviceBuf d, tmp;
+    DeviceBuf d, tmp, db;
     int rc = 0;
     do {
+        // a byte buffer with an odd tail first (8 n + n % 7 bytes): the pinned-slot copies split large pieces over threads
+        const size_t nb = (size_t)n * 8 + (size_t)(n % 7);
+        std::vector<uint8_t> hb(nb), bb(nb, 0xEE);
+        for (size_t i = 0; i < nb; ++i) hb[i] = (uint8_t)((i * 131u + (i >> 9)) & 0xFF);
+        if ((rc = upload(ctx, db, hb.data(), nb))) break;
+        if (copy_out(ctx, bb.data(), db.p, nb) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = fail("selftest: byte copy round trip failed (device error)"); break; }
+        if (memcmp(hb.data(), bb.data(), nb)) {
+            size_t at = 0;
+            while (at < nb && hb[at] == bb[at]) ++at;
+            rc = fail("selftest: byte copy round trip returned different bytes at offset " + std::to_string(at) + " of " + std::to_string(nb));
+            break;
+        }
         if ((rc = upload(ctx, d, h.data(), (size_t)n * 8))) break;
         if (copy_out(ctx, back.data(), d.p, (size_t)n * 8) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = fail("selftest: copy round trip failed (device error)"); break; }
@@ -259,6 +271,7 @@ int ugvc_selftest(ugvc_ctx* ctx, int64_t n) {
     } while (0);
     dev_free(d.p);
     dev_free(tmp.p);
+    dev_free(db.p);
     // under UGVC_POISON the harness itself is checked: a kernel that reads LDS it never wrote must see the pattern on every CU
     const char* pm = getenv("UGVC_POISON");
     const char* pl = getenv("UGVC_POISON_LDS");

@@ -267,7 +267,7 @@ static void host_copy(void* dst, const void* src, size_t n) {
     unsigned t = n >= kPar ? std::min<unsigned>(4u, std::max(1u, std::thread::hardware_concurrency() / 2)) : 1u;
     if (t <= 1) { memcpy(dst, src, n); return; }
     std::vector<std::thread> th;
-    const size_t piece = (n / t + 63) & ~(size_t)63;
+    const size_t piece = ((n + t - 1) / t + 63) & ~(size_t)63;     // (ceil: t pieces must cover n - a floor here lost the last n % t bytes)
     for (unsigned k = 1; k < t; ++k) {
         const size_t a = std::min(n, k * piece), b = std::min(n, (k + 1) * piece);
         if (b > a) th.emplace_back([=] { memcpy(static_cast<char*>(dst) + a, static_cast<const char*>(src) + a, b - a); });
