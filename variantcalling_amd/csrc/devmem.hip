@@ -31,6 +31,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "host_copy.hpp"
 #include "ugvc_device.hpp"
 
 namespace ugvc {
@@ -261,20 +262,6 @@ struct Bounce {
     bool busy[2] = {false, false};
     int next = 0;
 };
-
-static void host_copy(void* dst, const void* src, size_t n) {
-    const size_t kPar = 4u << 20;
-    unsigned t = n >= kPar ? std::min<unsigned>(4u, std::max(1u, std::thread::hardware_concurrency() / 2)) : 1u;
-    if (t <= 1) { memcpy(dst, src, n); return; }
-    std::vector<std::thread> th;
-    const size_t piece = ((n + t - 1) / t + 63) & ~(size_t)63;     // (ceil: t pieces must cover n - a floor here lost the last n % t bytes)
-    for (unsigned k = 1; k < t; ++k) {
-        const size_t a = std::min(n, k * piece), b = std::min(n, (k + 1) * piece);
-        if (b > a) th.emplace_back([=] { memcpy(static_cast<char*>(dst) + a, static_cast<const char*>(src) + a, b - a); });
-    }
-    memcpy(dst, src, std::min(n, piece));
-    for (auto& x : th) x.join();
-}
 
 static Bounce* bounce_of(ugvc_ctx* ctx) {
     if (ctx->bounce) return static_cast<Bounce*>(ctx->bounce);
