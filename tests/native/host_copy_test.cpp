@@ -1,5 +1,5 @@
 // tests/native/host_copy_test.cpp: csrc/host_copy.hpp - every byte of a copy arrives, nothing beyond it is written, for sizes around
-// the threading threshold and around multiples of 64 x threads (the shape that lost a buffer's tail), with 1 ... 7 threads.
+// the threading threshold and around multiples of 64 x threads (the shape that lost a buffer's tail), with 1 ... 9 threads.
 #include <stdint.h>
 #include <stdio.h>
 
@@ -11,7 +11,7 @@ int main() {
     std::vector<size_t> sizes = {0, 1, 63, 64, 65, 4095, 6239490, 6239488, 6239491, (4u << 20) - 1, 4u << 20, (4u << 20) + 1, (4u << 20) + 255,
                                  (4u << 20) + 256, (4u << 20) + 257, 5000000, 8388608 + 3, 1559872 * 4 + 1, 1559872 * 4 + 2, 1559872 * 4 + 3};
     for (size_t n : sizes)
-        for (unsigned t = 0; t <= 7; ++t) {
+        for (unsigned t = 0; t <= 9; ++t) {
             std::vector<uint8_t> src(n + 64), dst(n + 64, 0xEE);
             for (size_t i = 0; i < src.size(); ++i) src[i] = (uint8_t)((i * 131u + (i >> 9)) & 0xFF);
             host_copy(dst.data(), src.data(), n, t);

@@ -20,7 +20,9 @@ inline void host_copy_cuts(size_t n, unsigned t, std::vector<size_t>& cuts) {
 }
 
 inline unsigned host_copy_threads(size_t n) {
-    return n >= kHostCopyParallelFrom ? std::min<unsigned>(4u, std::max(1u, std::thread::hardware_concurrency() / 2)) : 1u;
+    // (eight threads saturate one socket's copy bandwidth on the MI355X hosts: the 3.1 GB reference upload of the CLI is bound by
+    // this copy, not by the link; a small host gets half its cores)
+    return n >= kHostCopyParallelFrom ? std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency() / 2)) : 1u;
 }
 
 inline void host_copy(void* dst, const void* src, size_t n, unsigned threads = 0) {
