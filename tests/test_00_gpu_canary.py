@@ -9,8 +9,8 @@ import pytest
 def test_device_canary_copies_and_computes(engine):
     info = engine.device_info()
     print("canary device:", info, flush=True)
-    assert "gfx950" in info["name"], f"not an MI355X: {info}"
-    assert info["n_cus"] >= 64 and info["hbm_bytes"] > (64 << 30)
+    assert "gfx950" in info["name"], f"not a gfx950 device (the library holds gfx950 code only): {info}"
+    assert info["n_cus"] >= 1 and info["hbm_bytes"] > 0          # (a partitioned device - fewer CUs, less memory - is still a usable one)
     # (the large sizes: copies above 4 MB are split over host threads - 8 n + n % 7 bytes with n / 4 not a whole number of
     # 64-byte lines, the shape that lost a buffer's last two bytes in the first version of the pinned-slot copies)
     for n in (1, 63, 64, 65, 1024, 100_003, 524_289, 779_936, (1 << 20) + 3, (2 << 20) + 5):
