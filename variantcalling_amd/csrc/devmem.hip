@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "host_copy.hpp"
+#include "host_pool.hpp"
 #include "ugvc_device.hpp"
 
 namespace ugvc {
@@ -261,6 +262,33 @@ struct Bounce {
     hipEvent_t ev[2] = {nullptr, nullptr};
     bool busy[2] = {false, false};
     int next = 0;
+    HostPool* pool = nullptr;       // the copy threads of large pieces (host_pool.hpp: the chunk pipeline's pool class), made on first use
+};
+
+// a piece between the caller's buffer and a slot: the context's copy pool once it is large enough (host_copy.hpp has the cuts;
+// starting threads per 16 MB piece cost more than the copy: ~80 ms of a 3.1 GB reference upload)
+static void piece_copy(Bounce* b, void* dst, const void* src, size_t n) {
+    const unsigned t = host_copy_threads(n);
+    if (t <= 1) { memcpy(dst, src, n); return; }
+    if (!b->pool) b->pool = new HostPool((int)t - 1);
+    const int parts = b->pool->size();
+    std::vector<size_t> cuts;
+    host_copy_cuts(n, (unsigned)parts, cuts);
+    const std::function<void(int)> job = [&](int k) {
+        const size_t a = cuts[(size_t)k], e = cuts[(size_t)k + 1];
+        if (e > a) memcpy(static_cast<char*>(dst) + a, static_cast<const char*>(src) + a, e - a);
+    };
+    b->pool->parallel_for(parts, job);
+}
+
+// (inside a copy of several pieces the pool's workers poll for the next piece instead of sleeping: HostPool::burst)
+struct BurstScope {
+    Bounce* b; bool on;
+    BurstScope(Bounce* bb, size_t bytes) : b(bb), on(bytes > kBounceSlot) {
+        if (on && !b->pool && host_copy_threads(kBounceSlot) > 1) b->pool = new HostPool((int)host_copy_threads(kBounceSlot) - 1);
+        if (on && b->pool) b->pool->burst(true);
+    }
+    ~BurstScope() { if (on && b->pool) b->pool->burst(false); }
 };
 
 static Bounce* bounce_of(ugvc_ctx* ctx) {
@@ -286,6 +314,7 @@ void bounce_destroy(ugvc_ctx* ctx) {
         (void)hipHostFree(b->slot[k]);
         (void)hipEventDestroy(b->ev[k]);
     }
+    delete b->pool;
     delete b;
     ctx->bounce = nullptr;
 }
@@ -294,6 +323,7 @@ hipError_t copy_in(ugvc_ctx* ctx, void* dst_dev, const void* src_host, size_t by
     if (!bytes) return hipSuccess;
     Bounce* b = bounce_of(ctx);
     if (!b) { set_error("cannot allocate the pinned staging slots"); return hipErrorOutOfMemory; }
+    BurstScope burst(b, bytes);
     for (size_t off = 0; off < bytes; off += kBounceSlot) {
         const size_t len = std::min(kBounceSlot, bytes - off);
         const int k = b->next;
@@ -303,7 +333,7 @@ hipError_t copy_in(ugvc_ctx* ctx, void* dst_dev, const void* src_host, size_t by
             if (e != hipSuccess) return e;
             b->busy[k] = false;
         }
-        host_copy(b->slot[k], static_cast<const char*>(src_host) + off, len);
+        piece_copy(b, b->slot[k], static_cast<const char*>(src_host) + off, len);
         hipError_t e = hipMemcpyAsync(static_cast<char*>(dst_dev) + off, b->slot[k], len, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipEventRecord(b->ev[k], ctx->stream);
         if (e != hipSuccess) return e;
@@ -316,6 +346,7 @@ hipError_t copy_out(ugvc_ctx* ctx, void* dst_host, const void* src_dev, size_t b
     if (!bytes) return hipSuccess;
     Bounce* b = bounce_of(ctx);
     if (!b) { set_error("cannot allocate the pinned staging slots"); return hipErrorOutOfMemory; }
+    BurstScope burst(b, bytes);
     size_t pend_off = 0, pend_len = 0;
     int pend_k = -1;
     auto drain = [&]() -> hipError_t {                                  // the piece in flight -> the caller's buffer
@@ -323,7 +354,7 @@ hipError_t copy_out(ugvc_ctx* ctx, void* dst_host, const void* src_dev, size_t b
         const hipError_t e = hipEventSynchronize(b->ev[pend_k]);
         if (e != hipSuccess) return e;
         b->busy[pend_k] = false;
-        host_copy(static_cast<char*>(dst_host) + pend_off, b->slot[pend_k], pend_len);
+        piece_copy(b, static_cast<char*>(dst_host) + pend_off, b->slot[pend_k], pend_len);
         pend_k = -1;
         return hipSuccess;
     };
