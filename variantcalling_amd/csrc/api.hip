@@ -181,7 +181,7 @@ int ugvc_ctx_destroy(ugvc_ctx* ctx) {
                         &ctx->v_alleles, &ctx->v_qual, &ctx->v_sor, &ctx->v_dp, &ctx->v_adr, &ctx->v_ada,
                         &ctx->v_gq, &ctx->r_score, &ctx->r_filter, &ctx->r_flags, &ctx->x_mat, &ctx->x_group,
                         &ctx->pl_off, &ctx->pl_off32, &ctx->pl_obsb, &ctx->pl_out, &ctx->sec_keys, &ctx->sec_coarse, &ctx->sec_exp, &ctx->sec_lgtab, &ctx->g_score[0], &ctx->g_filter[0], &ctx->g_flags[0],
-                        &ctx->g_score[1], &ctx->g_filter[1], &ctx->g_flags[1]};
+                        &ctx->g_score[1], &ctx->g_filter[1], &ctx->g_flags[1], &ctx->wclk_buf};
     for (auto* b : all) release(*b);
     for (int t = 0; t < UGVC_MAX_TRACKS; ++t) {
         release(ctx->trk_s[t]);
@@ -642,7 +642,7 @@ int ugvc_pass_clock(ugvc_ctx* ctx, int passes, double* shader_ghz, double* wave_
     ctx->clk_probe = 0;
     if (rc) return -1;
     UGVC_HIP(hipStreamSynchronize(ctx->stream));
-    if (!ctx->clk_rt || !ctx->clk_sh) return fail("ugvc_pass_clock: no clock words came back (no rows resident?)");
+    if (!ctx->clk_rt || !ctx->clk_sh) return fail("ugvc_pass_clock: no clock words came back (no rows resident, or the pass did not run the v5 kernel)");
     *shader_ghz = (double)ctx->clk_sh / ((double)ctx->clk_rt * 10.0);
     if (wave_ms) *wave_ms = (double)ctx->clk_rt * 1e-5;
     return 0;

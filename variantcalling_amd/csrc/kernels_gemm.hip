@@ -34,6 +34,7 @@ struct GemmArgs {
     int T, kind;
     float base;
     float* out;                // margin per evaluated row
+    int out_by_row = 0;        // forest_rows_kernel: the margin of evaluated row i goes to out[rows[i]] (what forest_gemm3_kernel does) instead of out[i]
 };
 
 __device__ __forceinline__ int path_entry(int i, int l) {          // C[i][l], node i = heap index - 1
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(256) void forest_rows_kernel(const GemmArgs g) {
             }
             margin += leaves[t * 64 + idx - 64];
         }
-        g.out[i] = margin;
+        g.out[g.out_by_row ? src : i] = margin;
     }
 }
 
@@ -451,8 +452,15 @@ extern "C" int ugvc_forest_gemm(ugvc_ctx* ctx, int group, const int32_t* rows, i
         // 32 feature registers (UGVC_PRED_ASM: checked in the listing of THIS build, not guaranteed by the compiler).  First use per
         // process: the margins of up to 512 rows against the scalar kernel's, bit for bit; on a mismatch the round-1 MFMA kernel
         // (LDS gathers, no register indexing) serves every later call and stderr says so once.
-        static std::atomic<int> gemm2_state{0};                  // 0 unchecked, 1 agrees, 2 differs
-        if (v2 && gemm2_state.load() == 0 && lds_tables <= 156 * 1024) {
+        // (one state PER INSTANTIATION: <true> (RF) and <false> are separately compiled kernels with their own register allocation -
+        // validating one says nothing about the other)
+        static std::atomic<int> gemm2_states[2];                 // 0 unchecked, 1 agrees, 2 differs, 3 could not be checked (said once)
+        std::atomic<int>& gemm2_state = gemm2_states[kind == UGVC_MODEL_RF ? 1 : 0];
+        if (v2 && gemm2_state.load() == 0 && lds_tables > 156 * 1024) {
+            fprintf(stderr, "[ugvc] forest_gemm2_kernel: the scalar kernel's tables (%zu B) do not fit LDS - the register-indexed predicates of this build run UNCHECKED\n", lds_tables);
+            gemm2_state.store(3);
+        }
+        if (v2 && gemm2_state.load() == 0) {
             const int64_t m = std::min<int64_t>(n, 512);
             DeviceBuf dchk;
             std::vector<float> h((size_t)(2 * m));
@@ -577,9 +585,14 @@ extern "C" int ugvc_forest_gemm3(ugvc_ctx* ctx, const int32_t* const* rows, cons
         // first use per process: this kernel shares forest_gemm2_kernel's register-indexed predicates (UGVC_PRED_ASM relies on
         // where the compiler put the row's feature registers) - up to 512 rows of the largest group against the scalar traversal,
         // bit for bit; a build on which they differ fails HERE, loudly, instead of returning margins (ugvc_forest_gemm serves then)
-        static std::atomic<int> gemm3_state{0};                  // 0 unchecked, 1 agrees, 2 differs
+        static std::atomic<int> gemm3_states[2];                 // per instantiation: 0 unchecked, 1 agrees, 2 differs, 3 could not be checked (said once)
+        std::atomic<int>& gemm3_state = gemm3_states[kind_all == UGVC_MODEL_RF ? 1 : 0];
         const size_t lds_rows = (size_t)a3.g[big].T * 64 * 12;
-        if (!rc && gemm3_state.load() == 0 && lds_rows <= 156 * 1024) {
+        if (!rc && gemm3_state.load() == 0 && lds_rows > 156 * 1024) {
+            fprintf(stderr, "[ugvc] forest_gemm3_kernel: the scalar traversal's tables (%zu B) do not fit LDS - the register-indexed predicates of this build run UNCHECKED\n", lds_rows);
+            gemm3_state.store(3);
+        }
+        if (!rc && gemm3_state.load() == 0) {
             const int64_t m = std::min<int64_t>(a3.g[big].n, 512);
             DeviceBuf dchk;
             std::vector<float> h((size_t)m), all((size_t)ctx->n);
@@ -605,12 +618,36 @@ extern "C" int ugvc_forest_gemm3(ugvc_ctx* ctx, const int32_t* const* rows, cons
             if (ran) {
                 bool same = true;
                 for (int64_t i = 0; i < m && same; ++i) same = memcmp(&h[(size_t)i], &all[(size_t)rows[big][i]], 4) == 0;
+                if (getenv("UGVC_GEMM3_FORCE_MISMATCH")) same = false;      // (tests: the fallback below)
                 gemm3_state.store(same ? 1 : 2);
+                if (!same) fprintf(stderr, "[ugvc] forest_gemm3_kernel disagrees with the scalar traversal on this build (register-indexed predicates): "
+                                           "the traversal (forest_rows_kernel, one launch per group) serves ugvc_forest_gemm3\n");
             }
         }
-        if (!rc && gemm3_state.load() == 2)
-            rc = fail("forest_gemm3_kernel disagrees with the scalar traversal on this build (register-indexed predicates): use ugvc_forest_gemm");
-        if (!rc) {
+        // A build on which the register-indexed predicates read the wrong registers (a compiler update moved the row's feature
+        // vector) must not brick config C5's default path: the scalar traversal - bit-identical margins by construction, one launch
+        // per group, ~15 % slower - serves every later call (round 5 failed loudly here).
+        if (!rc && gemm3_state.load() == 2) {
+            for (int k = 0; k < UGVC_N_GROUPS && !rc; ++k)
+                if (a3.g[k].n > 0 && (size_t)a3.g[k].T * 64 * 12 > 156 * 1024) rc = fail("ensemble too large for the LDS-resident traversal");
+            if (!rc && hipFuncSetAttribute(reinterpret_cast<const void*>(forest_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess)
+                rc = fail("cannot raise the dynamic LDS limit");
+            if (!rc && hipEventRecord(ctx->ev0, ctx->stream) != hipSuccess) rc = fail("event record failed");
+            for (int it = 0; it < iters && !rc; ++it)
+                for (int k = 0; k < UGVC_N_GROUPS; ++k)
+                    if (a3.g[k].n > 0) {
+                        GemmArgs gk = a3.g[k];
+                        gk.out_by_row = 1;
+                        UGVC_LAUNCH(forest_rows_kernel, dim3((unsigned)ctx->n_cus * 4), dim3(256), (size_t)gk.T * 64 * 12, ctx->stream, gk);
+                    }
+            if (!rc && (hipEventRecord(ctx->ev1, ctx->stream) != hipSuccess || hipEventSynchronize(ctx->ev1) != hipSuccess || hipGetLastError() != hipSuccess))
+                rc = fail("forest traversal launch failed");
+            if (!rc && ms_per_launch) {
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+                *ms_per_launch = ms / iters;
+            }
+        } else if (!rc) {
             if (hipEventRecord(ctx->ev0, ctx->stream) != hipSuccess) rc = fail("event record failed");
             for (int it = 0; it < iters && !rc; ++it) {
                 if (kind_all == UGVC_MODEL_RF) UGVC_LAUNCH(forest_gemm3_kernel<true>, dim3((unsigned)end), dim3(kGemm2Threads), lds, ctx->stream, a3);

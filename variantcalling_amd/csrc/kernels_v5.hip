@@ -1499,6 +1499,15 @@ __device__ __forceinline__ int tile_cut(bool& live, uint32_t& i, IndelCols& k) {
     return n0;
 }
 
+// The pass clock's end words (ugvc_pass_clock): left by workgroup 0's first wave on EVERY way out - also when it has no tiles, or
+// works on indel tiles (an indel-only first workgroup): round 5 wrote them on the SNP path alone and the probe then failed with
+// "no clock words came back" (ADVICE r5).
+__device__ __forceinline__ void pass_clock_end(const V5Args& v) {
+    if (!v.wave_clk) return;
+    v.wave_clk[1] = __builtin_amdgcn_s_memrealtime();
+    v.wave_clk[3] = __builtin_readcyclecounter();
+}
+
 // ---- Kf: persistent, one workgroup per CU; every wave works through tiles on its own --------------------
 // A workgroup owns `rows_wg` consecutive rows of the callset.  Prologue (the only workgroup barriers): the forest
 // and the threshold tables go to LDS while every wave counts the variant classes of its sixteenth of the rows; the
@@ -1700,7 +1709,7 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
     if (wave >= n_sw) {
         const int q = (nit + n_iw - 1) / n_iw;
         const int t0 = (wave - n_sw) * q, t1 = min(t0 + q, nit);
-        if (t0 >= t1) return;
+        if (t0 >= t1) { if (blockIdx.x == 0 && wave == 0 && lane == 0) pass_clock_end(v); return; }
         const uint64_t wclk_first = v.wave_clk ? __builtin_readcyclecounter() : 0;
         PhaseClk pc{};
 #ifdef UGVC_PHASE_CLOCK
@@ -1763,6 +1772,7 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
         if (v.wave_clk && lane == 0) {
             unsigned long long* w = v.wave_clk + 4 + ((size_t)blockIdx.x * 16 + wave) * 4;
             w[0] = wclk_entry; w[1] = wclk_first; w[2] = __builtin_readcyclecounter(); w[3] = (unsigned long long)n_done | ((unsigned long long)n_done << 32);
+            if (blockIdx.x == 0 && wave == 0) pass_clock_end(v);   // (an indel-only first workgroup: wave 0 works on indel tiles)
         }
 #ifdef UGVC_PHASE_CLOCK
         if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 133))
@@ -1788,7 +1798,7 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
         brk_refresh<NT>(a, b2, rfl((int)a.contig[b_row]), rfl(a.pos[b_row]), lane);
         brk_publish<NT>(L.gtab_b + 512u, b2, lane);
     }
-    if (t0 >= t1) return;
+    if (t0 >= t1) { if (blockIdx.x == 0 && wave == 0 && lane == 0) pass_clock_end(v); return; }
     const uint64_t wclk_first = v.wave_clk ? __builtin_readcyclecounter() : 0;
     // this wave's entries of the workgroup's SNP list; a tile = up to 64 of them from an offset (tile_cut)
     const int e0 = rfl(tile_off(t0, tb_s, b_s)), e1 = rfl(min(tile_off(t1, tb_s, b_s), (int)ns_l));
@@ -1864,10 +1874,7 @@ __global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
     if (v.wave_clk && lane == 0) {
         unsigned long long* w = v.wave_clk + 4 + ((size_t)blockIdx.x * 16 + wave) * 4;
         w[0] = wclk_entry; w[1] = wclk_first; w[2] = __builtin_readcyclecounter(); w[3] = (unsigned long long)n_done;
-        if (blockIdx.x == 0 && wave == 0) {
-            v.wave_clk[1] = __builtin_amdgcn_s_memrealtime();
-            v.wave_clk[3] = __builtin_readcyclecounter();
-        }
+        if (blockIdx.x == 0 && wave == 0) pass_clock_end(v);
     }
 #ifdef UGVC_PHASE_CLOCK
     if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 133))
@@ -2102,7 +2109,7 @@ int launch_filter_v5(ugvc_ctx* ctx, const FilterArgs& a) {
     // UGVC_WAVE_CLK=<file>: every wave of the fused kernel leaves its entry / first-tile / end clocks and its tile counts; the
     // buffer of the LAST pass is written to the file (tools/wave_clk.py reads it).  Waits for every pass: profiling only.
     static const char* wclk_path = getenv("UGVC_WAVE_CLK");
-    static DeviceBuf wclk_buf;
+    DeviceBuf& wclk_buf = ctx->wclk_buf;                              // (per context, freed with it: ADVICE r5)
     const size_t wclk_bytes = (size_t)((a.n + v.rows_wg - 1) / v.rows_wg) * 16 * 4 * 8 + 32;     // (+ the pass clock words)
     const bool want_clk = wclk_path || ctx->clk_probe;
     if (want_clk) {

@@ -144,6 +144,7 @@ struct ugvc_ctx {
     void* bounce = nullptr;         // ugvc::Bounce (devmem.hip): the two pinned slots every host <-> device copy goes through
     int clk_probe = 0;              // the next scoring passes leave their clock words (ugvc_pass_clock)
     unsigned long long clk_rt = 0, clk_sh = 0;   // 100 MHz ticks / shader-clock ticks across workgroup 0's first wave of the last probed pass
+    ugvc::DeviceBuf wclk_buf;       // the clock words of a probed pass (ugvc_pass_clock, UGVC_WAVE_CLK): per context, freed with it
     int step_events = 1;            // ugvc_timed_steps: an event pair around every step (0: one pair around the run)
     std::vector<float> step_ms;     // per-step kernel times of the last ugvc_timed_steps
     void* v2 = nullptr;             // ugvc::V2State (model_pack.hip)

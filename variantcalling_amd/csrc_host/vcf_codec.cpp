@@ -1210,12 +1210,14 @@ static int write_filtered_impl(const ugvc_vcf* h, const char* out_path, const fl
     // it is compressed.  (Round 4: format + gather were 0.17 s of the 5 M-record write-back's 0.45 s, in front of 0.26 s of deflate.)
     // (the per-thread text buffers and the two gather buffers live across the batches: fresh ones were ~90 MB of first-touch
     // page faults per batch, taken under the address-space lock that the compressing threads' allocations want too)
-    JoinedThread flusher_guard;
-    std::thread& flusher = flusher_guard.t;
     std::vector<std::string> part;
     std::unique_ptr<char[]> gbuf[2];
     size_t gcap[2] = {0, 0};
     int gsel = 0;
+    // (declared AFTER everything the flusher reads: locals unwind in reverse order, so on an exception - a bad_alloc for the next
+    // batch's buffer - the guard joins the helper thread BEFORE the gather buffers it is deflating from are freed)
+    JoinedThread flusher_guard;
+    std::thread& flusher = flusher_guard.t;
     for (int64_t b0 = 0; b0 < n && io_ok; b0 += batch) {
         const int64_t b1 = std::min(n, b0 + batch);
         const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(threads, (b1 - b0) / 1024));

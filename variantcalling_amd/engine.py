@@ -333,14 +333,20 @@ class Engine:
                 if a.dtype != dt or a.shape != (vt.n,) or not a.flags.c_contiguous or not a.flags.writeable:
                     raise ValueError("out: need writable C-contiguous tree_score f32 / filter u8 / flags u8 arrays of vt.n rows")
             res, cr = out, CResults(_p(out.tree_score, _f32p), _p(out.filter, _u8p), _p(out.flags, _u8p))
-        self._check(self.lib.ugvc_filter_variants(self._h, C.byref(cv), C.byref(cr)))
-        self.n = vt.n
+        # (the C side leaves the context EMPTY on any failed upload / boundary call: the cached row count follows what is
+        # resident on every way out, so that a later download / feature_matrix cannot size its buffers by a stale count - ADVICE r5)
+        try:
+            self._check(self.lib.ugvc_filter_variants(self._h, C.byref(cv), C.byref(cr)))
+        finally:
+            self.n = self.resident_count()[0]
         return res
 
     def upload_variants(self, vt: S.VariantTable):
         cv = self._cvariants(vt)
-        self._check(self.lib.ugvc_variants_upload(self._h, C.byref(cv)))
-        self.n = vt.n
+        try:
+            self._check(self.lib.ugvc_variants_upload(self._h, C.byref(cv)))
+        finally:
+            self.n = self.resident_count()[0]
 
     def filter_resident(self):
         self._check(self.lib.ugvc_filter_resident(self._h))
@@ -520,9 +526,11 @@ class Engine:
         prm = CBridgingParams(min_initial_qual, min_tumor_vaf, max_normal_vaf, min_query_hmer_size,
                               min_normal_depth, min_distance_from_edge)
         oh, op = np.zeros(vt.n, np.uint8), np.zeros(vt.n, np.uint8)
-        self._check(self.lib.ugvc_bridging_snvs(self._h, C.byref(cv), _p(ip, _u8p), _p(a, _i32p), _p(b, _i32p),
-                                                _p(d, _i32p), C.byref(prm), _p(oh, _u8p), _p(op, _u8p)))
-        self.n = vt.n
+        try:
+            self._check(self.lib.ugvc_bridging_snvs(self._h, C.byref(cv), _p(ip, _u8p), _p(a, _i32p), _p(b, _i32p),
+                                                    _p(d, _i32p), C.byref(prm), _p(oh, _u8p), _p(op, _u8p)))
+        finally:
+            self.n = self.resident_count()[0]
         return oh.astype(bool), op.astype(bool)
 
     # ---- multi-GPU
