@@ -195,8 +195,10 @@ def run_filter(args):
     if grp.rank == 0 and grp.world == 1 and args.cpu_sample > 0:
         cpu = cpu_baseline(cs, forests, min(args.cpu_sample, n_total))       # before the GPU context: forks
         cpu["host_cores_available"] = os.cpu_count()
-    mine = shard.shard_of(cs.variants, grp.rank, grp.world)
-    cap = shard.shard_cap(n_total, grp.world)
+    # (cuts snapped to a contig change where that costs < 1 % imbalance: shard.shard_bounds - every rank holds the whole callset here)
+    bounds = shard.shard_bounds(n_total, grp.world, cs.variants.contig)
+    mine = cs.variants.slice(int(bounds[grp.rank]), int(bounds[grp.rank + 1]))
+    cap = shard.shard_cap(n_total, grp.world, bounds)
 
     eng = Engine(grp.local_rank)
     info = eng.device_info()
@@ -285,7 +287,7 @@ def run_filter(args):
                                        and np.array_equal(res.tree_score[a:b_], exp.tree_score))
                 checked_rows += b_ - a
     if gather:
-        b = shard.shard_bounds(n_total, grp.world)
+        b = bounds
         allr = eng.gathered_download(cap, grp.world, [int(b[r + 1] - b[r]) for r in range(grp.world)])
         lo = int(b[grp.rank])
         ok = bool(allr.filter.size == n_total and np.array_equal(allr.filter[lo:lo + mine.n], res.filter)

@@ -113,7 +113,7 @@ int ugvc_vcf_set_deflate(int backend);
  * everything else 0, line ends dropped.  `--runs_file` / `--annotate_intervals`
  * (/root/reference/docs/filter_variants_pipeline.md:30-33,45-46): one (contig index, start, end) row per data line
  * whose contig is in `contig_names`, 0-based half-open; interval_list files (an '@' header line, or the file
- * extension) are 1-based inclusive and converted.  Sorting / merging stays with the caller.  Semantics are those
+ * extension) are 1-based inclusive and converted.  ugvc_intervals_track sorts / merges.  Semantics are those
  * of variantcalling_amd/io/fasta.py and bed.py (tests/test_vcf_native.py compares). */
 typedef struct ugvc_fasta ugvc_fasta;
 typedef struct ugvc_fasta_view {
@@ -138,7 +138,26 @@ typedef struct ugvc_intervals_view {
 int ugvc_intervals_read(const char* path, const char* const* contig_names, int n_contigs, int n_threads,
                         ugvc_intervals** out);
 int ugvc_intervals_get_view(const ugvc_intervals* h, ugvc_intervals_view* view);
+/* The finished track of the rows read (round 6; replaces the numpy post-processing of variantcalling_amd/io/bed.py:
+ * track_from_arrays, which stays as its checker): rows ordered by (contig, start, end), rows with end <= start dropped,
+ * with `merge` != 0 overlapping / nested / book-ended rows of a contig folded into one (a new interval opens where a start
+ * lies beyond every end seen so far), 32-bit coordinates, ptr[c] .. ptr[c + 1] = the rows of contig c (n_contigs + 1 entries)
+ * - the layout ugvc_runs_upload / ugvc_track_upload take (include/ugvc_mi355x.h).  The view lives as long as the handle. */
+typedef struct ugvc_track_view {
+    int64_t n;
+    const int32_t* start;
+    const int32_t* end;
+    const int32_t* ptr;
+} ugvc_track_view;
+int ugvc_intervals_track(ugvc_intervals* h, int n_contigs, int merge, ugvc_track_view* view);
 void ugvc_intervals_free(ugvc_intervals* h);
+
+/* The codec's file reader, bare: a plain / gzip / BGZF file -> its (inflated) bytes, BGZF members one block per thread through
+ * the selected deflate back end (ugvc_vcf_set_deflate) - what htslib's bgzf_read delivers.  For tools and for the parity test on
+ * a real htslib stream (tests/test_htslib_bgzf.py).  `*data` lives until ugvc_blob_free. */
+typedef struct ugvc_blob ugvc_blob;
+int ugvc_bgzf_read(const char* path, int n_threads, ugvc_blob** out, const char** data, int64_t* len);
+void ugvc_blob_free(ugvc_blob* b);
 
 /* Shortest decimal string that round-trips the f32 (fixed notation, at least one fractional digit):
  * the TREE_SCORE formatter, exposed for the parity test against numpy.format_float_positional. */

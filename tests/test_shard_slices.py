@@ -55,6 +55,50 @@ def test_sliced_context_on_real_hg38_edges(frozen_models):
                   int(b[r]), int(b[r + 1]), f"edges world {world} rank {r}")
 
 
+def test_cuts_snap_to_a_contig_change_within_one_percent(frozen_models):
+    """a cut moves to a contig's first row when that keeps every shard within 1 % of the equal share; cuts
+    without such a neighbour stay equal-count; the snapped shards still reassemble to the whole callset."""
+    # the plain cut is untouched without the column, with one contig, or when no change is near
+    assert shard.shard_bounds(1000, 4).tolist() == [0, 250, 500, 750, 1000]
+    assert shard.shard_bounds(1000, 4, np.zeros(1000, np.uint16)).tolist() == [0, 250, 500, 750, 1000]
+    far = np.repeat(np.arange(2, dtype=np.uint16), [400, 600])            # change at row 400: 100 rows from the nearest cut
+    assert shard.shard_bounds(1000, 4, far).tolist() == [0, 250, 500, 750, 1000]
+    # changes 2 rows before the first cut and 1 row behind the last one: both snap; the middle cut has no neighbour
+    near = np.repeat(np.arange(3, dtype=np.uint16), [248, 503, 249])       # changes at rows 248 and 751
+    assert shard.shard_bounds(1000, 4, near).tolist() == [0, 248, 500, 751, 1000]
+    assert shard.shard_cap(1000, 4, shard.shard_bounds(1000, 4, near)) == 256 and shard.shard_cap(1000, 4) == 256
+    # one row beyond the 1 % slack (2.5 rows of a 250-row share): stays
+    out = np.repeat(np.arange(2, dtype=np.uint16), [246, 754])
+    assert shard.shard_bounds(1000, 4, out).tolist() == [0, 250, 500, 750, 1000]
+    # properties on random columns: monotone, ends fixed, every shard within (1 + tol) of the share, a moved cut IS a change
+    rng = np.random.default_rng(2)
+    for _ in range(200):
+        n, world = int(rng.integers(1, 5000)), int(rng.integers(1, 9))
+        contig = np.sort(rng.integers(0, int(rng.integers(1, 30)), n)).astype(np.uint16)
+        plain, b = shard.shard_bounds(n, world), shard.shard_bounds(n, world, contig)
+        assert b[0] == 0 and b[-1] == n and np.all(np.diff(b) >= 0)
+        assert np.max(np.diff(b)) <= n / world * 1.01 + 1
+        for r in np.flatnonzero(b != plain):
+            assert contig[b[r]] != contig[b[r] - 1]
+        assert shard.shard_cap(n, world, b) >= np.max(np.diff(b)) and shard.shard_cap(n, world, b) % 256 == 0
+    # end to end: a callset whose second contig starts 3 rows behind the middle; the two snapped shards score like the whole
+    cs = synth.make_callset(6_000, genome_len=3_000_000, n_contigs=2, seed=9)
+    vt = cs.variants
+    change = int(np.flatnonzero(vt.contig[1:] != vt.contig[:-1])[0]) + 1
+    k = min(change - 3, vt.n - change + 3)                                 # 2 k rows with the change at row k + 3
+    vt = vt.slice(change - k - 3, change + k - 3)
+    assert vt.n == 2 * k and k > 1000
+    b = shard.shard_bounds(vt.n, 2, vt.contig)
+    assert b[1] == vt.n // 2 + 3 and vt.contig[b[1]] != vt.contig[b[1] - 1]
+    forests = frozen_models[RF]
+    full = O.filter_variants(vt, cs.ref, cs.runs, cs.tracks, cs.blacklist, forests)
+    for r in range(2):
+        mine = shard.shard_of(vt, r, 2, snap=True)
+        assert mine.n == int(b[r + 1] - b[r]) and np.unique(mine.contig).size == 1      # neither rank carries the boundary
+        ref_s, runs_s, tracks_s, bl_s, mine_s = shard.slice_context(cs.ref, cs.runs, cs.tracks, cs.blacklist, mine)
+        _same(O.filter_variants(mine_s, ref_s, runs_s, tracks_s, bl_s, forests), full, int(b[r]), int(b[r + 1]), f"snapped rank {r}")
+
+
 def test_empty_shard_and_missing_tables():
     cs = synth.make_callset(500, genome_len=400_000, n_contigs=2, seed=5)
     empty = cs.variants.slice(0, 0)

@@ -324,6 +324,37 @@ def test_interval_reader_matches_the_python_reference(tmp_path):
         nv.read_intervals(badp, names)
 
 
+def test_native_track_equals_the_numpy_statement_on_random_rows(tmp_path):
+    """ugvc_intervals_track (round 6: sort check / stable sort, empty rows dropped, merge by the running maximum of the ends,
+    row range per contig - in C++) against bed.track_from_arrays on the SAME tokenised rows: sorted, shuffled, nested, book-ended,
+    duplicated, zero-length and reversed intervals, contigs without rows, both merge modes."""
+    names = [f"chr{k}" for k in range(1, 8)]
+    rng = np.random.default_rng(11)
+    for trial in range(12):
+        n = int(rng.integers(0, 4000))
+        c = rng.integers(0, 6, n)                                 # (chr7 never has rows: an empty contig at the end)
+        s = rng.integers(0, 5000 if trial % 2 else 200_000, n)    # dense trials: plenty of overlap and nesting
+        ln = rng.integers(-2, 60, n)                              # end <= start for some rows
+        e = s + ln
+        if trial % 3 == 0:                                        # a sorted file, as a rule
+            o = np.lexsort((e, s, c))
+            c, s, e = c[o], s[o], e[o]
+        if trial == 5:                                            # book-ended rows
+            s = np.arange(n) * 10
+            e = s + 10
+            c = np.zeros(n, np.int64)
+        p = str(tmp_path / f"r{trial}.bed")
+        with open(p, "w") as fh:
+            for k in range(n):
+                fh.write(f"{names[int(c[k])]}\t{int(s[k])}\t{int(e[k])}\n")
+        for merge in (True, False):
+            a = nv.read_intervals(p, names, merge=merge, native_track=False)
+            b = nv.read_intervals(p, names, merge=merge)
+            assert np.array_equal(a.starts, b.starts) and np.array_equal(a.ends, b.ends), (trial, merge)
+            assert np.array_equal(a.contig_ptr, b.contig_ptr) and a.name == b.name
+            assert b.starts.dtype == np.int32 and b.contig_ptr.dtype == np.int32 and b.contig_ptr.size == len(names) + 1
+
+
 def _random_vcf(rng, n):
     nums = ["0", "1", "7", "42", "1e2", "1E-3", ".5", "5.", "+3", "-2", "nan", "NaN", "inf", "-Inf", "Infinity", ".", "", "abc",
             " 12", "12 ", "1_0", "0x10", "1e400", "-1e400", "1,2", "00012", "3.99", "-0.0", "2147483648", "-2147483649", "1e-320",

@@ -38,6 +38,10 @@ class _IntervalsView(C.Structure):
     _fields_ = [("n", C.c_int64), ("contig", C.c_void_p), ("start", C.c_void_p), ("end", C.c_void_p)]
 
 
+class _TrackView(C.Structure):
+    _fields_ = [("n", C.c_int64), ("start", C.c_void_p), ("end", C.c_void_p), ("ptr", C.c_void_p)]
+
+
 _COUNT_HOOK = C.CFUNCTYPE(None, C.c_int64, C.c_int64, C.c_void_p)
 
 
@@ -81,8 +85,14 @@ def load_library():
         lib.ugvc_intervals_read.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         lib.ugvc_intervals_get_view.restype = C.c_int
         lib.ugvc_intervals_get_view.argtypes = [C.c_void_p, C.POINTER(_IntervalsView)]
+        lib.ugvc_intervals_track.restype = C.c_int
+        lib.ugvc_intervals_track.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(_TrackView)]
         lib.ugvc_intervals_free.restype = None
         lib.ugvc_intervals_free.argtypes = [C.c_void_p]
+        lib.ugvc_bgzf_read.restype = C.c_int
+        lib.ugvc_bgzf_read.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        lib.ugvc_blob_free.restype = None
+        lib.ugvc_blob_free.argtypes = [C.c_void_p]
         _lib = lib
     return _lib
 
@@ -265,26 +275,45 @@ def read_fasta(path: str, contigs: list | None = None, n_threads: int = 0) -> S.
     return S.Reference(codes, off, names)
 
 
-def read_intervals(path: str, contig_names: list, merge: bool = True, n_threads: int = 0) -> S.IntervalTrack:
-    """io.bed.read_intervals through the native tokeniser; sorting / merging as in bed.track_from_arrays."""
+def read_intervals(path: str, contig_names: list, merge: bool = True, n_threads: int = 0, native_track: bool = True) -> S.IntervalTrack:
+    """io.bed.read_intervals through the native tokeniser AND the native sort / merge (ugvc_intervals_track, round 6);
+    `native_track=False`: the rows go through bed.track_from_arrays instead - its checker (tests/test_vcf_native.py)."""
     from . import bed
     lib = load_library()
     names = (C.c_char_p * len(contig_names))(*[n.encode() for n in contig_names])
+    stem = os.path.basename(path)
+    for suf in (".gz", ".bed", ".interval_list"):
+        if stem.endswith(suf):
+            stem = stem[: -len(suf)]
     h = C.c_void_p()
     if lib.ugvc_intervals_read(os.fsencode(path), names, len(contig_names), int(n_threads), C.byref(h)):
         raise ValueError(_err(lib))
     try:
+        if native_track:
+            t = _TrackView()
+            if lib.ugvc_intervals_track(h, len(contig_names), int(bool(merge)), C.byref(t)):
+                raise ValueError(_err(lib))
+            n = int(t.n)
+            return S.IntervalTrack(_arr(t.start, n, np.int32), _arr(t.end, n, np.int32), _arr(t.ptr, len(contig_names) + 1, np.int32), stem)
         v = _IntervalsView()
         lib.ugvc_intervals_get_view(h, C.byref(v))
         n = int(v.n)
         c, s, e = _arr(v.contig, n, np.int64), _arr(v.start, n, np.int64), _arr(v.end, n, np.int64)
     finally:
         lib.ugvc_intervals_free(h)
-    stem = os.path.basename(path)
-    for suf in (".gz", ".bed", ".interval_list"):
-        if stem.endswith(suf):
-            stem = stem[: -len(suf)]
     return bed.track_from_arrays(c, s, e, len(contig_names), stem, merge)
+
+
+def bgzf_read(path: str, n_threads: int = 0) -> bytes:
+    """The (inflated) bytes of a plain / gzip / BGZF file through the codec's own reader (ugvc_bgzf_read) - htslib's bgzf_read."""
+    lib = load_library()
+    h, data, n = C.c_void_p(), C.c_void_p(), C.c_int64()
+    if lib.ugvc_bgzf_read(os.fsencode(path), int(n_threads), C.byref(h), C.byref(data), C.byref(n)):
+        raise ValueError(_err(lib))
+    try:
+        return C.string_at(data, n.value) if n.value else b""
+    finally:
+        lib.ugvc_blob_free(h)
 
 
 def set_deflate(backend: str = "auto") -> str:
