@@ -36,7 +36,8 @@ ALG_BYTES_C2 = 107.6       # SNV-only
 ALG_BYTES_PILEUP = 84.0    # B/locus
 ALG_BYTES_SEC = 26.0       # B/call: key 8 + counts 12 + depth columns / flags 6
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec
-MFMA_I8_PEAK_TOPS = 5000.0  # dense int8 = the fp8 rate (MI355X_MICROARCH.md)
+MFMA_I8_PEAK_TOPS = 3944.0  # dense int8 MFMA: "≥ 3 944 TOPS measured" (MI355X_MICROARCH.md) - the guide's figure;
+MFMA_I8_SPEC_TOPS = 5000.0  # the datasheet's dense fp8 / int8 rate, reported beside it
 MODEL = "rf_model_ignore_gt_incl_hpol_runs"
 PASS_KERNELS = ("one scoring pass = fused5_kernel + forest5_kernel "
                 "(csrc/kernels_v5.hip; HIP events around the two launches on the context stream)")
@@ -174,6 +175,113 @@ def _device_clock_ghz(eng):
 
 def _pct(ms, q):
     return float(np.percentile(ms, q)) if len(ms) else None
+
+
+def other_workloads(eng, cs, forests_rf, budget_s=40.0):
+    """Bounded measurements of the OTHER workloads inside the default run (the driver runs only `bench.py --gpus 1`,
+    so C2 / C5 / pileup / SEC-apply had no driver-timed line): each a few launches behind the headline's timed region, HIP events
+    on the context stream, the same kernels and algorithmic bytes as `--workload <w>` reports; nothing here touches the headline
+    keys.  A measurement that fails or would overrun the budget is reported as such, never raised."""
+    from variantcalling_amd import model_io, synth
+    from variantcalling_amd.engine import configure
+    t_begin = time.perf_counter()
+    out = {}
+
+    def left():
+        return budget_s - (time.perf_counter() - t_begin)
+
+    def guarded(name, f):
+        if left() <= 0:
+            out[name] = dict(skipped=f"budget of {budget_s:.0f} s spent")
+            return
+        t0 = time.perf_counter()
+        try:
+            out[name] = f()
+            out[name]["wall_s"] = round(time.perf_counter() - t0, 2)
+        except Exception as e:                                   # noqa: BLE001 - the headline line must still be printed
+            out[name] = dict(error=repr(e)[:300])
+
+    # ---- SEC apply on the resident calls (the 5 M calls of the headline pass are resident and scored)
+    def sec():
+        rng = np.random.default_rng(0)
+        vk = cs.variants.keys()
+        loci = np.unique(vk[rng.random(vk.size) < 0.4])
+        keys = loci[rng.integers(0, loci.size, 4_000_000)]
+        counts = rng.integers(0, 60, size=(keys.size, 3)).astype(np.int32)
+        db_k, db_e = eng.sec_db_build(keys, counts)
+        eng.set_sec_db(db_k, db_e)
+        eng.timed_sec_apply(2)
+        ms = eng.timed_sec_apply(10) / 10
+        gbps = ALG_BYTES_SEC * cs.variants.n / (ms * 1e-3) / 1e9
+        return dict(ms=ms, frac=gbps / HBM_PEAK_GBPS, achieved_gbps=gbps, bound="hbm", units=cs.variants.n, database_loci=int(db_k.size),
+                    traffic=_traffic("sec_apply", cs.variants.n)[0], kernel="sec_apply_tiles_kernel<false, 3, 512>")
+    guarded("sec_apply", sec)
+
+    # ---- config C5 on the first 2 M calls of the same callset: feature build, leaf-matrix GEMM (one launch), row traversal
+    def c5():
+        xgb = model_io.load_models(os.path.join(ROOT, "tests", "golden", "synth_rf_v1.npz"))["xgb_model_ignore_gt_incl_hpol_runs"]
+        sub = cs.variants.slice(0, min(2_000_000, cs.variants.n))
+        eng.set_models(xgb)
+        eng.upload_variants(sub)
+        X, group = eng.feature_matrix()
+        N, F = X.shape
+        eng.timed_feature_matrix(2)
+        fm_ms = eng.timed_feature_matrix(5)
+        fm_bytes = ALG_BYTES_C3 + 4.0 * F
+        fm_gbps = fm_bytes * N / (fm_ms * 1e-3) / 1e9
+        rows_g = [np.flatnonzero(group == g).astype(np.int32) for g in range(3)]
+        m3, gemm_ms = eng.forest_gemm3(rows_g, iters=5)
+        trav_ms, same = 0.0, True
+        for g in range(3):
+            b, ms_b = eng.forest_gemm(g, rows_g[g], use_mfma=0, iters=3)
+            trav_ms += ms_b
+            same &= bool(np.array_equal(m3[rows_g[g]], b))
+        tops = 2.0 * 64 * 64 * 100 * N / (gemm_ms * 1e-3) / 1e12
+        return dict(units=N, feature_build=dict(ms=fm_ms, frac=fm_gbps / HBM_PEAK_GBPS, achieved_gbps=fm_gbps, bound="hbm",
+                                               traffic=_traffic("c5_feature_build", N)[0]),
+                    gemm3=dict(ms=gemm_ms, achieved_tops=tops, frac=tops / MFMA_I8_PEAK_TOPS, frac_of_spec_5000=tops / MFMA_I8_SPEC_TOPS, bound="mfma"),
+                    traversal_ms=trav_ms, gemm_equals_traversal=same)
+    guarded("c5", c5)
+
+    # ---- config C2: 1 M SNV-only callset, the scoring pass (its own genome-sized tables)
+    def c2():
+        from oracle import oracle as O
+        cs2 = synth.make_callset(1_000_000, snv_only=True)
+        configure(eng, cs2.ref, cs2.runs, cs2.tracks, cs2.blacklist, forests_rf, "TGCA", 10, 10, True)
+        eng.upload_variants(cs2.variants)
+        eng.timed_steps(60, 0, False)
+        tot, _ = eng.timed_steps(20, 0, False, per_step_events=False)
+        ms = tot / 20
+        gbps = ALG_BYTES_C2 * cs2.variants.n / (ms * 1e-3) / 1e9
+        eng.filter_resident()
+        res = eng.download_results()
+        k = 20_000
+        exp = O.filter_variants(cs2.variants.slice(0, k), cs2.ref, cs2.runs, cs2.tracks, cs2.blacklist, forests_rf)
+        ok = bool(np.array_equal(res.filter[:k], exp.filter) and np.array_equal(res.flags[:k], exp.flags) and np.array_equal(res.tree_score[:k], exp.tree_score))
+        return dict(ms=ms, frac=gbps / HBM_PEAK_GBPS, achieved_gbps=gbps, bound="hbm", units=cs2.variants.n,
+                    traffic=_traffic("c2", cs2.variants.n)[0], oracle_rows_bit_exact=ok, oracle_rows_checked=k)
+    guarded("c2", c2)
+
+    # ---- a11 pileup tally: 2 M loci x ~30 observations
+    def pileup():
+        from oracle import oracle as O
+        n_loci = 2_000_000
+        off, obs = synth.make_pileup(n_loci, seed=5)
+        eng.upload_pileup(off, obs)
+        eng.timed_pileup(2)
+        ms = eng.timed_pileup(10) / 10
+        gbps = ALG_BYTES_PILEUP * n_loci / (ms * 1e-3) / 1e9
+        exp = O.pileup_tally(off[:2001], obs[:off[2000]])
+        got = eng.pileup_tally(off[:2001], obs[:off[2000]])
+        ok = all(np.array_equal(got[k], exp[k]) for k in ("ref_fwd", "ref_rev", "alt_fwd", "alt_rev", "other", "dp", "bq_ref", "bq_alt"))
+        return dict(ms=ms, frac=gbps / HBM_PEAK_GBPS, achieved_gbps=gbps, bound="hbm", units=n_loci, observations=int(obs.size),
+                    traffic=None, oracle_slice_bit_exact=bool(ok))
+    guarded("pileup", pileup)
+    out["seconds"] = round(time.perf_counter() - t_begin, 1)
+    out["what"] = ("bounded measurements of the other workloads behind the headline's timed region (same kernels, same algorithmic bytes as "
+                   "`bench.py --workload <w>`; fewer launches, smaller pileup); frac = of the 8 TB/s HBM roofline, gemm3 of the 3 944 TOP/s "
+                   "the guide measures for dense int8 MFMA")
+    return out
 
 
 def run_filter(args):
@@ -367,7 +475,7 @@ def run_filter(args):
                         f"intervals), {cs.blacklist.size / 1e6:.1f}M-locus blacklist, "
                         "RF 40 trees depth 8 x 3 groups, F=20; fused featurize+lookup+score+FILTER, inputs resident in HBM",
                         variants_per_gpu=mine.n, model=MODEL, sharding=f"equal-count x{grp.world}"
-                        + (", per-rank genome / side-table slices" if grp.world > 1 else ""),
+                        + (", cuts snapped to a contig change within 1 %, per-rank genome / side-table slices" if grp.world > 1 else ""),
                         collective="RCCL all-gather (score f32, filter u8, flags u8)" if gather else "none",
                         rccl_nranks=rccl["nranks"] if rccl else 1,
                         device=info["name"], kernel_variant=args.variant, commit=_git_head()),
@@ -382,10 +490,13 @@ def run_filter(args):
                                             "per-pass event pairs of the warm-up steps and the last 40 spin-up passes (untimed)"),
                           alg_bytes_per_variant=alg, variants_per_launch=mine.n,
                           issue_bound=issue),
-            e2e_incl_pcie=e2e, spinup=ramp,
+            e2e_incl_pcie=e2e, spinup=ramp, other_workloads=None,
             parity=dict(oracle_slice_bit_exact=check, oracle_rows_checked=checked_rows, gather_consistent=ok_all,
                         gathered_all_rows_bit_exact=gathered_ok),
             setup_s=round(t_setup, 1), cpu_baseline=cpu)
+        # the other workloads (the driver's default run only): behind everything the headline keys are made of
+        if grp.world == 1 and not args.no_other and not snv_only and args.variant == 0:
+            out["other_workloads"] = other_workloads(eng, cs, forests)
         print(json.dumps(out), flush=True)
     eng.close()
     grp.close()
@@ -548,7 +659,7 @@ def run_c5(args):
                       "groups; HIP events around the launches", kernel_ms=tot_gemm, round4_kernel_ms_three_launches=tot_gemm2,
                round1_kernel_ms=tot_gemm_r1,
                alg_ops_per_variant=2.0 * I * L * T, traversal_ms=tot_trav, traversal_variants_per_s=N / (tot_trav * 1e-3),
-               tops_vs_measured_i8_ceiling=tops / 3944.0,
+               frac_of_spec_5000=tops / MFMA_I8_SPEC_TOPS,
                feature_build=dict(bound="hbm", ms=fm_ms, achieved=fm_gbps, peak=HBM_PEAK_GBPS, unit="GB/s", frac=fm_gbps / HBM_PEAK_GBPS,
                                   alg_bytes_per_variant=fm_bytes, traffic=_traffic("c5_feature_build", N)[0],
                                   kernel="fused5_kernel<3, 16, true> via ugvc_feature_matrix (resident N x F f32, no download)")),
@@ -568,6 +679,7 @@ def main():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--cpu-sample", type=int, default=100_000, help="variants timed on the single-process CPU baseline (0 = skip)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive measurement")
+    ap.add_argument("--no-other", action="store_true", help="skip the bounded measurements of the other workloads (`other_workloads`)")
     ap.add_argument("--spinup", type=int, default=150,
                     help="untimed passes before the warm-up steps: brings the GPU to its sustained clock (reported in `spinup`; 0 = none)")
     ap.add_argument("--check-rows", type=int, default=5000,

@@ -36,6 +36,46 @@ class FakeEngine:
     def reserve(self, n_variants, alleles_len):               # (Engine.reserve: allocations only)
         assert n_variants >= 0 and alleles_len >= 0
 
+    # ---- the per-table setters of the single-process tool (round 6: a table goes up the moment its reader has it, on the
+    # context's thread - filter_variants_pipeline.run); together they build what `configure` sets in one go
+    def _part(self):
+        if not isinstance(self.cfg, dict):
+            self.cfg = dict(ref=None, runs=None, tracks={}, n_tracks=0, bl=None, forests=None, flow="TGCA", hp=(10, 10, True))
+        return self.cfg
+
+    def set_reference(self, ref):
+        self._part()["ref"] = ref
+
+    def set_runs(self, runs, min_len=10, max_dist=10, mark_hpol=True):
+        c = self._part()
+        assert c["ref"] is not None, "the engine checks interval tables against the reference's contigs: reference first"
+        c["runs"], c["hp"] = runs, (min_len, max_dist, mark_hpol)
+
+    def set_track(self, t, tr):
+        c = self._part()
+        assert c["ref"] is not None and 0 <= t < S.MAX_TRACKS
+        c["tracks"][t] = tr
+
+    def set_n_tracks(self, n):
+        self._part()["n_tracks"] = n
+
+    def set_blacklist(self, keys):
+        self._part()["bl"] = keys
+
+    def set_flow_order(self, flow):
+        self._part()["flow"] = flow
+
+    def set_models(self, forests):
+        self._part()["forests"] = forests
+
+    def _cfg_tuple(self):
+        if isinstance(self.cfg, dict):
+            c = self.cfg
+            assert sorted(c["tracks"]) == list(range(c["n_tracks"])), "every track slot below n_tracks must have been uploaded"
+            runs = c["runs"] if c["runs"] is not None and c["runs"].starts.size else None
+            return (c["ref"], runs, [c["tracks"][t] for t in range(c["n_tracks"])], c["bl"], c["forests"], c["flow"]) + tuple(c["hp"])
+        return self.cfg
+
     # ---- what bench.py asks of an engine beyond the tool's calls
     def close(self):
         pass
@@ -76,7 +116,7 @@ class FakeEngine:
         return self.res
 
     def filter_variants(self, vt):
-        ref, runs, tracks, bl, forests, flow, hp_len, hp_dist, mark = self.cfg
+        ref, runs, tracks, bl, forests, flow, hp_len, hp_dist, mark = self._cfg_tuple()
         return O.filter_variants(vt, ref, runs, tracks, bl, forests, flow, hp_len, hp_dist, mark)
 
     def upload_variants(self, vt):

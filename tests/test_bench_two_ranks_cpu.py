@@ -46,7 +46,8 @@ def test_bench_shards_gathers_and_reports(tmp_path, world):
     n_total = int(cfg["workload"].split()[1])
     assert abs(n_total - N_VAR) < 100 and cfg["rccl_nranks"] == world and cfg["sharding"].startswith(f"equal-count x{world}")
     sizes = [int(np.load(ex / f"rank{r}.npz")["ts"].size) for r in range(world)]
-    assert sum(sizes) == n_total and max(sizes) - min(sizes) <= 1 and cfg["variants_per_gpu"] == sizes[0]
+    # equal-count shards; a cut may have moved to a contig change within 1 % of the share (shard.shard_bounds with the contig column)
+    assert sum(sizes) == n_total and max(sizes) <= n_total / world * 1.01 + 1 and cfg["variants_per_gpu"] == sizes[0]
     par = d["parity"]
     # rank 0's shard, scored against ITS slice of the tables, equals the oracle on the whole tables; every rank found its shard in
     # the gathered columns; the gathered callset equals the oracle row for row

@@ -11,6 +11,7 @@ from conftest import GOLDEN, real_chr1_reference
 
 pytestmark = pytest.mark.gpu
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RF = "rf_model_ignore_gt_incl_hpol_runs"
 XGB = "xgb_model_ignore_gt_incl_hpol_runs"
 
@@ -604,18 +605,27 @@ def test_full_size_every_row_equals_the_oracle(engine, frozen_models, config):
     forests = frozen_models[RF]
     _configure(engine, cs.ref, cs.runs, cs.tracks, cs.blacklist, forests)
     got = engine.filter_variants(cs.variants)
+    # ... and the RESIDENT path - upload_variants + filter_resident + download_results: one launch pair over the whole callset, the
+    # path bench.py times (the host-buffer call above scores the callset chunk by chunk) - every row as well
+    engine.upload_variants(cs.variants)
+    engine.filter_resident()
+    got_res = engine.download_results()
+    # a second resident pass over the same rows: what the bench's K timed steps repeat
+    engine.filter_resident()
+    got_res2 = engine.download_results()
     n = cs.variants.n
     assert n > (4_900_000 if config == "C3" else 990_000)
     bad = 0
     for a in range(0, n, 250_000):
         b = min(a + 250_000, n)
         exp = O.filter_variants(cs.variants.slice(a, b), cs.ref, cs.runs, cs.tracks, cs.blacklist, forests)
-        for what in ("filter", "flags", "tree_score"):
-            g, e = getattr(got, what)[a:b], getattr(exp, what)
-            if not np.array_equal(g, e):
-                rows = a + np.flatnonzero(g != e)
-                bad += rows.size
-                print(f"{config} rows {a}..{b}: {rows.size} {what} differ, first {rows[:5]}")
+        for path, res in (("host-buffer", got), ("resident", got_res), ("resident, second pass", got_res2)):
+            for what in ("filter", "flags", "tree_score"):
+                g, e = getattr(res, what)[a:b], getattr(exp, what)
+                if not np.array_equal(g, e):
+                    rows = a + np.flatnonzero(g != e)
+                    bad += rows.size
+                    print(f"{config} {path} rows {a}..{b}: {rows.size} {what} differ, first {rows[:5]}")
     assert bad == 0
 
 
@@ -664,6 +674,41 @@ def test_c5_leaf_matrix_gemm(engine, small_callset, frozen_models):
     engine.feature_matrix(cs.variants)
     with pytest.raises(RuntimeError, match="additive|depth"):
         engine.forest_gemm(0, None)
+
+
+def test_gemm3_falls_back_to_the_traversal_when_its_self_check_fails(tmp_path):
+    """forest_gemm3_kernel reads its predicates' operands by register index and relies on where the compiler put the row's feature
+    registers; its first use per process is checked against the scalar traversal.  Round 5 FAILED the call on a mismatch - a hipcc
+    update could have turned config C5's default path into an error.  Round 6: the traversal serves the call (and every later one),
+    bit-identical margins, one note on stderr.  The mismatch is forced (UGVC_GEMM3_FORCE_MISMATCH, read by the self-check alone)
+    in a process of its own: the state is per process."""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+from oracle import oracle as O
+from variantcalling_amd import model_io, schema as S, synth
+from variantcalling_amd.engine import Engine, configure
+forests = model_io.load_models(os.path.join(%r, "tests", "golden", "synth_rf_v1.npz"))["xgb_model_ignore_gt_incl_hpol_runs"]
+cs = synth.make_callset(20_000, genome_len=10_000_000, n_contigs=3, seed=11)
+with Engine(0) as eng:
+    configure(eng, cs.ref, cs.runs, cs.tracks, cs.blacklist, forests)
+    X, group = eng.feature_matrix(cs.variants)
+    rows_g = [np.flatnonzero(group == g).astype(np.int32) for g in range(S.N_GROUPS)]
+    exp = np.zeros(X.shape[0], np.float32)
+    for g in range(S.N_GROUPS):
+        exp[rows_g[g]] = O.forest_predict(forests[g], X[rows_g[g]])[0]
+    for _ in range(2):                                   # the first call runs the self-check, the second finds the state
+        got, ms = eng.forest_gemm3(rows_g, iters=2)
+        assert np.array_equal(got, exp) and ms > 0
+print("FALLBACK-OK")
+""" % (ROOT, ROOT)
+    env = dict(os.environ, UGVC_GEMM3_FORCE_MISMATCH="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "FALLBACK-OK" in r.stdout, r.stderr[-2000:]
+    assert r.stderr.count("forest_gemm3_kernel disagrees with the scalar traversal") == 1     # said once
 
 
 def _stump_forest(specs, n_features=20):

@@ -58,8 +58,8 @@ def _same_file(a, b, mutect=False):
 
 def test_header_symbols_are_exported():
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "ugvc_vcf.h")).read(), flags=re.S)
-    names = sorted(set(re.findall(r"\b(ugvc_(?:vcf|fasta|intervals)_[a-z0-9_]+)\s*\(", text)))
-    assert len(names) == 17
+    names = sorted(set(re.findall(r"\b(ugvc_(?:vcf|fasta|intervals|bgzf|blob)_[a-z0-9_]+)\s*\(", text)))
+    assert len(names) == 20                                      # (round 6: + ugvc_intervals_track, ugvc_bgzf_read, ugvc_blob_free)
     lib = nv.load_library()
     for n in names:
         assert hasattr(lib, n), n

@@ -319,8 +319,20 @@ void bounce_destroy(ugvc_ctx* ctx) {
     ctx->bounce = nullptr;
 }
 
+// UGVC_COPY=direct (round 6, for the A/B of VERDICT r5 item 3): the runtime's own copies on the caller's memory, as until round 4 -
+// a copy larger than the runtime's staging buffer makes it pin the caller's pages for the duration (userptr).  The default stays
+// the pinned slots; profiles/r06_copy_path_ab.txt has both on fresh leases in the driver's order.
+static bool copy_direct() {
+    static const bool on = [] { const char* e = getenv("UGVC_COPY"); return e && strcmp(e, "direct") == 0; }();
+    return on;
+}
+
 hipError_t copy_in(ugvc_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
     if (!bytes) return hipSuccess;
+    if (copy_direct()) {
+        const hipError_t e = hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream);
+        return e != hipSuccess ? e : hipStreamSynchronize(ctx->stream);      // (copy_in returns with the source no longer referenced)
+    }
     Bounce* b = bounce_of(ctx);
     if (!b) { set_error("cannot allocate the pinned staging slots"); return hipErrorOutOfMemory; }
     BurstScope burst(b, bytes);
@@ -344,6 +356,10 @@ hipError_t copy_in(ugvc_ctx* ctx, void* dst_dev, const void* src_host, size_t by
 
 hipError_t copy_out(ugvc_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes) {
     if (!bytes) return hipSuccess;
+    if (copy_direct()) {
+        const hipError_t e = hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream);
+        return e != hipSuccess ? e : hipStreamSynchronize(ctx->stream);      // (copy_out returns with the bytes in the caller's buffer)
+    }
     Bounce* b = bounce_of(ctx);
     if (!b) { set_error("cannot allocate the pinned staging slots"); return hipErrorOutOfMemory; }
     BurstScope burst(b, bytes);

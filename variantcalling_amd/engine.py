@@ -222,6 +222,17 @@ class Engine:
         self._check(self.lib.ugvc_set_n_tracks(self._h, len(tracks)))
         self.n_tracks = len(tracks)
 
+    def set_track(self, t: int, tr: S.IntervalTrack):
+        """One annotation track into slot t (a tool uploads each as its reader finishes; set_n_tracks when all are there)."""
+        if not 0 <= t < S.MAX_TRACKS:
+            raise ValueError(f"at most {S.MAX_TRACKS} annotation tracks")
+        s, e, p = _col(tr.starts, np.int32), _col(tr.ends, np.int32), _col(tr.contig_ptr, np.int32)
+        self._check(self.lib.ugvc_track_upload(self._h, t, _p(s, _i32p), _p(e, _i32p), _p(p, _i32p), s.size))
+
+    def set_n_tracks(self, n: int):
+        self._check(self.lib.ugvc_set_n_tracks(self._h, int(n)))
+        self.n_tracks = int(n)
+
     def set_blacklist(self, keys: np.ndarray | None):
         k = _col(keys if keys is not None else np.zeros(0, np.uint64), np.uint64)
         self._check(self.lib.ugvc_blacklist_upload(self._h, _p(k, _u64p), k.size))

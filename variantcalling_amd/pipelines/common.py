@@ -13,12 +13,15 @@ from ..io import bed
 logger = logging.getLogger("ugvc")
 
 
-def load_side_tables(reference_file, runs_file, annotate_intervals, blacklist_file, also=None):
+def load_side_tables(reference_file, runs_file, annotate_intervals, blacklist_file, also=None, on_ready=None):
     """Reference, homopolymer runs, annotation tracks, blacklist - read CONCURRENTLY (the native readers release the GIL;
     each is threaded itself, but none keeps a large host busy alone: FASTA encode, four interval files and a 100 MB BGZF are
     0.3-0.6 s one after the other).  The interval files need the contig names: with a `.fai` beside the FASTA they start at
     once, otherwise when the FASTA has been read.  `also`: {name: f(contig_names)} extra readers that need only the names
-    (the callset VCF of filter_variants_pipeline) - their results come back as a dict in fifth place."""
+    (the callset VCF of filter_variants_pipeline) - their results come back as a dict in fifth place.  `on_ready(kind, index,
+    table)` (kind "reference" | "runs" | "track" | "blacklist"; round 6): called on the reader's thread the moment a table is
+    there - filter_variants_pipeline hands it to the GPU context's thread, so that the uploads run under the slowest reader
+    instead of behind all of them."""
     from concurrent.futures import ThreadPoolExecutor
     from ..io import vcf_native                        # threaded native readers (libugvc_vcf.so); io.fasta / io.bed are their references
     if len(annotate_intervals or []) > S.MAX_TRACKS:
@@ -27,24 +30,28 @@ def load_side_tables(reference_file, runs_file, annotate_intervals, blacklist_fi
     import time
     seconds = {}
 
-    def timed(name, f):
+    def timed(name, f, kind=None, index=0):
         def g(*a):
             t0 = time.perf_counter()
             try:
-                return f(*a)
+                out = f(*a)
             finally:
                 seconds[name] = time.perf_counter() - t0
+            if on_ready is not None and kind is not None:
+                on_ready(kind, index, out)
+            return out
         return g
     load_side_tables.last_seconds = seconds                  # (read by tools/bench_pipeline.py: which reader the stage waits for)
     with ThreadPoolExecutor(max_workers=8) as pool:
-        f_ref = pool.submit(timed("reference", vcf_native.read_fasta), reference_file)
+        f_ref = pool.submit(timed("reference", vcf_native.read_fasta, "reference"), reference_file)
         names = vcf_native.read_fasta_names(reference_file) if os.path.exists(reference_file + ".fai") else None
         if names is None:
             names = f_ref.result().names
         # homopolymer runs are disjoint by nature; book-ended runs of different bases must stay separate
-        f_runs = pool.submit(timed("runs", vcf_native.read_intervals), runs_file, names, False) if runs_file else None
-        f_tracks = [pool.submit(timed(f"track {os.path.basename(p)}", vcf_native.read_intervals), p, names, True) for p in (annotate_intervals or [])]
-        f_bl = pool.submit(timed("blacklist", bed.read_blacklist), blacklist_file, names) if blacklist_file else None
+        f_runs = pool.submit(timed("runs", vcf_native.read_intervals, "runs"), runs_file, names, False) if runs_file else None
+        f_tracks = [pool.submit(timed(f"track {os.path.basename(p)}", vcf_native.read_intervals, "track", k), p, names, True)
+                    for k, p in enumerate(annotate_intervals or [])]
+        f_bl = pool.submit(timed("blacklist", bed.read_blacklist, "blacklist"), blacklist_file, names) if blacklist_file else None
         f_also = {k: pool.submit(timed(k, f), names) for k, f in also.items()}
         ref = f_ref.result()
         if list(ref.names) != list(names):
