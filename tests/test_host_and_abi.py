@@ -362,3 +362,22 @@ ctypes.CDLL(None).abort()
     crumbs = [l.split()[-1] for l in err.splitlines() if l.startswith("[ugvc]   kernel_")]
     assert crumbs == [f"kernel_{k}" for k in range(3, 11)]                  # the ring keeps the last eight, oldest first
     assert err.index("[ugvc] process aborted") < err.index("Fatal Python error: Aborted")
+
+
+def test_gemm_predicate_listing_check(tmp_path):
+    """tools/isa/check_pred_asm.py (run by csrc/Makefile before the library is linked): a listing whose register-indexed predicates
+    have `x0` off the first register of the feature tuple - what a compiler update could produce - fails the build."""
+    import subprocess
+    import sys
+    script = os.path.join(ROOT, "tools", "isa", "check_pred_asm.py")
+    good = "\n".join(f"\t; ugvc_pred x0=v{a} xv=v[{a}:{a + 31}]\n\ts_set_gpr_idx_on s4, gpr_idx(SRC0)" for a in (12, 12, 40))
+    p = tmp_path / "good.s"
+    p.write_text(good)
+    assert subprocess.run([sys.executable, script, str(p)], capture_output=True).returncode == 0
+    for bad in (good + "\n\t; ugvc_pred x0=v13 xv=v[12:43]\n",        # x0 is the tuple's SECOND register
+                good + "\n\t; ugvc_pred x0=v12 xv=v[12:41]\n",        # a 30-register tuple
+                good + "\n\t; ugvc_pred x0=v12 xv=s[12:43]\n",        # not a VGPR tuple
+                "\tv_mov_b32 v0, v1\n"):                              # no instance at all: the check did not see the kernels
+        p = tmp_path / "bad.s"
+        p.write_text(bad)
+        assert subprocess.run([sys.executable, script, str(p)], capture_output=True).returncode != 0, bad[-60:]

@@ -139,12 +139,14 @@ constexpr int kGemm2RowB = 80;          // bytes per staged predicate row (64 + 
 // byte K of `a` := (the lane goes RIGHT at the node) ? 1 : 0 - right = !(x <= thr) for scikit-learn forests, !(x < thr) for
 // XGBoost-style ensembles (a NaN feature goes right in both, as in the traversal kernel's compares).  x = xv[fidx]: the compare
 // reads the feature vector by REGISTER INDEX (VGPR index mode on its first source: xv's first register + fidx) - no move, no LDS.
-// `xv` is passed as an operand of its own so that the 32 registers stay live and contiguous; `x0` is its element 0 - the
-// listing is checked for `x0` being the tuple's first register (tests/ would fail bit-exactness otherwise).
+// `xv` is passed as an operand of its own so that the 32 registers stay live and contiguous; `x0` is its element 0 - every
+// instance leaves a comment `; ugvc_pred x0=vN xv=v[N:N+31]` in the listing, and the BUILD checks it (csrc/Makefile: check-gemm,
+// tools/isa/check_pred_asm.py: x0 is the tuple's first register in every instance) before the library is linked; at run time the
+// first use per kernel is compared with the scalar traversal, which serves the calls if they differ.
 // (s_set_gpr_idx_on writes M0, which clang reserves and warns about when it is clobbered; nothing else in this kernel uses M0)
 #pragma clang diagnostic ignored "-Winline-asm"
 #define UGVC_PRED_ASM(CMP, BYTE)                                                                                          \
-    asm("s_set_gpr_idx_on %5, gpr_idx(SRC0)\n\t" CMP " vcc, %4, %3\n\ts_set_gpr_idx_off\n\t"                              \
+    asm("; ugvc_pred x0=%4 xv=%6\n\ts_set_gpr_idx_on %5, gpr_idx(SRC0)\n\t" CMP " vcc, %4, %3\n\ts_set_gpr_idx_off\n\t"     \
         "v_cndmask_b32_sdwa %0, %1, %2, vcc dst_sel:" BYTE " dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"   \
         : "+v"(a) : "v"(zero), "v"(one), "s"(thr), "v"(x0), "s"(fidx), "v"(xv) : "vcc", "m0")
 template <int K, bool RF>

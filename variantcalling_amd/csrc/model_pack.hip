@@ -656,7 +656,7 @@ int v5_fused_waves(const V5Args& v);
 
 // Everything the v5 launches need for the resident variants: node tables, index lists, brackets, record lists,
 // and the LDS layout of a wave's staged side-table slices (capacities follow the tables' densities).
-int v5_fill_args(ugvc_ctx* ctx, V5Args& v, const FilterArgs& a, bool scoring) {
+int v5_fill_args(ugvc_ctx* ctx, V5Args& v, const FilterArgs& a, bool scoring, int wg_per_cu) {
     V2State* s = state(ctx);
     if (!s->css.p && build_css_lut(ctx)) return -1;
     v = V5Args{};
@@ -700,7 +700,8 @@ int v5_fill_args(ugvc_ctx* ctx, V5Args& v, const FilterArgs& a, bool scoring) {
     for (int k = 0; k < 3; ++k) { v.eyt_off[k] = s->eyt_off[k]; v.eyt_bits[k] = s->eyt_bits[k]; }
     v.css_lut = s->css.as<uint8_t>();
     // rows per workgroup of the fused kernel: the callset split evenly over the CUs (at least kMinRowsWg5 rows each)
-    v.rows_wg = (int)std::max<int64_t>((n + ctx->n_cus - 1) / ctx->n_cus, kMinRowsWg5);
+    const int64_t n_slots = (int64_t)ctx->n_cus * std::max(wg_per_cu, 1);
+    v.rows_wg = (int)std::max<int64_t>((n + n_slots - 1) / n_slots, kMinRowsWg5);
     const int64_t n_wg = (n + v.rows_wg - 1) / v.rows_wg;
     v.list_stride = (v.rows_wg + kTile5 - 1) / kTile5 * kTile5 + kTile5;
     // record lists: a workgroup's indel tiles go round-robin over the kShards lists of their group

@@ -135,7 +135,7 @@ struct V5Args {
     int forest_lds_tail;                 // forest5_kernel: byte offset of its shard-offset / total words in the dynamic LDS
 };
 
-int v5_fill_args(ugvc_ctx* ctx, V5Args& v, const FilterArgs& a, bool scoring = true);
+int v5_fill_args(ugvc_ctx* ctx, V5Args& v, const FilterArgs& a, bool scoring = true, int wg_per_cu = 1);
 
 int pack_model_group(ugvc_ctx* ctx, int g, const int32_t* feature, const float* threshold,
                      const int32_t* left, const int32_t* right, int n_nodes, const int32_t* tree_root,

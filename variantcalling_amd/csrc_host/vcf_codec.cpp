@@ -1144,6 +1144,12 @@ static int write_filtered_impl(const ugvc_vcf* h, const char* out_path, const fl
     // Round 6: a flush is TWO stages - the blocks of a batch are compressed (worker threads), then written in file order by a
     // writer thread of their own, while the NEXT batch is already being compressed into the other set of block buffers: format |
     // deflate | write run side by side (until round 5 a batch's write stood between its deflate and the next batch's).
+    const int deflate_threads = n_threads > 0 ? threads : (int)std::min<unsigned>(128u, std::max<unsigned>((unsigned)threads, std::thread::hardware_concurrency() / 2));
+    struct CompPool {                                        // the threads' libdeflate compressors, kept across the flushes
+        std::vector<void*> v;
+        ~CompPool() { const LibDeflate& l = libdeflate(); for (void* c : v) if (c && l.ok) l.free_c(c); }
+    } comp_pool;
+    std::vector<void*>& ld_comp = comp_pool.v;
     std::vector<std::string> comp_buf[2];                    // compressed blocks of a flush, two sets (kept: their capacity is reused)
     int comp_sel = 0;
     std::atomic<int64_t> ns_deflate{0}, ns_write{0};         // (UGVC_VCF_TRACE: summed over the flushes)
@@ -1172,12 +1178,18 @@ static int write_filtered_impl(const ugvc_vcf* h, const char* out_path, const fl
         // threshold, i.e. an mmap + 66 page faults + munmap per 64 KB block, serialised on the process' address-space lock
         // when 256 threads do it at once (0.3 s per 2 M records against 0.04 s of actual compression)
         std::atomic<int64_t> next_blk{0};
-        const int T = (int)std::max<int64_t>(1, std::min<int64_t>(threads, (int64_t)nb));
+        // (round 6: the compression of a batch is what the writer waits for - 0.24-0.38 s of a 5 M-record write-back's 0.5 s with 64
+        // threads, profiles/r06_c1_pipeline_5M.txt - so it takes up to half of the host's threads, 128 at most, and every thread
+        // keeps its compressor from flush to flush instead of allocating one per flush)
+        const int T = (int)std::max<int64_t>(1, std::min<int64_t>(deflate_threads, (int64_t)nb));
         const LibDeflate& ld = libdeflate();
-        parallel_ranges(T, T, [&](int, int64_t, int64_t) {
+        if (ld.ok && ld_comp.size() < (size_t)T) ld_comp.resize((size_t)T, nullptr);
+        parallel_ranges(T, T, [&](int part_k, int64_t, int64_t) {
             static const unsigned char hd[16] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 'B', 'C', 0x02, 0};
             if (ld.ok) {
-                void* c = ld.alloc_c(6);
+                void*& slot = ld_comp[(size_t)part_k];
+                if (!slot) slot = ld.alloc_c(6);
+                void* c = slot;
                 if (!c) { bad = 1; return; }
                 const size_t bound = ld.bound(c, kBlk);
                 for (;;) {
@@ -1196,7 +1208,6 @@ static int write_filtered_impl(const ugvc_vcf* h, const char* out_path, const fl
                     for (int i = 0; i < 4; ++i) { t[i] = (unsigned char)(crc >> (8 * i)); t[4 + i] = (unsigned char)((uint32_t)len >> (8 * i)); }
                     o.resize(18 + clen + 8);
                 }
-                ld.free_c(c);
                 return;
             }
             z_stream zs;

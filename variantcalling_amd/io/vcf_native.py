@@ -13,7 +13,8 @@ import numpy as np
 
 from .. import schema as S
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libugvc_vcf.so")
+# (UGVC_VCF_LIB: another build of the same library - the sanitizer build of tools/codec_asan.sh)
+LIB_PATH = os.environ.get("UGVC_VCF_LIB") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libugvc_vcf.so")
 _lib = None
 
 
