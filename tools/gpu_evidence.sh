@@ -24,7 +24,7 @@ d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r=d['roofline']
 print(sys.argv[2], 'ms', round(d['ms_per_step'],4), 'kernel_ms', round(r.get('kernel_ms',0),4), 'frac', round(r['frac'],4), 'traffic', r.get('traffic'), (r.get('feature_build') or {}).get('frac'), d.get('parity'), 'cpu', (d.get('cpu_baseline') or {}).get('value'))" "$1" "$2"; }
 prof() {  # tag, traffic key, kernel filter, bench args...
   local tag=$1 key=$2 filt=$3; shift 3
-  local CMD="python bench.py --steps 20 --warmup 5 --cpu-sample 0 --no-e2e $*"
+  local CMD="python bench.py --steps 20 --warmup 5 --cpu-sample 0 --no-e2e --no-other $*"
   rm -rf $O/prof_$tag
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$tag/trace -o trace -- $CMD > $O/prof_$tag.log 2>&1
   for c in FETCH_SIZE WRITE_SIZE; do
@@ -55,7 +55,7 @@ work)
 shards)
   { echo "# python bench.py --variants N --steps 40 --warmup 5 --cpu-sample 0 --no-e2e : kernel time of one pass (HIP events, after the spin-up), one GPU"
   for n in 5000000 2500000 1250000 625000; do
-  python bench.py --variants $n --steps 40 --warmup 5 --cpu-sample 0 --no-e2e 2>/dev/null | python -c "
+  python bench.py --variants $n --steps 40 --warmup 5 --cpu-sample 0 --no-e2e --no-other 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
 print(d['config']['variants_per_gpu'], 'variants: pass mean %.1f us  p50 %.1f us  step %.1f us  parity' % (r['kernel_ms']*1e3, r['kernel_ms_p50']*1e3, d['ms_per_step']*1e3), d['parity'])"
@@ -74,9 +74,9 @@ import json; d=json.load(open('$O/hbm_traffic.json'))
 for k,v in d['workloads'].items(): print(k, v.get('bytes_per_launch'), v.get('commit'))" ;;
 sq)
   : > $O/${T}_sq_counters.txt
-  for var in 0 131072; do
+  for var in ${SQ_VARIANTS:-0 131072}; do      # (131072 no SNP walk, 262144 no indel tiles, 524288 no side-table joins: sums of them ablate several)
     rm -rf $O/pm
-    timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/pm -o pmc -- python bench.py --steps 4 --warmup 1 --spinup 0 --cpu-sample 0 --no-e2e --check-rows 0 --variant $var > $O/pm.log 2>&1 || tail -3 $O/pm.log
+    timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/pm -o pmc -- python bench.py --steps 4 --warmup 1 --spinup 0 --cpu-sample 0 --no-e2e --no-other --check-rows 0 --variant $var > $O/pm.log 2>&1 || tail -3 $O/pm.log
     python - "$var" "$T" <<'PY'
 import csv, glob, sys, collections
 var, tag = sys.argv[1], sys.argv[2]
@@ -110,7 +110,7 @@ PY
   rm -rf $O/pm5; cat $O/${T}_c5_sq_counters.txt ;;
 wclk)
   for n in 5000000 625000; do
-    UGVC_WAVE_CLK=/tmp/wclk.bin python bench.py --variants $n --steps 3 --warmup 2 --spinup 20 --cpu-sample 0 --no-e2e --check-rows 0 > /tmp/wclk.json 2>/tmp/wclk.err || tail -3 /tmp/wclk.err
+    UGVC_WAVE_CLK=/tmp/wclk.bin python bench.py --variants $n --steps 3 --warmup 2 --spinup 20 --cpu-sample 0 --no-e2e --no-other --check-rows 0 > /tmp/wclk.json 2>/tmp/wclk.err || tail -3 /tmp/wclk.err
     echo "== $n variants"; python tools/wave_clk.py /tmp/wclk.bin
   done > $O/${T}_wave_clk.txt; grep -E "==|workgroup end" $O/${T}_wave_clk.txt ;;
 cli)

@@ -1515,11 +1515,10 @@ __device__ __forceinline__ void pass_clock_end(const V5Args& v) {
 // alt_len: the SNP forest) and indels - in callset order.  A tile is 64 consecutive entries of a list: pure in
 // class (every lane of a wave walks the SAME forest), ascending in position.  Waves then take CONSECUTIVE tiles:
 // the first `n_sw` waves share the SNP tiles, the others the indel tiles, in proportion to the tile counts.
-// WPE (round 6, feature-matrix launches only): waves per SIMD the register allocation is held to - the matrix build walks nothing,
-// its tiles are chains of dependent memory round trips, and twice the waves in flight hide twice as many of them; WPE > 1 compiles
-// for 8-wave workgroups (several per CU) at 512 / WPE registers, with what does not fit in scratch.
-template <int NTRK, int NTW, bool WX = false, int WPE = 1>
-__global__ __launch_bounds__(WPE > 1 ? 512 : kK2Threads, WPE) void fused5_kernel(const V5Args v) {
+// (Round 6 compiled the WX instantiation for 6 waves per SIMD - 80 registers, three 8-wave workgroups per CU - to hide more of the
+// matrix build's round trips: 168 spilled registers, 0.205 against 0.152 ms per 2 M rows, profiles/r06_fm_dense_ab.txt.  Not kept.)
+template <int NTRK, int NTW, bool WX = false>
+__global__ __launch_bounds__(kK2Threads) void fused5_kernel(const V5Args v) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NT = 1 + NTRK;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -2077,16 +2076,6 @@ int launch_feature_matrix_v5(ugvc_ctx* ctx, const FilterArgs& a) {
     v.run_forest = 0;
     v.n_waves = 16;
     v.n_indel_waves = 8;
-    // (experiment, round 6: UGVC_FM_WPE=6 - three 8-wave workgroups per CU at 80 registers; 3-track kernel only)
-    static const int fm_wpe = [] { const char* e = getenv("UGVC_FM_WPE"); return e ? atoi(e) : 0; }();
-    const bool dense = fm_wpe == 6 && a.n_tracks == 3;
-    if (dense) {
-        if (v5_fill_args(ctx, v, a, false, 3)) return -1;
-        for (int g = 0; g < UGVC_N_GROUPS; ++g) v.pg[g].ok = 0;
-        v.run_forest = 0;
-        v.n_waves = 8;
-        v.n_indel_waves = 4;
-    }
     v.indel_w = 768;                                              // without the walk an indel tile costs about three SNP tiles
     // every wave's LDS scratch also holds a tile's rows on their way out (store_feature_rows_tile): 64 F floats + 64 indices
     const int rows_lds = (64 * kMaxFeatures * 4 + 256 + 63) & ~63;
@@ -2095,15 +2084,7 @@ int launch_feature_matrix_v5(ugvc_ctx* ctx, const FilterArgs& a) {
     if (const char* e = getenv("UGVC_FM_INDEL_W")) v.indel_w = std::max(1, (int)(atof(e) * 256.0));      // (profiling)
     if (lds5_bytes(v, v.n_waves) > (size_t)kLds5Limit) return fail("internal: feature-matrix scratch does not fit LDS");
     const unsigned n_wg = (unsigned)((a.n + v.rows_wg - 1) / v.rows_wg);
-    if (dense) {
-        static bool attr6 = false;
-        if (!attr6) {
-            UGVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused5_kernel<3, 16, true, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds5Limit));
-            attr6 = true;
-        }
-        UGVC_LAUNCH((fused5_kernel<3, 16, true, 6>), dim3(n_wg), dim3(v.n_waves * 64), lds5_bytes(v, v.n_waves), ctx->stream, v);
-    } else
-        UGVC_LAUNCH(fused5_wx_for(a.n_tracks), dim3(n_wg), dim3(v.n_waves * 64), lds5_bytes(v, v.n_waves), ctx->stream, v);
+    UGVC_LAUNCH(fused5_wx_for(a.n_tracks), dim3(n_wg), dim3(v.n_waves * 64), lds5_bytes(v, v.n_waves), ctx->stream, v);
     UGVC_HIP(hipGetLastError());
     return 0;
 }

@@ -1144,7 +1144,12 @@ static int write_filtered_impl(const ugvc_vcf* h, const char* out_path, const fl
     // Round 6: a flush is TWO stages - the blocks of a batch are compressed (worker threads), then written in file order by a
     // writer thread of their own, while the NEXT batch is already being compressed into the other set of block buffers: format |
     // deflate | write run side by side (until round 5 a batch's write stood between its deflate and the next batch's).
-    const int deflate_threads = n_threads > 0 ? threads : (int)std::min<unsigned>(128u, std::max<unsigned>((unsigned)threads, std::thread::hardware_concurrency() / 2));
+    int deflate_threads = n_threads > 0 ? threads : (int)std::min<unsigned>(128u, std::max<unsigned>((unsigned)threads, std::thread::hardware_concurrency() / 2));
+    if (const char* e = getenv("UGVC_VCF_DEFLATE_THREADS")) deflate_threads = std::max(1, atoi(e));       // (measurement knob)
+    // compression level of the libdeflate back end (1..12; 6 = what htslib's bgzf writes by default, and the default here; the zlib back
+    // end stays at 6 - its bytes are the pure-Python reference codec's).  Measured on 5 M records: profiles/r06_writer_sweep.txt
+    int ld_level = 6;
+    if (const char* e = getenv("UGVC_VCF_LEVEL")) ld_level = std::min(12, std::max(1, atoi(e)));
     struct CompPool {                                        // the threads' libdeflate compressors, kept across the flushes
         std::vector<void*> v;
         ~CompPool() { const LibDeflate& l = libdeflate(); for (void* c : v) if (c && l.ok) l.free_c(c); }
@@ -1188,7 +1193,7 @@ static int write_filtered_impl(const ugvc_vcf* h, const char* out_path, const fl
             static const unsigned char hd[16] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 'B', 'C', 0x02, 0};
             if (ld.ok) {
                 void*& slot = ld_comp[(size_t)part_k];
-                if (!slot) slot = ld.alloc_c(6);
+                if (!slot) slot = ld.alloc_c(ld_level);
                 void* c = slot;
                 if (!c) { bad = 1; return; }
                 const size_t bound = ld.bound(c, kBlk);

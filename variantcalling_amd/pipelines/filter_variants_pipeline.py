@@ -177,7 +177,25 @@ def run(argv: list[str]):
                 raise RuntimeError("internal: the codec's part bounds differ from shard.shard_bounds")
             mine = table
         counts = [int(x.decode()) for x in grp.allgather_bytes(str(mine.n).encode())]
-    with f_eng.result() as eng:
+    # (the context is CLOSED on a thread of its own once the verdict is on the host: freeing 3+ GB of device buffers is tens of
+    # milliseconds the write-back need not wait for - round 6; joined before the tool returns)
+    class _CloseBehind:
+        def __init__(self, eng):
+            self.eng, self.t = eng, None
+
+        def __enter__(self):
+            return self.eng
+
+        def __exit__(self, *exc):
+            self.t = threading.Thread(target=self.eng.close, daemon=False)
+            self.t.start()
+            return False
+
+        def join(self):
+            if self.t is not None:
+                self.t.join()
+    closing = _CloseBehind(f_eng.result())
+    with closing as eng:
         if grp.world == 1:
             try:
                 for f in early["futs"]:                          # the uploads that ran under the readers: wait, surface their errors
@@ -226,11 +244,15 @@ def run(argv: list[str]):
         res = multiallelic.collapse(res_rows, base_row, vcf.table.n) if (grp.world == 1 or part is None) else None
     grp.barrier()
     if grp.rank != 0:
+        closing.join()
         grp.close()
         return 0
     cg = common.cg_insertion_mask(vcf.table) if args.blacklist_cg_insertions else None
     logger.info("writing %s", args.output_file)
-    vcfio.write_filtered_vcf(args.output_file, vcf, res, cg)
+    try:
+        vcfio.write_filtered_vcf(args.output_file, vcf, res, cg)
+    finally:
+        closing.join()
     lap("FILTER/INFO write-back (native codec)")
     run.last_stage_seconds = stages                        # read by tools/bench_pipeline.py
     logger.info("stage seconds: %s", ", ".join(f"{k} {v:.3f}" for k, v in stages.items()))
