@@ -83,7 +83,8 @@ def test_train_then_filter(tmp_path):
     models = pickle.load(open(prefix + ".pkl", "rb"))
     assert set(models) == {"rf_model_ignore_gt_incl_hpol_runs", "dt_model_ignore_gt_incl_hpol_runs",
                            "rf_model_ignore_gt_excl_hpol_runs", "dt_model_ignore_gt_excl_hpol_runs",
-                           "threshold_model_ignore_gt_incl_hpol_runs", "threshold_model_ignore_gt_excl_hpol_runs"}
+                           "threshold_model_ignore_gt_incl_hpol_runs", "threshold_model_ignore_gt_excl_hpol_runs",
+                           "xgb_model_ignore_gt_incl_hpol_runs", "xgb_model_ignore_gt_excl_hpol_runs"}
     rows = [x.split(";") for x in open(prefix + ".stats.csv").read().splitlines()]
     assert rows[0][0] == "group" and rows[1][0] == "SNP" and float(rows[1][6]) > 0.7      # SNP f1 after filtering
     from variantcalling_amd.io import h5
@@ -110,7 +111,8 @@ def test_train_then_filter(tmp_path):
     assert np.array_equal(res2["label"], res["label"]) and np.array_equal(res2["pos"], res["pos"])
     for f in feat:
         assert np.array_equal(res2[f], res[f]), f
-    for name in ("dt_model_ignore_gt_excl_hpol_runs", "rf_model_ignore_gt_incl_hpol_runs", "threshold_model_ignore_gt_incl_hpol_runs"):
+    for name in ("dt_model_ignore_gt_excl_hpol_runs", "rf_model_ignore_gt_incl_hpol_runs", "threshold_model_ignore_gt_incl_hpol_runs",
+                 "xgb_model_ignore_gt_incl_hpol_runs"):
         out = str(tmp_path / f"{name}.vcf")
         filter_variants_pipeline.run(["filter_variants_pipeline", "--input_file", d["vcf"], "--model_file", prefix + ".pkl",
                                       "--model_name", name, "--runs_file", d["runs"], "--blacklist", d["bl"],
@@ -119,9 +121,19 @@ def test_train_then_filter(tmp_path):
                    if g in models[name] else None for g in S.GROUP_NAMES]
         exp = O.filter_variants(cs.variants, cs.ref, cs.runs, cs.tracks, bl, forests)
         score, tags = _parse_out(out, cs.variants.n)
+        g0 = ft["group"] == 0
+        if name.startswith("xgb"):
+            # the gradient-boosted ensemble (round 6: fitted by scikit-learn's histogram gradient boosting, stored and scored in
+            # XGBoost's format): FILTER decided on the bit-exact f32 margin; TREE_SCORE = sigmoid through device libm (1e-6 abs,
+            # the stated tolerance of the GBT path); against scikit-learn's own f64 probabilities to 1e-5
+            assert all(f.kind == S.MODEL_GBT and f.n_trees == 100 and f.max_depth <= 6 for f in forests)
+            assert np.array_equal(np.array(["LOW_SCORE" in t for t in tags]), exp.filter == 1)
+            assert np.abs(score - exp.tree_score).max() <= 1e-6
+            sk = models[name]["snp"].predict_proba(ft["X"][g0])[:, 1]
+            assert np.abs(exp.tree_score[g0] - sk).max() < 1e-5 and ((exp.tree_score[g0] > 0.5) == is_tp[g0]).mean() > 0.75
+            continue
         assert np.array_equal(score, exp.tree_score)
         assert np.array_equal(np.array(["LOW_SCORE" in t for t in tags]), exp.filter == 1)
-        g0 = ft["group"] == 0
         if name.startswith("threshold"):                       # the two-feature model: labels were drawn from QUAL, so it must separate
             assert ((exp.tree_score[g0] > 0.5) == is_tp[g0]).mean() > 0.75
             continue

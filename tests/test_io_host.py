@@ -298,3 +298,34 @@ def test_fai_index_points_at_every_contigs_first_base(tmp_path):
         assert raw[int(off) - 1:int(off)] == b"\n"
         assert raw[int(off):int(off) + 1] == fasta.CODE_TO_CHAR[cs.ref.codes[cs.ref.contig_off[c]]].encode()
     assert nv.read_fasta_names(p) == list(cs.ref.names)
+
+
+def test_hist_gradient_boosting_flattens_to_the_xgboost_style_table():
+    """train_models_pipeline's `xgb_model_*` (round 6): a scikit-learn HistGradientBoostingClassifier stored in XGBoost's format -
+    `x <= t64` of scikit-learn becomes `x < nextafter(f32_floor(t64))`, so every finite f32 input takes the same path (also rows
+    sitting exactly ON a threshold), the f32 margin equals scikit-learn's f64 decision function to ~1e-5, depth <= 6 and 100 trees
+    (the shape the leaf-matrix GEMM takes), and it round-trips through the .npz the filter tool loads."""
+    from sklearn.ensemble import HistGradientBoostingClassifier
+    from oracle import oracle as O
+    from variantcalling_amd import model_io, schema as S
+    rng = np.random.default_rng(0)
+    X = rng.normal(size=(6000, 20)).astype(np.float32)
+    X[:, 2] = rng.integers(0, 50, 6000)
+    y = (X[:, 0] + X[:, 3] * X[:, 5] + 0.1 * X[:, 2] > 2.5).astype(int)
+    m = HistGradientBoostingClassifier(max_iter=100, max_depth=6, max_leaf_nodes=64, learning_rate=0.1, early_stopping=False, random_state=0).fit(X, y)
+    f = model_io.flatten_sklearn(m)
+    assert f.kind == S.MODEL_GBT and f.n_trees == 100 and f.max_depth <= 6 and f.n_features == 20
+    margin, score = O.forest_predict(f, X)
+    ref = m.decision_function(X)
+    assert np.abs(margin - ref).max() < 2e-5 and np.array_equal(margin > 0, ref > 0)
+    assert np.abs(score - m.predict_proba(X)[:, 1]).max() < 1e-5
+    # rows placed exactly on thresholds, and one float below
+    inner = np.flatnonzero(f.feature >= 0)
+    Xa = X[:1500].copy()
+    for k in range(Xa.shape[0]):
+        j = int(inner[rng.integers(0, inner.size)])
+        Xa[k, f.feature[j]] = np.nextafter(f.threshold[j], np.float32(-np.inf)) if k % 2 else f.threshold[j]
+    ma, _ = O.forest_predict(f, Xa)
+    assert np.abs(ma - m.decision_function(Xa)).max() < 2e-5
+    with pytest.raises(ValueError, match="binary"):
+        model_io.flatten_hist_gbt(HistGradientBoostingClassifier(max_iter=3).fit(X[:300], rng.integers(0, 3, 300)))

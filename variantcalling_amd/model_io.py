@@ -83,7 +83,8 @@ def feature_permutation(model, track_names: list | None = None):
 def flatten_sklearn(model, n_features: int | None = None, track_names: list | None = None) -> S.FlatForest:
     """RandomForestClassifier / ExtraTrees / DecisionTreeClassifier (binary) -> FlatForest."""
     perm = feature_permutation(model, track_names)
-    f = _flatten_sklearn(model, n_features)
+    # (a histogram gradient-boosting classifier - the XGBoost-style additive ensemble train_models_pipeline fits as `xgb_model_*`)
+    f = flatten_hist_gbt(model, n_features) if hasattr(model, "_predictors") and hasattr(model, "_baseline_prediction") else _flatten_sklearn(model, n_features)
     if perm is not None:
         inner = f.feature >= 0
         f.feature = np.where(inner, perm[np.clip(f.feature, 0, perm.size - 1)], f.feature).astype(np.int32)
@@ -226,6 +227,36 @@ def make_gbt(trees: list, n_features: int, base_margin: float = 0.0) -> S.FlatFo
     doc = dict(learner=dict(learner_model_param=dict(base_score=str(p), num_feature=str(n_features)),
                             gradient_booster=dict(model=dict(trees=doc_trees))))
     return flatten_xgb_json(doc)
+
+
+def flatten_hist_gbt(model, n_features: int | None = None) -> S.FlatForest:
+    """A fitted scikit-learn `HistGradientBoostingClassifier` (binary) -> FlatForest (MODEL_GBT), the XGBoost-style table the engine
+    scores (f32 `x < threshold` goes left, f32 additive margin from `base_score`, sigmoid).
+
+    scikit-learn sends a row left when `x <= num_threshold` (f64 threshold, the f32 feature widened): for every finite f32 x that
+    is `x <= t` with t = the largest f32 not above the threshold, i.e. `x < nextafter(t, +inf)` - the threshold stored here, so
+    every finite input takes the same path.  NaN inputs go RIGHT here (the engine's compare is false), which is scikit-learn's
+    choice too when it saw no missing value in that feature during the fit... only if the right child is the larger one: the
+    hot path's features are never NaN after featurisation (QUAL / SOR default to 0), so this is not exercised.  Leaf values carry
+    the learning rate already; the margins are added in f32 here and in f64 by scikit-learn: equal to ~1e-6 relative, the class
+    (margin > 0) equal except inside that sliver."""
+    preds = getattr(model, "_predictors", None)
+    if preds is None or any(len(it) != 1 for it in preds):
+        raise ValueError("expected a fitted binary HistGradientBoostingClassifier")
+    trees = []
+    for (p,) in preds:
+        nd = p.nodes
+        if nd["is_categorical"].any():
+            raise ValueError("categorical splits are not supported (the hot path's features are numeric)")
+        leaf = nd["is_leaf"].astype(bool)
+        t32 = np.nextafter(f32_floor(nd["num_threshold"].astype(np.float64)), np.float32(np.inf)).astype(np.float32)
+        feat = np.where(leaf, -1, nd["feature_idx"].astype(np.int64)).astype(np.int32)
+        lc = np.where(leaf, -1, nd["left"].astype(np.int64))
+        rc = np.where(leaf, -1, nd["right"].astype(np.int64))
+        trees.append((feat, np.where(leaf, np.float32(0), t32), lc, rc, nd["value"].astype(np.float64)))
+    nf = int(n_features if n_features is not None else model.n_features_in_)
+    f = make_gbt(trees, nf, float(np.asarray(model._baseline_prediction).ravel()[0]))
+    return f
 
 
 def make_threshold_model(a, b, label, weight=None, i_a: int = 0, i_b: int = 1, n_features: int = 2, k: int = 16) -> S.FlatForest:

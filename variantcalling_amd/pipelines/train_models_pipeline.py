@@ -5,7 +5,8 @@ Drop-in for `ugbio_filtering.train_models_pipeline.run(argv)` (registered at
 docs/train_models_pipeline.md:17-81.  Two modes (docs :5-10): approximate ground truth from a call VCF
 (dbSNP id => true positive, `--blacklist` member => false positive) or exact labels.  The N x F feature
 matrix is built on the GPU (`ugvc_feature_matrix`); fitting is scikit-learn on the host as in the reference
-(random forest / decision tree, one model per variant-type group, exome re-weighting docs :66-72); the
+(random forest / decision tree / the two-feature threshold model / an XGBoost-style gradient-boosted ensemble - `fit_models` -,
+one model per variant-type group, exome re-weighting docs :66-72); the
 optional `--evaluate_concordance` pass scores on the GPU.
 Exact-label input is the comparison HDF5 (per-contig pandas frames with a `classify` column, read by io/h5.py +
 io/concordance.py; `--list_of_contigs_to_read` picks the keys) or an `.npz` dump of the SoA table with a `label`
@@ -29,6 +30,8 @@ from . import common
 
 logger = logging.getLogger("ugvc")
 N_TREES, MAX_DEPTH = 40, 8
+# the XGBoost-style additive ensemble (round 6): 100 trees of depth <= 6 - the shape config C5 scores as a leaf-matrix GEMM on MFMA
+GBT_TREES, GBT_DEPTH, GBT_RATE = 100, 6, 0.1
 
 
 def get_parser() -> argparse.ArgumentParser:
@@ -164,13 +167,19 @@ def _inside_intervals(track: S.IntervalTrack, contig: np.ndarray, pos: np.ndarra
 
 
 def fit_models(X, group, label, weights, hpol_flag):
-    from sklearn.ensemble import RandomForestClassifier
+    """One model per variant-type group and kind.  `xgb_model_*` (round 6): the newer reference tool is XGBoost-based
+    (`setup/environment.yml:354`); xgboost itself cannot be installed here, so the additive ensemble is fitted by
+    scikit-learn's histogram gradient boosting - the algorithm family of XGBoost's `hist` tree method (binned features, second-order
+    logistic loss, shrinkage) - and stored in XGBoost's FORMAT and scoring semantics (f32 `x < threshold`, f32 additive margin,
+    sigmoid: model_io.flatten_hist_gbt), which is what the engine scores (v3 traversal, or the leaf-matrix GEMM of config C5).  The
+    trees are not the ones xgboost would grow on the same data: BUILDER-DEFINED fit, reference-defined format."""
+    from sklearn.ensemble import HistGradientBoostingClassifier, RandomForestClassifier
     from sklearn.tree import DecisionTreeClassifier
     models = {}
     for incl in (True, False):
         use = (label >= 0) & (incl | ~hpol_flag)
         suffix = "ignore_gt_" + ("incl" if incl else "excl") + "_hpol_runs"
-        rf, dt, thr = {}, {}, {}
+        rf, dt, thr, gb = {}, {}, {}, {}
         i_qual, i_sor = S.BASE_FEATURES.index("qual"), S.BASE_FEATURES.index("sor")
         for g, gname in enumerate(S.GROUP_NAMES):
             m = use & (group == g)
@@ -180,11 +189,14 @@ def fit_models(X, group, label, weights, hpol_flag):
             rf[gname] = RandomForestClassifier(n_estimators=N_TREES, max_depth=MAX_DEPTH, random_state=g, n_jobs=-1).fit(
                 X[m], label[m], sample_weight=weights[m])
             dt[gname] = DecisionTreeClassifier(max_depth=MAX_DEPTH, random_state=g).fit(X[m], label[m], sample_weight=weights[m])
+            gb[gname] = HistGradientBoostingClassifier(max_iter=GBT_TREES, max_depth=GBT_DEPTH, max_leaf_nodes=1 << GBT_DEPTH, learning_rate=GBT_RATE,
+                                                       early_stopping=False, random_state=g).fit(X[m], label[m], sample_weight=weights[m])
             # the two-feature "simple model" (docs/howto-callset-filter.md:129,139): QUAL (= 10 * TLOD with --mutect) and SOR
             thr[gname] = model_io.make_threshold_model(X[m, i_qual], X[m, i_sor], label[m], weights[m], i_qual, i_sor, X.shape[1])
         models["rf_model_" + suffix] = rf
         models["dt_model_" + suffix] = dt
         models["threshold_model_" + suffix] = thr
+        models["xgb_model_" + suffix] = gb
     return models
 
 
