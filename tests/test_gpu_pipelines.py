@@ -105,8 +105,12 @@ def test_train_then_filter(tmp_path):
     prefix2 = str(tmp_path / "test.model2")
     rc = train_models_pipeline.run(["train_models_pipeline", "--input_file", str(tmp_path / "labelled.h5"), "--reference", d["fa"],
                                     "--runs_intervals", d["runs"], "--flow_order", "TGCA", "--output_file_prefix", prefix2,
-                                    "--ignore_filter_status"] + d["ann"])        # (the frame carries round one's FILTER tags)
+                                    "--ignore_filter_status",                     # (the frame carries round one's FILTER tags)
+                                    # config C5 inside the tool: the gradient-boosted ensemble applied by the scoring pass AND as a
+                                    # leaf-matrix GEMM on the resident feature matrix - the tool raises if the two disagree
+                                    "--evaluate_concordance", "--apply_model", "xgb_model_ignore_gt_incl_hpol_runs"] + d["ann"])
     assert rc == 0
+    assert h5.read_hdf(prefix2 + ".h5", "scored_concordance").n_rows == cs.variants.n
     res2 = h5.read_hdf(prefix2 + ".h5", "training_set")
     assert np.array_equal(res2["label"], res["label"]) and np.array_equal(res2["pos"], res["pos"])
     for f in feat:

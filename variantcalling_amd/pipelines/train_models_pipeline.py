@@ -260,9 +260,21 @@ def run(argv: list[str]):
             name = args.apply_model or "rf_model_ignore_gt_incl_hpol_runs"
             if name not in models:
                 raise KeyError(f"--apply_model {name!r}; trained: {sorted(models)}")
-            eng.set_models(_flatten(models[name]))
+            flat_applied = _flatten(models[name])
+            eng.set_models(flat_applied)
             eng.set_blacklist(bl)
             res = eng.filter_variants(vt)
+            # config C5: an additive ensemble of depth <= 6 (the `xgb_model_*` this tool fits) is ALSO evaluated as a leaf-matrix GEMM on
+            # the matrix cores over the feature matrix still resident from the fit (`ugvc_forest_gemm3`: one launch for the three
+            # variant-type groups) - the margins must decide every FILTER exactly as the scoring pass did and give its TREE_SCORE
+            if all(f is None or (f.kind == S.MODEL_GBT and f.max_depth <= 6) for f in flat_applied) and any(f is not None for f in flat_applied):
+                rows_g = [np.flatnonzero((group == g)).astype(np.int32) if flat_applied[g] is not None else None for g in range(S.N_GROUPS)]
+                margin, ms = eng.forest_gemm3(rows_g)
+                has = np.isin(group, [g for g in range(S.N_GROUPS) if flat_applied[g] is not None])
+                p_gemm = (1.0 / (1.0 + np.exp(-margin[has].astype(np.float64)))).astype(np.float32)
+                if not np.array_equal(margin[has] > 0, res.filter[has] == S.FILTER_PASS) or np.abs(p_gemm - res.tree_score[has]).max() > 2e-6:
+                    raise RuntimeError("internal: the leaf-matrix GEMM and the scoring pass disagree on the applied ensemble")
+                logger.info("leaf-matrix GEMM (MFMA) over %d rows in %.2f ms: FILTER and TREE_SCORE equal the scoring pass", int(has.sum()), ms)
             sel = label >= 0
             if args.evaluate_concordance_contig and args.evaluate_concordance_contig in ref.names:
                 sel &= vt.contig == ref.names.index(args.evaluate_concordance_contig)
