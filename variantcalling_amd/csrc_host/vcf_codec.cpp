@@ -1162,11 +1162,13 @@ static int write_filtered_impl(const ugvc_vcf* h, const char* out_path, const fl
     std::thread& writer = writer_guard.t;
     auto write_blocks = [&](const std::vector<std::string>* cv, size_t nb) {
         const auto t0 = std::chrono::steady_clock::now();
-        for (size_t b = 0; b < nb; ++b) {
-            const std::string& o = (*cv)[b];
-            if (fwrite(o.data(), 1, o.size(), fh) != o.size()) io_ok = false;
-            blk_clen.push_back((uint32_t)o.size());
-        }
+        try {
+            for (size_t b = 0; b < nb; ++b) {
+                const std::string& o = (*cv)[b];
+                if (fwrite(o.data(), 1, o.size(), fh) != o.size()) io_ok = false;
+                blk_clen.push_back((uint32_t)o.size());
+            }
+        } catch (...) { io_ok = false; }                     // (the writer thread: nothing thrown may leave it)
         ns_write += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
     };
     auto flush_blocks = [&](const char* data, size_t size, bool final, bool timed) -> size_t {
@@ -1359,7 +1361,11 @@ static int write_filtered_impl(const ugvc_vcf* h, const char* out_path, const fl
         st.lap("wait for the previous batch's deflate + write");
         const size_t used = gz ? total / kBlk * kBlk : total;
         stream.assign(dst + used, total - used);
-        flusher = std::thread([&flush_blocks, dst, total] { (void)flush_blocks(dst, total, false, false); });
+        // (nothing thrown on the helper thread may leave it - an allocation of a block buffer, a thread that cannot start: the write
+        // is marked failed and the call returns an error instead of the process ending in std::terminate)
+        flusher = std::thread([&flush_blocks, &io_ok, dst, total] {
+            try { (void)flush_blocks(dst, total, false, false); } catch (...) { io_ok = false; }
+        });
         gsel ^= 1;
     }
     if (flusher.joinable()) flusher.join();

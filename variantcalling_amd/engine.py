@@ -273,6 +273,14 @@ class Engine:
         self._check(self.lib.ugvc_reserve(self._h, int(n_variants), int(alleles_len)))
         self.n = self.resident_count()[0]           # (a reservation that re-allocates a resident column empties the context)
 
+    def _follow_resident_count(self):
+        """The cached row count follows what the context holds (0 after a failed upload / boundary call); never raises - it runs
+        in `finally` blocks and must not replace the error that is on its way out."""
+        try:
+            self.n = self.resident_count()[0]
+        except Exception:                                       # noqa: BLE001
+            self.n = 0
+
     def resident_count(self):
         """(rows resident, whether the resident result columns hold a scoring pass over them)."""
         n, sc = C.c_int64(), C.c_int()
@@ -349,7 +357,7 @@ class Engine:
         try:
             self._check(self.lib.ugvc_filter_variants(self._h, C.byref(cv), C.byref(cr)))
         finally:
-            self.n = self.resident_count()[0]
+            self._follow_resident_count()
         return res
 
     def upload_variants(self, vt: S.VariantTable):
@@ -357,7 +365,7 @@ class Engine:
         try:
             self._check(self.lib.ugvc_variants_upload(self._h, C.byref(cv)))
         finally:
-            self.n = self.resident_count()[0]
+            self._follow_resident_count()
 
     def filter_resident(self):
         self._check(self.lib.ugvc_filter_resident(self._h))
@@ -541,7 +549,7 @@ class Engine:
             self._check(self.lib.ugvc_bridging_snvs(self._h, C.byref(cv), _p(ip, _u8p), _p(a, _i32p), _p(b, _i32p),
                                                     _p(d, _i32p), C.byref(prm), _p(oh, _u8p), _p(op, _u8p)))
         finally:
-            self.n = self.resident_count()[0]
+            self._follow_resident_count()
         return oh.astype(bool), op.astype(bool)
 
     # ---- multi-GPU
