@@ -65,7 +65,10 @@ struct StageTimer {
 int pick_threads(int n_threads) {
     if (n_threads > 0) return std::min(n_threads, 256);
     const unsigned hw = std::thread::hardware_concurrency();
-    return (int)std::min<unsigned>(hw ? hw : 1, 64);
+    // (64 at most by default: a tool runs several readers side by side; UGVC_VCF_MAX_THREADS is the measurement knob behind that
+    // number - profiles/r06_reader_threads.txt)
+    static const unsigned cap = [] { const char* e = getenv("UGVC_VCF_MAX_THREADS"); const int v = e ? atoi(e) : 0; return (unsigned)(v > 0 ? std::min(v, 256) : 64); }();
+    return (int)std::min<unsigned>(hw ? hw : 1, cap);
 }
 
 // f(part, lo, hi) over [0, n) cut into `parts` contiguous ranges
